@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — samples/s of the D2R hot path (fwd + bwd + gradient all-reduce + fused AdamW) on N MI355X GPUs.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1 is launched through
+torch.distributed.run, one rank per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* come from the environment).
+Rank 0 prints ONE JSON line.
+
+Workload = BASELINE.json configs[1] ("C2"): synthetic MVSA-Single shape — per-GPU batch 32, text length 128,
+224x224 images at patch 16 (197 ViT tokens), DR_step 3, 12+12 encoder layers, bf16 compute, random-init weights,
+BERT dropout 0.  Weak scaling: the per-GPU batch is fixed as N grows.
+
+Extra objects on the JSON line (tier contract section 4):
+  roofline      the dominant kernel family by GPU time, timed live with HIP events on the launching stream in an
+                instrumented pass of the SAME step right after the timed region (per-launch events would perturb
+                the timed region); `roofline_kernels` lists router pool (K1), route_aggregate (K8) and the
+                cross-attention core (K2) against the HBM roofline, and the GEMM families against the MFMA roofline
+  cpu_baseline  the pinned CPU oracle (oracle/d2r_oracle.py, a port of the reference's maths — the reference itself
+                cannot travel to the GPU box) timed on the host cores for a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress on stderr (keeps the GPU box's silence watchdog fed; stdout carries only the JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--patch", type=int, default=16)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--dr-step", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=8)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="overlap bucketed grad all-reduce with backward")
+    return ap.parse_args()
+
+
+def synthetic_batch(B, L, image_size, device, seed):
+    """ids ~ U{1000..29999} with [:,0]=101, all-ones mask, images ~ N(0,1), labels ~ U{0..2}."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1000, 30000, (B, L), generator=g)
+    ids[:, 0] = 101
+    mask = torch.ones(B, L, dtype=torch.long)
+    tt = torch.zeros(B, L, dtype=torch.long)
+    images = torch.randn(B, 3, image_size, image_size, generator=g)
+    labels = torch.randint(0, 3, (B,), generator=g)
+    return tuple(t.to(device) for t in (ids, mask, tt, labels, images))
+
+
+def cpu_baseline(args, sd_cpu):
+    """Oracle (CPU port of the reference's maths) fwd+bwd on the host cores, bounded sample of the same workload."""
+    import torch
+    from oracle import d2r_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # a 1-GPU box owns a 16-core CPU share; os.cpu_count() reports the whole host
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig(text_layers=args.layers, vision_layers=args.layers, image_size=args.image_size,
+                         patch_size=args.patch, DR_step=args.dr_step)
+    n = args.cpu_samples
+
+    def run(nb):
+        ids, mask, tt, labels, images = synthetic_batch(nb, args.seq, args.image_size, "cpu", seed=0)
+        sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+              for k, v in sd_cpu.items()}
+        t0 = time.time()
+        loss, _, _ = O.forward(sd, cfg, ids, mask, tt, labels, images, train=True)
+        loss.backward()
+        return time.time() - t0
+
+    log("cpu baseline: warm-up sample")
+    run(1)  # warm-up (thread pool, allocator)
+    log(f"cpu baseline: timing {n} samples")
+    dt = run(n)
+    log(f"cpu baseline: {n / dt:.3f} samples/s")
+    return {"value": round(n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} samples of the same workload (L={args.seq}, {(args.image_size // args.patch) ** 2 + 1} image tokens, "
+                      f"{args.layers}+{args.layers} encoder layers, DR_step {args.dr_step}), 1 fwd+bwd iteration, fp32, "
+                      f"torch CPU {torch.get_num_threads()} threads, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from d2r_amd import modules as M
+    from d2r_amd._lib import KernelTimer
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.dp import DataParallel, init_process_group_from_env
+    from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
+
+    log("imports done")
+    rank, world = init_process_group_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(2023)  # reference default seed (run.py:49); identical replicas, then broadcast anyway
+    tc = TextConfig(num_hidden_layers=args.layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vc = VisionConfig(num_hidden_layers=args.layers, image_size=args.image_size, patch_size=args.patch)
+    model = M.UnimoModelF(default_args(DR_step=args.dr_step), vc, tc)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    log("model built on host")
+    model.to(dev).set_compute_dtype(dtype).train()
+    store = ParamStore(model, dtype)
+    log(f"model on {dev}: {store.live_numel() / 1e6:.1f} M live parameters in flat buffers")
+    opt = FusedAdamW(store, lr=3e-5)
+    total_steps = args.warmup + args.steps + 8
+    sched = LinearWarmupSchedule(opt, 0.01 * total_steps, total_steps)
+    dp = DataParallel(store, opt, model, overlap=args.overlap)
+    dp.broadcast_parameters()
+    batch = synthetic_batch(args.batch, args.seq, args.image_size, dev, seed=rank)
+
+    def step():
+        dp.begin_step()
+        loss, logits = model(*batch)
+        loss.backward()
+        dp.reduce_gradients()
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i + 1}/{args.warmup} done")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.item())
+    ms = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+    log(f"timed region: {args.steps} steps, {ms:.2f} ms/step, {value:.1f} samples/s")
+
+    out = {
+        "metric": "samples/sec fwd+bwd", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: synthetic MVSA-Single shape, per-GPU batch %d, seq_len %d, %d image tokens, "
+                               "DR_step %d, %d+%d encoder layers, random-init weights, dropout 0; step = fwd+bwd+grad-allreduce+AdamW"
+                               % (args.batch, args.seq, (args.image_size // args.patch) ** 2 + 1, args.dr_step, args.layers, args.layers),
+                   "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}"},
+        "final_loss": round(loss_val, 5),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        with KernelTimer() as kt:
+            for _ in range(2):
+                step()
+        summ = kt.summary()
+        kernels = []
+        for name, r in summ.items():
+            calls, t_s = r["calls"], r["ms"] * 1e-3
+            if t_s <= 0:
+                continue
+            ent = {"kernel": name, "launches_per_step": calls // 2, "ms_per_step": round(r["ms"] / 2, 4),
+                   "avg_us": round(r["ms"] * 1e3 / calls, 2)}
+            if name.startswith("gemm_"):
+                key = "bf16" if "bf16" in name else "f32"
+                ach = r["flops"] / t_s / 1e12
+                ent.update(bound="mfma", achieved=round(ach, 2), peak=MFMA_PEAK_TF[key], unit="TFLOP/s",
+                           frac=round(ach / MFMA_PEAK_TF[key], 4))
+            else:
+                nbytes = r["algo_bytes"] if r["algo_bytes"] > 0 else r["bytes"]
+                if nbytes > 0:
+                    ach = nbytes / t_s / 1e9
+                    if name.startswith("xattn_core") and name.endswith("bwd"):
+                        ach = 2 * summ.get("xattn_core_fwd", r)["algo_bytes"] / t_s / 1e9  # bwd = 2x fwd bytes
+                    ent.update(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=round(ach / HBM_PEAK_GBS, 4))
+            kernels.append(ent)
+        kernels.sort(key=lambda e: -e["ms_per_step"])
+        total_ms = sum(e["ms_per_step"] for e in kernels)
+        dom = next((e for e in kernels if "bound" in e), None)
+        if dom is not None:
+            out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
+                               "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": None,
+                               "avg_launch_us": dom["avg_us"], "share_of_kernel_time": round(dom["ms_per_step"] / max(total_ms, 1e-9), 3)}
+        log("instrumented (per-kernel HIP event) pass done")
+        out["roofline_kernels"] = kernels[:24]
+        out["kernel_ms_per_step_total"] = round(total_ms, 3)
+
+    if sd_cpu is not None:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, sd_cpu)
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        except Exception as e:  # the baseline is a reported extra; never lose the GPU number because of it
+            out["cpu_baseline"] = {"error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

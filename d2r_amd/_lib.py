@@ -1,0 +1,162 @@
+"""ctypes binding of libd2r_hip.so (the C ABI declared in include/d2r_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.  The
+product path never routes through PyTorch reference code or the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libd2r_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU, ACT_QUICK_GELU, ACT_TANH_RELU, ACT_SIGMOID = range(7)
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("c_dtype", i32), ("layout", i32), ("act", i32),
+        ("M", i32), ("N", i32), ("K", i32), ("nb", i32), ("nh", i32),
+        ("alpha", f32), ("beta", f32),
+        ("A", vp), ("lda", i64), ("sAb", i64), ("sAh", i64),
+        ("B", vp), ("ldb", i64), ("sBb", i64), ("sBh", i64),
+        ("C", vp), ("ldc", i64), ("sCb", i64), ("sCh", i64),
+        ("bias", vp),
+        ("residual", vp), ("ldr", i64), ("sRb", i64), ("sRh", i64),
+        ("preact", vp),
+        ("workspace", vp), ("workspace_bytes", sz),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/d2r_hip.h declares
+SIGNATURES = {
+    "d2r_version": (C.c_char_p, []),
+    "d2r_last_error": (C.c_char_p, []),
+    "d2r_gemm": (i32, [C.POINTER(GemmDesc), vp]),
+    "d2r_gemm_tuning": (None, [i32, i32, i32]),
+    "d2r_softmax_fwd": (i32, [i32, i32, vp, vp, i64, i64, i32, f32, vp, i64, vp]),
+    "d2r_softmax_bwd": (i32, [i32, i32, vp, vp, vp, i64, i64, i32, f32, vp]),
+    "d2r_layernorm_fwd": (i32, [i32, vp, vp, vp, f32, i64, i32, vp, vp, vp, vp]),
+    "d2r_layernorm_bwd_workspace": (sz, [i64, i32]),
+    "d2r_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "d2r_l2norm_fwd": (i32, [i32, vp, vp, vp, i64, i32, vp]),
+    "d2r_l2norm_bwd": (i32, [i32, vp, vp, vp, vp, i64, i32, vp]),
+    "d2r_act_bwd": (i32, [i32, i32, vp, vp, vp, i64, vp]),
+    "d2r_act_fwd": (i32, [i32, i32, vp, vp, i64, vp]),
+    "d2r_sqdiff_fwd": (i32, [i32, vp, vp, vp, i64, vp]),
+    "d2r_sqdiff_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
+    "d2r_muladd_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),
+    "d2r_muladd_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
+    "d2r_lerp_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),
+    "d2r_lerp_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "d2r_add": (i32, [i32, vp, vp, vp, i64, vp]),
+    "d2r_lincomb": (i32, [C.POINTER(vp), C.POINTER(f32), i32, vp, vp]),
+    "d2r_axpby": (i32, [i32, f32, vp, f32, vp, i64, vp]),
+    "d2r_cast": (i32, [i32, vp, i32, vp, i64, vp]),
+    "d2r_colsum_workspace": (sz, [i64, i32]),
+    "d2r_colsum": (i32, [i32, vp, i64, i64, i32, vp, vp, sz, vp]),
+    "d2r_meanpool_fwd": (i32, [i32, C.POINTER(vp), i32, i32, i32, i32, vp, vp]),
+    "d2r_meanpool_bwd": (i32, [i32, vp, i32, i32, i32, vp, i32, vp]),
+    "d2r_route_aggregate_fwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), vp, i32, i32, i32, i32, C.POINTER(vp), vp, vp]),
+    "d2r_route_aggregate_bwd_workspace": (sz, [i32, i32, i32, i32]),
+    "d2r_route_aggregate_bwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), vp,
+                                      i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), vp, vp, sz, vp]),
+    "d2r_saf_gate_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "d2r_saf_gate_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "d2r_jsdiv_fwd": (i32, [vp, vp, i32, vp, vp]),
+    "d2r_jsdiv_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp]),
+    "d2r_ce_fwd": (i32, [vp, vp, i32, i32, vp, vp]),
+    "d2r_ce_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "d2r_block_merge_fwd": (i32, [i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "d2r_block_merge_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "d2r_bert_embed_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "d2r_bert_embed_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i64, vp, vp, vp, vp]),
+    "d2r_patchify": (i32, [i32, vp, i32, i32, i32, i32, vp, vp]),
+    "d2r_clip_embed_finish": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
+    "d2r_clip_embed_bwd": (i32, [i32, vp, i32, i32, i32, vp, vp, vp]),
+    "d2r_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
+}
+
+
+class D2RError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads libd2r_hip.so once; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise D2RError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m d2r_amd.build` "
+            "(or __graft_entry__.build()). d2r_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch; let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().d2r_last_error().decode(errors="replace")
+        raise D2RError(f"{what or 'libd2r_hip'} failed with status {rc}: {msg}")
+
+
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launching stream (bench.py's roofline leg).
+    Usage: ``with KernelTimer() as kt: step()`` then ``kt.summary()`` -> {group: (calls, total_ms, meta sums)}."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = None
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for group, meta, e0, e1 in self.records:
+            rec = out.setdefault(group, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0, algo_bytes=0.0))
+            rec["calls"] += 1
+            rec["ms"] += e0.elapsed_time(e1)
+            rec["flops"] += float(meta.get("flops", 0.0))
+            rec["bytes"] += float(meta.get("bytes", 0.0))
+            rec["algo_bytes"] += float(meta.get("algo_bytes", 0.0))
+        return out
+
+
+_timer = None
+
+
+def call(name: str, *args, meta=None):
+    if _timer is None:
+        rc = getattr(load(), name)(*args)
+    else:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()  # torch's current stream == the stream every d2r kernel is launched on
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        m = meta or {}
+        _timer.records.append((m.get("group", name), m, e0, e1))
+    if rc != 0:
+        check(rc, name)

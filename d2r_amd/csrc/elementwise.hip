@@ -1,0 +1,273 @@
+// elementwise.hip — 16-byte vectorised elementwise kernels (activation fwd/bwd, squared difference, FiLM
+// mul-add, gate lerp, axpby, casts, AdamW).  Grid-stride over 16-B packs with a scalar tail; when a pointer is
+// not 16-B aligned the scalar path is used for everything.
+#include "common.h"
+
+template <int NIN, int NOUT>
+struct EwPtrs {
+  const void* in[NIN > 0 ? NIN : 1];
+  void* out[NOUT];
+};
+
+// F::apply(const float (&in)[NIN], float (&out)[NOUT])
+template <typename T, int NIN, int NOUT, typename F>
+__global__ __launch_bounds__(256) void ew_kernel(EwPtrs<NIN, NOUT> p, int64_t n, int vec_ok, F f) {
+  constexpr int VEC = PackOf<T>::N;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t npk = vec_ok ? n / VEC : 0;
+  for (int64_t k = tid; k < npk; k += nthreads) {
+    Pack<T, VEC> pin[NIN > 0 ? NIN : 1], pout[NOUT];
+#pragma unroll
+    for (int a = 0; a < NIN; ++a) pin[a] = ld_pack<T, VEC>(reinterpret_cast<const T*>(p.in[a]) + k * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float x[NIN > 0 ? NIN : 1], y[NOUT];
+#pragma unroll
+      for (int a = 0; a < NIN; ++a) x[a] = to_f<T>(pin[a].v[j]);
+      f.apply(x, y);
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) pout[o].v[j] = from_f<T>(y[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) st_pack<T, VEC>(reinterpret_cast<T*>(p.out[o]) + k * VEC, pout[o]);
+  }
+  for (int64_t e = npk * VEC + tid; e < n; e += nthreads) {
+    float x[NIN > 0 ? NIN : 1], y[NOUT];
+#pragma unroll
+    for (int a = 0; a < NIN; ++a) x[a] = to_f<T>(reinterpret_cast<const T*>(p.in[a])[e]);
+    f.apply(x, y);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) reinterpret_cast<T*>(p.out[o])[e] = from_f<T>(y[o]);
+  }
+}
+
+template <int NIN, int NOUT, typename F>
+static int ew_launch(const char* name, int dtype, const EwPtrs<NIN, NOUT>& p, int64_t n, F f, void* stream) {
+  if (n < 0) return d2r_fail(D2R_ERR_INVALID, "%s: negative size", name);
+  if (n == 0) return D2R_OK;
+  int vec_ok = 1;
+  for (int a = 0; a < NIN; ++a) {
+    if (!p.in[a]) return d2r_fail(D2R_ERR_INVALID, "%s: null input %d", name, a);
+    vec_ok &= d2r_aligned16(p.in[a]);
+  }
+  for (int o = 0; o < NOUT; ++o) {
+    if (!p.out[o]) return d2r_fail(D2R_ERR_INVALID, "%s: null output %d", name, o);
+    vec_ok &= d2r_aligned16(p.out[o]);
+  }
+  const int64_t work = n / (dtype == D2R_BF16 ? 8 : 4) + 1;
+  int blocks = (int)((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == D2R_BF16) hipLaunchKernelGGL((ew_kernel<bf16_t, NIN, NOUT, F>), dim3(blocks), dim3(256), 0, st, p, n, vec_ok, f);
+  else if (dtype == D2R_F32) hipLaunchKernelGGL((ew_kernel<float, NIN, NOUT, F>), dim3(blocks), dim3(256), 0, st, p, n, vec_ok, f);
+  else return d2r_fail(D2R_ERR_INVALID, "%s: bad dtype %d", name, dtype);
+  return d2r_check_launch(name);
+}
+
+// ---- functors -----------------------------------------------------------------------------------------
+struct ActFwdF {
+  int act;
+  __device__ void apply(const float (&x)[1], float (&y)[1]) const { y[0] = act_apply(act, x[0]); }
+};
+struct ActBwdF {  // in: dY, ref
+  int act;
+  __device__ void apply(const float (&x)[2], float (&y)[1]) const { y[0] = x[0] * act_grad(act, x[1]); }
+};
+struct SqDiffFwdF {
+  __device__ void apply(const float (&x)[2], float (&y)[1]) const {
+    const float d = x[0] - x[1];
+    y[0] = d * d;
+  }
+};
+struct SqDiffBwdF {  // in: a, b, dout -> da, db
+  __device__ void apply(const float (&x)[3], float (&y)[2]) const {
+    const float g = 2.f * (x[0] - x[1]) * x[2];
+    y[0] = g;
+    y[1] = -g;
+  }
+};
+struct MulAddFwdF {  // a, s, h -> a*s + h
+  __device__ void apply(const float (&x)[3], float (&y)[1]) const { y[0] = x[0] * x[1] + x[2]; }
+};
+struct MulAddBwdF {  // a, s, dout -> da, ds
+  __device__ void apply(const float (&x)[3], float (&y)[2]) const {
+    y[0] = x[2] * x[1];
+    y[1] = x[2] * x[0];
+  }
+};
+struct LerpFwdF {  // g, a, b -> g*a + (1-g)*b
+  __device__ void apply(const float (&x)[3], float (&y)[1]) const { y[0] = x[0] * x[1] + (1.f - x[0]) * x[2]; }
+};
+struct LerpBwdF {  // g, a, b, dout -> dg, da, db
+  __device__ void apply(const float (&x)[4], float (&y)[3]) const {
+    y[0] = x[3] * (x[1] - x[2]);
+    y[1] = x[3] * x[0];
+    y[2] = x[3] * (1.f - x[0]);
+  }
+};
+struct AddF {
+  __device__ void apply(const float (&x)[2], float (&y)[1]) const { y[0] = x[0] + x[1]; }
+};
+struct AxpbyF {  // x, y_old -> alpha*x + beta*y_old
+  float alpha, beta;
+  __device__ void apply(const float (&x)[2], float (&y)[1]) const { y[0] = alpha * x[0] + (beta != 0.f ? beta * x[1] : 0.f); }
+};
+
+extern "C" int d2r_act_fwd(int dtype, int act, const void* X, void* Y, int64_t n, void* stream) {
+  EwPtrs<1, 1> p{{X}, {Y}};
+  return ew_launch("d2r_act_fwd", dtype, p, n, ActFwdF{act}, stream);
+}
+extern "C" int d2r_act_bwd(int dtype, int act, const void* dY, const void* ref, void* dX, int64_t n, void* stream) {
+  EwPtrs<2, 1> p{{dY, ref}, {dX}};
+  return ew_launch("d2r_act_bwd", dtype, p, n, ActBwdF{act}, stream);
+}
+extern "C" int d2r_sqdiff_fwd(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream) {
+  EwPtrs<2, 1> p{{a, b}, {out}};
+  return ew_launch("d2r_sqdiff_fwd", dtype, p, n, SqDiffFwdF{}, stream);
+}
+extern "C" int d2r_sqdiff_bwd(int dtype, const void* a, const void* b, const void* dout, void* da, void* db,
+                              int64_t n, void* stream) {
+  EwPtrs<3, 2> p{{a, b, dout}, {da, db}};
+  return ew_launch("d2r_sqdiff_bwd", dtype, p, n, SqDiffBwdF{}, stream);
+}
+extern "C" int d2r_muladd_fwd(int dtype, const void* a, const void* s, const void* h, void* out, int64_t n,
+                              void* stream) {
+  EwPtrs<3, 1> p{{a, s, h}, {out}};
+  return ew_launch("d2r_muladd_fwd", dtype, p, n, MulAddFwdF{}, stream);
+}
+extern "C" int d2r_muladd_bwd(int dtype, const void* a, const void* s, const void* dout, void* da, void* ds,
+                              int64_t n, void* stream) {
+  EwPtrs<3, 2> p{{a, s, dout}, {da, ds}};
+  return ew_launch("d2r_muladd_bwd", dtype, p, n, MulAddBwdF{}, stream);
+}
+extern "C" int d2r_lerp_fwd(int dtype, const void* g, const void* a, const void* b, void* out, int64_t n,
+                            void* stream) {
+  EwPtrs<3, 1> p{{g, a, b}, {out}};
+  return ew_launch("d2r_lerp_fwd", dtype, p, n, LerpFwdF{}, stream);
+}
+extern "C" int d2r_lerp_bwd(int dtype, const void* g, const void* a, const void* b, const void* dout, void* dg,
+                            void* da, void* db, int64_t n, void* stream) {
+  EwPtrs<4, 3> p{{g, a, b, dout}, {dg, da, db}};
+  return ew_launch("d2r_lerp_bwd", dtype, p, n, LerpBwdF{}, stream);
+}
+extern "C" int d2r_axpby(int dtype, float alpha, const void* x, float beta, void* y, int64_t n, void* stream) {
+  EwPtrs<2, 1> p{{x, y}, {y}};
+  return ew_launch("d2r_axpby", dtype, p, n, AxpbyF{alpha, beta}, stream);
+}
+
+extern "C" int d2r_add(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream) {
+  EwPtrs<2, 1> p{{a, b}, {out}};
+  return ew_launch("d2r_add", dtype, p, n, AddF{}, stream);
+}
+
+// out[0] = sum_k coef[k] * x_k[0]  (scalar loss combination: CE + js terms, models/unimo_model.py:160,
+// models/modeling_unimo.py:849)
+struct LinCombArgs {
+  const float* x[8];
+  float c[8];
+};
+__global__ void lincomb_kernel(LinCombArgs a, int n, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < n; ++k) t += a.c[k] * a.x[k][0];
+    out[0] = t;
+  }
+}
+extern "C" int d2r_lincomb(const float* const* h_x, const float* h_coef, int n, float* out, void* stream) {
+  D2R_REQUIRE(h_x && h_coef && out && n >= 1 && n <= 8, "d2r_lincomb: bad arguments");
+  LinCombArgs a;
+  for (int k = 0; k < 8; ++k) {
+    a.x[k] = k < n ? h_x[k] : nullptr;
+    a.c[k] = k < n ? h_coef[k] : 0.f;
+    D2R_REQUIRE(k >= n || a.x[k], "d2r_lincomb: null input %d", k);
+  }
+  hipLaunchKernelGGL(lincomb_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, n, out);
+  return d2r_check_launch("d2r_lincomb");
+}
+
+// ---- casts ---------------------------------------------------------------------------------------------
+template <typename S, typename Dt>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, Dt* __restrict__ dst, int64_t n) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n / 4;
+  for (int64_t k = tid; k < n4; k += nthreads) {
+    Pack<S, 4> a = ld_pack<S, 4>(src + k * 4);
+    Pack<Dt, 4> b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.v[j] = from_f<Dt>(to_f<S>(a.v[j]));
+    st_pack<Dt, 4>(dst + k * 4, b);
+  }
+  for (int64_t e = n4 * 4 + tid; e < n; e += nthreads) dst[e] = from_f<Dt>(to_f<S>(src[e]));
+}
+
+extern "C" int d2r_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream) {
+  D2R_REQUIRE(src && dst && n >= 0, "d2r_cast: bad arguments");
+  D2R_REQUIRE(d2r_aligned16(src) && d2r_aligned16(dst), "d2r_cast: pointers must be 16-byte aligned");
+  if (n == 0) return D2R_OK;
+  int blocks = (int)((n / 4 + 256) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == D2R_F32 && dst_dtype == D2R_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == D2R_BF16 && dst_dtype == D2R_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == D2R_F32 && dst_dtype == D2R_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else if (src_dtype == D2R_BF16 && dst_dtype == D2R_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  else return d2r_fail(D2R_ERR_INVALID, "d2r_cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
+  return d2r_check_launch("d2r_cast");
+}
+
+// ---- K14 AdamW over a flat fp32 range (modules/train.py:287-322; torch.optim.AdamW semantics) -----------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ w16, int64_t n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n / 4;
+  auto upd = [&](float& wi, float gi, float& mi, float& vi) {
+    gi *= gscale;
+    wi *= (1.f - lr * wd);                       // decoupled weight decay
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    wi -= (lr / bc1) * (mi / denom);
+  };
+  for (int64_t k = tid; k < n4; k += nthreads) {
+    Pack<float, 4> pw = ld_pack<float, 4>(w + k * 4), pg = ld_pack<float, 4>(g + k * 4);
+    Pack<float, 4> pm = ld_pack<float, 4>(m + k * 4), pv = ld_pack<float, 4>(v + k * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) upd(pw.v[j], pg.v[j], pm.v[j], pv.v[j]);
+    st_pack<float, 4>(w + k * 4, pw);
+    st_pack<float, 4>(m + k * 4, pm);
+    st_pack<float, 4>(v + k * 4, pv);
+    if (w16) {
+      Pack<bf16_t, 4> ph;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ph.v[j] = (bf16_t)pw.v[j];
+      st_pack<bf16_t, 4>(w16 + k * 4, ph);
+    }
+  }
+  for (int64_t e = n4 * 4 + tid; e < n; e += nthreads) {
+    float wi = w[e], mi = m[e], vi = v[e];
+    upd(wi, g[e], mi, vi);
+    w[e] = wi; m[e] = mi; v[e] = vi;
+    if (w16) w16[e] = (bf16_t)wi;
+  }
+}
+
+extern "C" int d2r_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                              float grad_scale, void* stream) {
+  D2R_REQUIRE(w && g && m && v && n >= 0 && step >= 1, "d2r_adamw_step: bad arguments");
+  D2R_REQUIRE(d2r_aligned16(w) && d2r_aligned16(g) && d2r_aligned16(m) && d2r_aligned16(v), "d2r_adamw_step: pointers must be 16-byte aligned");
+  D2R_REQUIRE(!w_bf16 || (reinterpret_cast<uintptr_t>(w_bf16) & 7u) == 0, "d2r_adamw_step: bf16 shadow must be 8-byte aligned");
+  if (n == 0) return D2R_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  int blocks = (int)((n / 4 + 256) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (bf16_t*)w_bf16, n, lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  return d2r_check_launch("d2r_adamw_step");
+}

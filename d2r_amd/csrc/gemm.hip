@@ -1,0 +1,511 @@
+// gemm.hip — K11 gemm_bias_act: LDS-tiled MFMA GEMM family for gfx950 (wave64).
+//
+//   C[z] = epilogue(alpha * A[z] x B[z]),   z = batch index (two-level strides: b*s?b + h*s?h)
+//
+// bf16 inputs use v_mfma_f32_16x16x32_bf16 (each lane feeds 8 consecutive k), fp32 inputs the exact-f32
+// v_mfma_f32_16x16x4_f32.  Operand tiles are staged global -> registers -> LDS with 16-byte accesses, the loads
+// of tile t+1 being issued before the MFMAs of tile t.  An operand whose global layout is k-contiguous
+// (A of NT/NN, B of NT) sits in LDS as [row][k] and a fragment is one ds_read_b128; an operand that is
+// k-STRIDED in memory (B of NN, A and B of TN) is kept as loaded, [k][row], and its bf16 fragments are fetched
+// with two ds_read_b64_tr_b16 (hardware transpose read; lane map pinned by tests/probes/tr_probe.hip), fp32
+// fragments with plain ds_read_b32 — no transposing stores anywhere.
+//
+// Weight-gradient GEMMs (TN, 768x768 outputs reduced over thousands of tokens) have few output tiles: they are
+// split along K over gridDim.z into fp32 partial slabs in a caller workspace and combined by a fixed-order
+// reduce kernel (deterministic; no float atomics).
+//
+// Replaces (reference file:line): every F.linear / torch.bmm / torch.matmul of the hot path — see
+// include/d2r_hip.h, section K11.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  const void* R;
+  void* P;
+  float* ws;  // split-K partial slabs [splits][M][N] (fp32) or null
+  int M, N, K, nh, splits, tiles_per_split;
+  int64_t lda, ldb, ldc, ldr;
+  int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh;
+  float alpha, beta;
+  int act, c_dtype, vecA, vecB, vecC;
+};
+
+// Loads VEC consecutive elements [c0, c0+VEC) of a row; zero outside [0, climit) or when !row_ok.
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_guard(const T* rowp, int c0, int climit, bool row_ok, bool vec_ok) {
+  Pack<T, VEC> r;
+  if (row_ok && vec_ok && c0 + VEC <= climit) {
+    r = ld_pack<T, VEC>(rowp + c0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) r.v[j] = (row_ok && c0 + j < climit) ? rowp[c0 + j] : from_f<T>(0.f);
+  }
+  return r;
+}
+
+__device__ __forceinline__ void store_c(void* C, int c_dtype, int64_t idx, float v) {
+  if (c_dtype == D2R_BF16) reinterpret_cast<bf16_t*>(C)[idx] = (bf16_t)v;
+  else reinterpret_cast<float*>(C)[idx] = v;
+}
+__device__ __forceinline__ float load_c(const void* C, int c_dtype, int64_t idx) {
+  return c_dtype == D2R_BF16 ? (float)reinterpret_cast<const bf16_t*>(C)[idx] : reinterpret_cast<const float*>(C)[idx];
+}
+
+template <typename T, int LAYOUT, int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int BK = IS_BF16 ? 64 : 16;
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int NT = 256;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave output tile
+  constexpr int TM = WM / 16, TN = WN / 16;            // 16x16 MFMA tiles per wave
+  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of 16");
+  constexpr bool A_KCONT = (LAYOUT != D2R_GEMM_TN);  // A stored [M,K]
+  constexpr bool B_KCONT = (LAYOUT == D2R_GEMM_NT);  // B stored [N,K]
+  // LDS row strides (elements): k-contiguous image [rows][BK + pad]; k-strided image [BK][rows + pad]
+  constexpr int LDK = BK + (IS_BF16 ? 8 : 1);        // bf16: 144 B rows -> conflict-free ds_read_b128
+  constexpr int LDA_T = BM + (IS_BF16 ? 8 : 16);
+  constexpr int LDB_T = BN + (IS_BF16 ? 8 : 16);
+  constexpr int SZ_A = A_KCONT ? BM * LDK : BK * LDA_T;
+  constexpr int SZ_B = B_KCONT ? BN * LDK : BK * LDB_T;
+  constexpr int CH_A = BM * BK / VEC, CH_B = BN * BK / VEC;  // 16-B chunks per tile
+  constexpr int IT_A = (CH_A + NT - 1) / NT, IT_B = (CH_B + NT - 1) / NT;
+
+  // one LDS array: two operand-tile buffers (double buffering); reused by the vectorised bf16 epilogue
+  constexpr int SZ_BUF = SZ_A + SZ_B;
+  constexpr int SZ_EPI = 4 * WM * (WN + 8);  // bf16 C staging, per wave [WM][WN+8]
+  constexpr int SZ_ALL = (NBUF * SZ_BUF * (int)sizeof(T) >= SZ_EPI * 2) ? NBUF * SZ_BUF : (SZ_EPI * 2 + (int)sizeof(T) - 1) / (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) T smem[SZ_ALL];
+  T* As = smem;
+  T* Bs = smem + SZ_A;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int z = blockIdx.z, split = 0;
+  if (g.splits > 1) {
+    split = z;
+    z = 0;
+  }
+  const int zb = z / g.nh, zh = z % g.nh;
+  const T* A = reinterpret_cast<const T*>(g.A) + zb * g.sAb + zh * g.sAh;
+  const T* B = reinterpret_cast<const T*>(g.B) + zb * g.sBb + zh * g.sBh;
+  const bool vecA = g.vecA != 0, vecB = g.vecB != 0;
+
+  Pack<T, VEC> ra[IT_A], rb[IT_B];
+
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < IT_A; ++it) {
+      const int c = tid + it * NT;
+      if (CH_A % NT == 0 || c < CH_A) {
+        if constexpr (A_KCONT) {
+          const int r = c / (BK / VEC), kc = (c % (BK / VEC)) * VEC;
+          const int row = m0 + r;
+          ra[it] = load_guard<T, VEC>(A + (int64_t)row * g.lda, k0 + kc, g.K, row < g.M, vecA);
+        } else {  // stored [K][M]
+          const int k = c / (BM / VEC), rc = (c % (BM / VEC)) * VEC;
+          const int row = k0 + k;
+          ra[it] = load_guard<T, VEC>(A + (int64_t)row * g.lda, m0 + rc, g.M, row < g.K, vecA);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT_B; ++it) {
+      const int c = tid + it * NT;
+      if (CH_B % NT == 0 || c < CH_B) {
+        if constexpr (B_KCONT) {
+          const int r = c / (BK / VEC), kc = (c % (BK / VEC)) * VEC;
+          const int row = n0 + r;
+          rb[it] = load_guard<T, VEC>(B + (int64_t)row * g.ldb, k0 + kc, g.K, row < g.N, vecB);
+        } else {  // stored [K][N]
+          const int k = c / (BN / VEC), rc = (c % (BN / VEC)) * VEC;
+          const int row = k0 + k;
+          rb[it] = load_guard<T, VEC>(B + (int64_t)row * g.ldb, n0 + rc, g.N, row < g.K, vecB);
+        }
+      }
+    }
+  };
+
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < IT_A; ++it) {
+      const int c = tid + it * NT;
+      if (CH_A % NT == 0 || c < CH_A) {
+        if constexpr (A_KCONT) {
+          const int r = c / (BK / VEC), kc = (c % (BK / VEC)) * VEC;
+          if constexpr (IS_BF16) {
+            st_pack<T, VEC>(&As[r * LDK + kc], ra[it]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) As[r * LDK + kc + j] = ra[it].v[j];
+          }
+        } else {
+          const int k = c / (BM / VEC), rc = (c % (BM / VEC)) * VEC;
+          st_pack<T, VEC>(&As[k * LDA_T + rc], ra[it]);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT_B; ++it) {
+      const int c = tid + it * NT;
+      if (CH_B % NT == 0 || c < CH_B) {
+        if constexpr (B_KCONT) {
+          const int r = c / (BK / VEC), kc = (c % (BK / VEC)) * VEC;
+          if constexpr (IS_BF16) {
+            st_pack<T, VEC>(&Bs[r * LDK + kc], rb[it]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) Bs[r * LDK + kc + j] = rb[it].v[j];
+          }
+        } else {
+          const int k = c / (BN / VEC), rc = (c % (BN / VEC)) * VEC;
+          st_pack<T, VEC>(&Bs[k * LDB_T + rc], rb[it]);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tq = (lane & 15) >> 2, tp = lane & 3;  // transpose-read address roles inside a 16-lane group
+  const int nk_all = (g.K + BK - 1) / BK;
+  int t_begin = 0, t_end = nk_all;
+  if (g.splits > 1) {
+    t_begin = split * g.tiles_per_split;
+    t_end = min(nk_all, t_begin + g.tiles_per_split);
+  }
+  // pipeline: global loads of tile t+1 are issued before the MFMAs of tile t and written to the OTHER LDS buffer
+  // after them; one barrier per K-tile
+  int cur = 0;
+  if (t_begin < t_end) {
+    prefetch(t_begin * BK);
+    if constexpr (NBUF == 2) stage();
+  }
+  if constexpr (NBUF == 2) __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
+    if constexpr (NBUF == 1) {  // single buffer: write, barrier, then issue the next tile's loads
+      stage();
+      __syncthreads();
+    }
+    if (more) prefetch((t + 1) * BK);
+    if constexpr (NBUF == 2) {
+      As = smem + cur * SZ_BUF;
+      Bs = As + SZ_A;
+    }
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if constexpr (A_KCONT) {
+            af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm0 + i * 16 + fr) * LDK + kk * 32 + fq * 8]);
+          } else {
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const T* p0 = &As[(kk * 32 + fq * 8 + tq) * LDA_T + wm0 + i * 16 + tp * 4];
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * LDA_T));
+            af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (B_KCONT) {
+            bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn0 + j * 16 + fr) * LDK + kk * 32 + fq * 8]);
+          } else {
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const T* p0 = &Bs[(kk * 32 + fq * 8 + tq) * LDB_T + wn0 + j * 16 + tp * 4];
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * LDB_T));
+            bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = A_KCONT ? As[(wm0 + i * 16 + fr) * LDK + ks * 4 + fq] : As[(ks * 4 + fq) * LDA_T + wm0 + i * 16 + fr];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[j] = B_KCONT ? Bs[(wn0 + j * 16 + fr) * LDK + ks * 4 + fq] : Bs[(ks * 4 + fq) * LDB_T + wn0 + j * 16 + fr];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if constexpr (NBUF == 2) {
+      if (more) {
+        As = smem + (cur ^ 1) * SZ_BUF;
+        Bs = As + SZ_A;
+        stage();
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg -------------
+  if (g.splits > 1) {  // raw fp32 partial slab; the reduce kernel applies alpha/beta
+    float* slab = g.ws + (int64_t)split * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 16 + fr;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm0 + i * 16 + fq * 4 + r;
+          if (row < g.M) slab[(int64_t)row * g.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  const int64_t cz = zb * g.sCb + zh * g.sCh;
+  const int64_t rz = zb * g.sRb + zh * g.sRh;
+  if (g.c_dtype == D2R_BF16 && g.vecC) {
+    // bf16 output: the MFMA layout gives each lane one column of four rows (2-byte stores, 32 B segments).
+    // Stage v = alpha*acc + bias per wave in LDS as bf16 [WM][WN+8], then each lane handles 8 consecutive columns
+    // of one row: 16-byte loads of residual / old C, 16-byte stores of preact and C (8 lanes = one 128 B row).
+    constexpr int LDE = WN + 8;
+    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem) + wave * WM * LDE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 16 + fr;
+        const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(i * 16 + fq * 4 + r) * LDE + j * 16 + fr] = (bf16_t)(g.alpha * acc[i][j][r] + bv);
+      }
+    // same-wave hand-off through LDS: wait for the wave's own ds_writes (no block barrier: regions are private)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = WN / 8;  // 16-byte chunks per row
+    bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C);
+    bf16_t* Pg = reinterpret_cast<bf16_t*>(g.P);
+    const bf16_t* Rg = reinterpret_cast<const bf16_t*>(g.R);
+#pragma unroll
+    for (int it = 0; it < WM * CPR / 64; ++it) {
+      const int e = it * 64 + lane;
+      const int rl = e / CPR, ch = e % CPR;
+      const int row = m0 + wm0 + rl, col = n0 + wn0 + ch * 8;
+      if (row >= g.M || col >= g.N) continue;
+      const Pack<bf16_t, 8> pv = ld_pack<bf16_t, 8>(Cs + rl * LDE + ch * 8);
+      const int64_t ci = cz + (int64_t)row * g.ldc + col;
+      const int64_t ri = rz + (int64_t)row * g.ldr + col;
+      if (col + 8 <= g.N) {
+        if (Pg) st_pack<bf16_t, 8>(Pg + ci, pv);
+        Pack<bf16_t, 8> rv, cv, ov;
+        if (Rg) rv = ld_pack<bf16_t, 8>(Rg + ri);
+        if (g.beta != 0.f) cv = ld_pack<bf16_t, 8>(Cg + ci);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float v = act_apply(g.act, (float)pv.v[u]);
+          if (Rg) v += (float)rv.v[u];
+          if (g.beta != 0.f) v += g.beta * (float)cv.v[u];
+          ov.v[u] = (bf16_t)v;
+        }
+        st_pack<bf16_t, 8>(Cg + ci, ov);
+      } else {
+        for (int u = 0; u < 8 && col + u < g.N; ++u) {
+          if (Pg) Pg[ci + u] = pv.v[u];
+          float v = act_apply(g.act, (float)pv.v[u]);
+          if (Rg) v += (float)Rg[ri + u];
+          if (g.beta != 0.f) v += g.beta * (float)Cg[ci + u];
+          Cg[ci + u] = (bf16_t)v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 16 + fr;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm0 + i * 16 + fq * 4 + r;
+        if (row >= g.M) continue;
+        float v = g.alpha * acc[i][j][r] + bv;
+        const int64_t ci = cz + (int64_t)row * g.ldc + col;
+        if (g.P) store_c(g.P, g.c_dtype, ci, v);
+        v = act_apply(g.act, v);
+        if (g.R) v += load_c(g.R, g.c_dtype, rz + (int64_t)row * g.ldr + col);
+        if (g.beta != 0.f) v += g.beta * load_c(g.C, g.c_dtype, ci);
+        store_c(g.C, g.c_dtype, ci, v);
+      }
+    }
+  }
+}
+
+// C[m,n] = epilogue(alpha * sum_s ws[s][m][n])   (fixed order over s; same epilogue as the main kernel)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+  const int64_t total = (int64_t)g.M * g.N;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < g.splits; ++k) s += g.ws[(int64_t)k * total + idx];
+    const int m = (int)(idx / g.N), n = (int)(idx - (int64_t)m * g.N);
+    const int64_t ci = (int64_t)m * g.ldc + n;
+    float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f);
+    if (g.P) store_c(g.P, g.c_dtype, ci, v);
+    v = act_apply(g.act, v);
+    if (g.R) v += load_c(g.R, g.c_dtype, (int64_t)m * g.ldr + n);
+    if (g.beta != 0.f) v += g.beta * load_c(g.C, g.c_dtype, ci);
+    store_c(g.C, g.c_dtype, ci, v);
+  }
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+// tuning switches (A/B in one process: tests/bench_gemm.py); defaults are the measured winners
+static int g_nbuf = env_int("D2R_GEMM_NBUF", 1);
+static int g_vepi = env_int("D2R_GEMM_VEPI", 1);
+static int g_tile = env_int("D2R_GEMM_TILE", -1);
+extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
+  g_nbuf = nbuf;
+  g_vepi = vepi;
+  g_tile = tile;
+}
+
+template <typename T, int LAYOUT, int BM, int BN, int WM_, int WN_>
+static void launch_tile(const GemmArgs& a, int gz, hipStream_t st) {
+  dim3 grid(d2r_cdiv(a.N, BN), d2r_cdiv(a.M, BM), gz);
+  if (g_nbuf == 2) hipLaunchKernelGGL((gemm_kernel<T, LAYOUT, BM, BN, WM_, WN_, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_kernel<T, LAYOUT, BM, BN, WM_, WN_, 1>), grid, dim3(256), 0, st, a);
+}
+
+template <typename T, int LAYOUT>
+static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t ws_bytes) {
+  constexpr int BK = sizeof(T) == 2 ? 64 : 16;
+  const int64_t t128 = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 128) * batch;
+  const int64_t t12864 = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 64) * batch;
+  const int64_t t64 = (int64_t)d2r_cdiv(a.M, 64) * d2r_cdiv(a.N, 64) * batch;
+  // tile choice, measured on MI355X with tests/bench_gemm.py (profiles/gemm_ab_r01.log): with this register-staged
+  // single-buffer loop, occupancy wins — 64x64 tiles (46 VGPRs, 8 waves/SIMD) beat 128x64 / 128x128 on every NT/NN
+  // shape of the workload (288-474 vs 100-350 TFLOP/s); the reduction-heavy TN weight-gradient GEMMs prefer
+  // 128x128 when the output is large and 128x64 + split-K when it is 768x768.
+  int tile;  // 0: 32x64, 1: 64x64, 2: 128x64, 3: 128x128
+  if (a.M <= 32) tile = 0;
+  else if (LAYOUT == D2R_GEMM_TN && batch == 1) tile = ((int64_t)a.M * a.N >= 2000000) ? 3 : 2;
+  else tile = 1;
+  if (g_tile >= 0 && a.M > 32) tile = g_tile;
+  if (tile > 1) a.vecC = 0;  // the LDS-staged epilogue only pays on the small tiles (register pressure on the large ones)
+  // deterministic split-K for reduction-heavy GEMMs with few output tiles (weight gradients)
+  a.splits = 1;
+  a.tiles_per_split = 0;
+  a.ws = nullptr;
+  const int nk = d2r_cdiv(a.K, BK);
+  if (batch == 1 && ws && nk >= 8) {
+    const int64_t tiles = tile == 3 ? t128 : (tile == 2 ? t12864 : (tile == 1 ? t64 : (int64_t)d2r_cdiv(a.M, 32) * d2r_cdiv(a.N, 64)));
+    if (tiles < 256) {
+      int want = (int)((512 + tiles - 1) / tiles);
+      if (want > 16) want = 16;
+      if (want > nk / 2) want = nk / 2;
+      while (want > 1 && (size_t)want * a.M * a.N * sizeof(float) > ws_bytes) --want;
+      if (want > 1) {
+        a.tiles_per_split = d2r_cdiv(nk, want);
+        a.splits = d2r_cdiv(nk, a.tiles_per_split);
+        a.ws = (float*)ws;
+      }
+    }
+  }
+  const int gz = a.splits > 1 ? a.splits : batch;
+  switch (tile) {
+    case 0: launch_tile<T, LAYOUT, 32, 64, 2, 2>(a, gz, st); break;
+    case 1: launch_tile<T, LAYOUT, 64, 64, 2, 2>(a, gz, st); break;
+    case 2: launch_tile<T, LAYOUT, 128, 64, 2, 2>(a, gz, st); break;
+    default: launch_tile<T, LAYOUT, 128, 128, 2, 2>(a, gz, st); break;
+  }
+  if (int rc = d2r_check_launch("d2r_gemm")) return rc;
+  if (a.splits > 1) {
+    int blocks = d2r_cdiv((int64_t)a.M * a.N, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return d2r_check_launch("d2r_gemm(split-K reduce)");
+  }
+  return D2R_OK;
+}
+
+template <typename T>
+static int launch_dtype(const GemmArgs& a, int layout, int batch, hipStream_t st, void* ws, size_t ws_bytes) {
+  switch (layout) {
+    case D2R_GEMM_NT: return launch_layout<T, D2R_GEMM_NT>(a, batch, st, ws, ws_bytes);
+    case D2R_GEMM_NN: return launch_layout<T, D2R_GEMM_NN>(a, batch, st, ws, ws_bytes);
+    case D2R_GEMM_TN: return launch_layout<T, D2R_GEMM_TN>(a, batch, st, ws, ws_bytes);
+  }
+  return d2r_fail(D2R_ERR_INVALID, "d2r_gemm: bad layout %d", layout);
+}
+
+extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
+  D2R_REQUIRE(d != nullptr, "d2r_gemm: null descriptor");
+  D2R_REQUIRE(d->A && d->B && d->C, "d2r_gemm: null operand");
+  D2R_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "d2r_gemm: negative size");
+  D2R_REQUIRE(d->dtype == D2R_F32 || d->dtype == D2R_BF16, "d2r_gemm: bad dtype %d", d->dtype);
+  D2R_REQUIRE(d->c_dtype == D2R_F32 || d->c_dtype == D2R_BF16, "d2r_gemm: bad c_dtype %d", d->c_dtype);
+  D2R_REQUIRE(d->nb >= 1 && d->nh >= 1, "d2r_gemm: batch must be >= 1");
+  D2R_REQUIRE((int64_t)d->nb * d->nh <= 65535, "d2r_gemm: batch %lld exceeds grid.z", (long long)d->nb * d->nh);
+  const bool a_kcont = d->layout != D2R_GEMM_TN, b_kcont = d->layout == D2R_GEMM_NT;
+  D2R_REQUIRE(d->lda >= (a_kcont ? d->K : d->M), "d2r_gemm: lda %lld too small", (long long)d->lda);
+  D2R_REQUIRE(d->ldb >= (b_kcont ? d->K : d->N), "d2r_gemm: ldb %lld too small", (long long)d->ldb);
+  D2R_REQUIRE(d->ldc >= d->N, "d2r_gemm: ldc %lld < N", (long long)d->ldc);
+  D2R_REQUIRE(!d->residual || d->ldr >= d->N, "d2r_gemm: ldr too small");
+  D2R_REQUIRE(!d->workspace || d2r_aligned16(d->workspace), "d2r_gemm: workspace must be 16-byte aligned");
+  if (d->M == 0 || d->N == 0) return D2R_OK;
+  GemmArgs a;
+  a.A = d->A; a.B = d->B; a.C = d->C; a.bias = d->bias; a.R = d->residual; a.P = d->preact;
+  a.M = d->M; a.N = d->N; a.K = d->K; a.nh = d->nh;
+  a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldr = d->ldr;
+  a.sAb = d->sAb; a.sAh = d->sAh; a.sBb = d->sBb; a.sBh = d->sBh;
+  a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh;
+  a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype;
+  a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0;
+  const int64_t es = (int64_t)d2r_esize(d->dtype);
+  auto vec_ok = [&](const void* p, int64_t ld, int64_t sb, int64_t sh) {
+    return d2r_aligned16(p) && (ld * es) % 16 == 0 && (sb * es) % 16 == 0 && (sh * es) % 16 == 0;
+  };
+  a.vecA = vec_ok(d->A, d->lda, d->sAb, d->sAh) ? 1 : 0;
+  a.vecB = vec_ok(d->B, d->ldb, d->sBb, d->sBh) ? 1 : 0;
+  {
+    const int64_t cs = (int64_t)d2r_esize(d->c_dtype);
+    auto cvec = [&](const void* p, int64_t ld, int64_t sb, int64_t sh) {
+      return !p || (d2r_aligned16(p) && (ld * cs) % 16 == 0 && (sb * cs) % 16 == 0 && (sh * cs) % 16 == 0);
+    };
+    a.vecC = (g_vepi && cvec(d->C, d->ldc, d->sCb, d->sCh) && cvec(d->preact, d->ldc, d->sCb, d->sCh) &&
+              cvec(d->residual, d->ldr, d->sRb, d->sRh)) ? 1 : 0;
+  }
+  const int batch = d->nb * d->nh;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == D2R_BF16) return launch_dtype<bf16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
+  return launch_dtype<float>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
+}

@@ -1,0 +1,637 @@
+// routing.hip — K1 router pooling and K8 route_aggregate (path normalisation + threshold gate + aggregation).
+//
+// HBM-bound streaming kernels: every activation element is read once as a 16-byte pack, all per-sample
+// routing coefficients live in LDS/registers, reductions are fixed-order (wave shuffles -> LDS -> stage-2
+// kernel), no float atomics.
+//
+// Reference: models/Router.py:23 (mean over tokens); models/DynamicInteraction.py:50-67 (=:119-132,
+// :170-187, :239-252) for P=6 and :104-117 (=:224-237) for the final layer P=1; RIC relu models/Cells.py:38.
+#include "common.h"
+
+struct Ptrs8 {
+  const void* p[8];
+};
+struct MPtrs8 {
+  void* p[8];
+};
+
+#define TH_GATE 1e-4f          /* self.threshold (models/DynamicInteraction.py:24) */
+#define TH_GATE_FINAL ((float)(1e-4 / 6.0))
+#define EPS_NORM 1e-8f
+
+// =====================================================================================================
+// K1: mean over tokens.  grid = (D / (16*VEC), B, nsrc); 256 threads = 16 column packs x 16 row groups
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void meanpool_fwd_kernel(Ptrs8 srcs, int B, int L, int D, float* __restrict__ pooled) {
+  constexpr int VEC = PackOf<T>::N;
+  __shared__ float sh[16][16 * VEC + 1];
+  const int cp = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int b = blockIdx.y, s = blockIdx.z;
+  const int col0 = (blockIdx.x * 16 + cp) * VEC;
+  const T* x = reinterpret_cast<const T*>(srcs.p[s]) + (int64_t)b * L * D;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (col0 < D) {
+    for (int l = rg; l < L; l += 16) {
+      Pack<T, VEC> p = ld_pack<T, VEC>(x + (int64_t)l * D + col0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += to_f<T>(p.v[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sh[rg][cp * VEC + j] = acc[j];
+  __syncthreads();
+  const int c = threadIdx.x;  // one thread per column of the block's 16*VEC columns
+  if (c < 16 * VEC) {
+    const int col = blockIdx.x * 16 * VEC + c;
+    if (col < D) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += sh[r][c];
+      pooled[((int64_t)s * B + b) * D + col] = t / (float)L;
+    }
+  }
+}
+
+extern "C" int d2r_meanpool_fwd(int dtype, const void* const* h_srcs, int nsrc, int B, int L, int D, float* pooled,
+                                void* stream) {
+  D2R_REQUIRE(h_srcs && pooled, "d2r_meanpool_fwd: null pointer");
+  D2R_REQUIRE(nsrc >= 1 && nsrc <= 8, "d2r_meanpool_fwd: nsrc=%d outside [1,8]", nsrc);
+  D2R_REQUIRE(B >= 1 && L >= 1 && D >= 1, "d2r_meanpool_fwd: bad shape");
+  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  D2R_REQUIRE(D % VEC == 0, "d2r_meanpool_fwd: D=%d must be a multiple of %d", D, VEC);
+  Ptrs8 ps;
+  for (int i = 0; i < 8; ++i) ps.p[i] = i < nsrc ? h_srcs[i] : nullptr;
+  for (int i = 0; i < nsrc; ++i) D2R_REQUIRE(ps.p[i] && d2r_aligned16(ps.p[i]), "d2r_meanpool_fwd: source %d null or unaligned", i);
+  dim3 grid(d2r_cdiv(D, 16 * VEC), B, nsrc), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == D2R_BF16) hipLaunchKernelGGL((meanpool_fwd_kernel<bf16_t>), grid, block, 0, st, ps, B, L, D, pooled);
+  else if (dtype == D2R_F32) hipLaunchKernelGGL((meanpool_fwd_kernel<float>), grid, block, 0, st, ps, B, L, D, pooled);
+  else return d2r_fail(D2R_ERR_INVALID, "d2r_meanpool_fwd: bad dtype %d", dtype);
+  return d2r_check_launch("d2r_meanpool_fwd");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ dpooled, int B, int L, int D,
+                                                           T* __restrict__ dX, int accumulate) {
+  constexpr int VEC = PackOf<T>::N;
+  const int npk = D / VEC;
+  const int64_t total = (int64_t)B * L * npk;
+  const float invL = 1.f / (float)L;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int pk = (int)(idx % npk);
+    const int64_t bl = idx / npk;
+    const int b = (int)(bl / L);
+    const float* g = dpooled + (int64_t)b * D + pk * VEC;
+    T* dst = dX + bl * D + pk * VEC;
+    Pack<T, VEC> o;
+    if (accumulate) {
+      Pack<T, VEC> old = ld_pack<T, VEC>(dst);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(to_f<T>(old.v[j]) + g[j] * invL);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(g[j] * invL);
+    }
+    st_pack<T, VEC>(dst, o);
+  }
+}
+
+extern "C" int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, int D, void* dX, int accumulate,
+                                void* stream) {
+  D2R_REQUIRE(dpooled && dX && d2r_aligned16(dX), "d2r_meanpool_bwd: null or unaligned pointer");
+  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  D2R_REQUIRE(B >= 1 && L >= 1 && D % VEC == 0, "d2r_meanpool_bwd: bad shape");
+  int blocks = d2r_cdiv((int64_t)B * L * (D / VEC), 256);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == D2R_BF16) hipLaunchKernelGGL((meanpool_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, dpooled, B, L, D, (bf16_t*)dX, accumulate);
+  else if (dtype == D2R_F32) hipLaunchKernelGGL((meanpool_bwd_kernel<float>), dim3(blocks), dim3(256), 0, st, dpooled, B, L, D, (float*)dX, accumulate);
+  else return d2r_fail(D2R_ERR_INVALID, "d2r_meanpool_bwd: bad dtype %d", dtype);
+  return d2r_check_launch("d2r_meanpool_bwd");
+}
+
+// =====================================================================================================
+// K8 forward.  gates: fp32 [6, B, P] (cell-major).  Cells 1 (GLAC) and 5 (GESC) are [B,D] broadcasts.
+// =====================================================================================================
+template <typename T, int VEC>
+__device__ __forceinline__ void ld_f(const T* p, float (&o)[VEC]) {
+  Pack<T, VEC> k = ld_pack<T, VEC>(p);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) o[j] = to_f<T>(k.v[j]);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void st_f(T* p, const float (&o)[VEC]) {
+  Pack<T, VEC> k;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) k.v[j] = from_f<T>(o[j]);
+  st_pack<T, VEC>(p, k);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* __restrict__ gates, int B, int L, int D,
+                                                       MPtrs8 outs, float* __restrict__ probs) {
+  constexpr int VEC = PackOf<T>::N;
+  __shared__ float c[6][6];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 6) {
+    const int i = tid;
+    float g[6], S = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      g[j] = gates[((int64_t)j * B + b) * 6 + i];
+      S += g[j];
+    }
+    const float skip = S < TH_GATE ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float ph = g[j] / (S + EPS_NORM);
+      c[i][j] = ph + (j == 0 ? skip : 0.f);
+      if (blockIdx.x == 0) probs[((int64_t)b * 6 + i) * 6 + j] = ph;
+    }
+  }
+  __syncthreads();
+  const int npk = D / VEC;
+  const int total = L * npk;
+  for (int idx = blockIdx.x * 256 + tid; idx < total; idx += gridDim.x * 256) {
+    const int l = idx / npk, pk = idx - l * npk;
+    const int64_t off = ((int64_t)b * L + l) * D + pk * VEC, boff = (int64_t)b * D + pk * VEC;
+    float e[6][VEC];
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, e[0]);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) e[0][j] = fmaxf(e[0][j], 0.f);
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[1]) + boff, e[1]);
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[2]) + off, e[2]);
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[3]) + off, e[3]);
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[4]) + off, e[4]);
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e[5]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = c[i][0] * e[0][j];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) t += c[i][k] * e[k][j];
+        o[j] = t;
+      }
+      st_f<T, VEC>(reinterpret_cast<T*>(outs.p[i]) + off, o);
+    }
+  }
+}
+
+// final layer (P = 1): out = sum_j (g_j emb_j + s_j ref_j) / (sum s + sum g)
+template <typename T>
+__global__ __launch_bounds__(256) void agg_fwd1_kernel(Ptrs8 embs, Ptrs8 refs, const float* __restrict__ gates, int B,
+                                                       int L, int D, T* __restrict__ out, float* __restrict__ probs) {
+  constexpr int VEC = PackOf<T>::N;
+  __shared__ float cg[6], cs[6];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid == 0) {
+    float g[6], s[6], sg = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      g[j] = gates[(int64_t)j * B + b];
+      s[j] = g[j] < TH_GATE_FINAL ? 1.f : 0.f;
+      sg += g[j];
+      ss += s[j];
+      if (blockIdx.x == 0) probs[(int64_t)b * 6 + j] = g[j];
+    }
+    const float inv = 1.f / (ss + sg);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      cg[j] = g[j] * inv;
+      cs[j] = s[j] * inv;
+    }
+  }
+  __syncthreads();
+  const int npk = D / VEC;
+  const int total = L * npk;
+  for (int idx = blockIdx.x * 256 + tid; idx < total; idx += gridDim.x * 256) {
+    const int l = idx / npk, pk = idx - l * npk;
+    const int64_t off = ((int64_t)b * L + l) * D + pk * VEC, boff = (int64_t)b * D + pk * VEC;
+    float o[VEC], e[VEC];
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, e);  // x0 == ref_0
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = cg[0] * fmaxf(e[j], 0.f) + cs[0] * e[j];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+      const bool bc = (k == 1 || k == 5);
+      ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + (bc ? boff : off), e);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] += cg[k] * e[j];
+      if (cs[k] != 0.f) {  // block-uniform: the skip term is read only for closed paths
+        ld_f<T, VEC>(reinterpret_cast<const T*>(refs.p[k]) + off, e);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] += cs[k] * e[j];
+      }
+    }
+    st_f<T, VEC>(out + off, o);
+  }
+}
+
+static int agg_chunks(int L, int D, int VEC) {
+  int64_t packs = (int64_t)L * (D / VEC);
+  int c = (int)((packs + 1023) / 1024);  // ~4 packs per thread
+  return c < 1 ? 1 : c;
+}
+
+extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, const void* const* h_refs,
+                                       const float* gates, int B, int L, int D, int P, void* const* h_outs,
+                                       float* probs, void* stream) {
+  D2R_REQUIRE(h_embs && gates && h_outs && probs, "d2r_route_aggregate_fwd: null pointer");
+  D2R_REQUIRE(P == 6 || P == 1, "d2r_route_aggregate_fwd: P=%d (must be 6 or 1)", P);
+  D2R_REQUIRE(P == 6 || h_refs, "d2r_route_aggregate_fwd: the final layer needs refs");
+  D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_route_aggregate_fwd: bad dtype %d", dtype);
+  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  D2R_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D % VEC == 0, "d2r_route_aggregate_fwd: bad shape B=%d L=%d D=%d", B, L, D);
+  Ptrs8 e{}, r{};
+  MPtrs8 o{};
+  for (int j = 0; j < 6; ++j) {
+    e.p[j] = h_embs[j];
+    D2R_REQUIRE(e.p[j] && d2r_aligned16(e.p[j]), "d2r_route_aggregate_fwd: emb %d null or unaligned", j);
+    if (P == 1) {
+      r.p[j] = h_refs[j];
+      D2R_REQUIRE(r.p[j] && d2r_aligned16(r.p[j]), "d2r_route_aggregate_fwd: ref %d null or unaligned", j);
+    }
+  }
+  for (int i = 0; i < P; ++i) {
+    o.p[i] = h_outs[i];
+    D2R_REQUIRE(o.p[i] && d2r_aligned16(o.p[i]), "d2r_route_aggregate_fwd: out %d null or unaligned", i);
+  }
+  dim3 grid(agg_chunks(L, D, VEC), B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 6) {
+    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd6_kernel<bf16_t>), grid, block, 0, st, e, gates, B, L, D, o, probs);
+    else hipLaunchKernelGGL((agg_fwd6_kernel<float>), grid, block, 0, st, e, gates, B, L, D, o, probs);
+  } else {
+    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd1_kernel<bf16_t>), grid, block, 0, st, e, r, gates, B, L, D, (bf16_t*)o.p[0], probs);
+    else hipLaunchKernelGGL((agg_fwd1_kernel<float>), grid, block, 0, st, e, r, gates, B, L, D, (float*)o.p[0], probs);
+  }
+  return d2r_check_launch("d2r_route_aggregate_fwd");
+}
+
+// =====================================================================================================
+// K8 backward.  Block = (token chunk, sample); a thread owns one column pack and walks the chunk's rows.
+// Per block: NDOT dot-product partials + NBC broadcast-gradient partial rows -> workspace; stage 2 finishes.
+//   workspace layout: dots [B][nchunk][NDOT] | bcast [B][nchunk][NBC][D]
+// =====================================================================================================
+#define AGG_LC 8  /* token rows per block */
+
+template <int N>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[N], float* sh /*[4][N]*/, float* dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float t = wave_sum(acc[k]);
+    if (lane == 0) sh[wave * N + k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) dst[threadIdx.x] = sh[threadIdx.x] + sh[N + threadIdx.x] + sh[2 * N + threadIdx.x] + sh[3 * N + threadIdx.x];
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* __restrict__ gates, Ptrs8 douts, int B,
+                                                       int L, int D, MPtrs8 dembs, float* __restrict__ ws_dots,
+                                                       float* __restrict__ ws_bc) {
+  constexpr int VEC = PackOf<T>::N;
+  extern __shared__ float dsh[];  // [RG][2][D] broadcast partials, then reused for the dot reduction
+  __shared__ float c[6][6];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, tid = threadIdx.x;
+  if (tid < 6) {
+    const int i = tid;
+    float g[6], S = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      g[j] = gates[((int64_t)j * B + b) * 6 + i];
+      S += g[j];
+    }
+    const float skip = S < TH_GATE ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      c[i][j] = g[j] / (S + EPS_NORM) + (j == 0 ? skip : 0.f);
+    }
+  }
+  __syncthreads();
+  const int npk = D / VEC;
+  const int RG = 256 / npk;  // row groups per block (>= 1, checked on the host)
+  const int pk = tid % npk, rg = tid / npk;
+  const bool active = rg < RG;
+  float dots[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) dots[k] = 0.f;
+  float b1[VEC], b5[VEC], e1[VEC], e5[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) b1[j] = b5[j] = e1[j] = e5[j] = 0.f;
+  const int l0 = chunk * AGG_LC, l1 = min(L, l0 + AGG_LC);
+  if (active) {
+    const int64_t boff = (int64_t)b * D + pk * VEC;
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[1]) + boff, e1);
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
+    for (int l = l0 + rg; l < l1; l += RG) {
+      const int64_t off = ((int64_t)b * L + l) * D + pk * VEC;
+      float dv[6][VEC], x0[VEC], e[VEC], o[VEC];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ld_f<T, VEC>(reinterpret_cast<const T*>(douts.p[i]) + off, dv[i]);
+      // cell 0 (RIC): emb = relu(x0)
+      ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, x0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float r = fmaxf(x0[j], 0.f);
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          dots[i * 6 + 0] += dv[i][j] * r;
+          t += c[i][0] * dv[i][j];
+        }
+        o[j] = x0[j] > 0.f ? t : 0.f;
+      }
+      st_f<T, VEC>(reinterpret_cast<T*>(dembs.p[0]) + off, o);
+      // full cells 2,3,4
+#pragma unroll
+      for (int k = 2; k <= 4; ++k) {
+        ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, e);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            dots[i * 6 + k] += dv[i][j] * e[j];
+            t += c[i][k] * dv[i][j];
+          }
+          o[j] = t;
+        }
+        st_f<T, VEC>(reinterpret_cast<T*>(dembs.p[k]) + off, o);
+      }
+      // broadcast cells 1,5
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t1 = 0.f, t5 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          dots[i * 6 + 1] += dv[i][j] * e1[j];
+          dots[i * 6 + 5] += dv[i][j] * e5[j];
+          t1 += c[i][1] * dv[i][j];
+          t5 += c[i][5] * dv[i][j];
+        }
+        b1[j] += t1;
+        b5[j] += t5;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      dsh[(rg * 2 + 0) * D + pk * VEC + j] = b1[j];
+      dsh[(rg * 2 + 1) * D + pk * VEC + j] = b5[j];
+    }
+  }
+  __syncthreads();
+  float* wb = ws_bc + ((int64_t)b * nchunk + chunk) * 2 * D;
+  for (int cidx = tid; cidx < 2 * D; cidx += 256) {
+    float t = 0.f;
+    for (int r = 0; r < RG; ++r) t += dsh[r * 2 * D + cidx];
+    wb[cidx] = t;
+  }
+  __syncthreads();
+  block_reduce_store<36>(dots, dsh, ws_dots + ((int64_t)b * nchunk + chunk) * 36);
+}
+
+// stage 2 (P=6): grid = B.  d_gates[j][b][i] from dp_hat (+ dprobs), broadcast grads summed over chunks.
+template <typename T>
+__global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __restrict__ gates,
+                                                              const float* __restrict__ dprobs,
+                                                              const float* __restrict__ ws_dots,
+                                                              const float* __restrict__ ws_bc, int B, int D, int nchunk,
+                                                              T* __restrict__ demb1, T* __restrict__ demb5,
+                                                              float* __restrict__ d_gates) {
+  __shared__ float dph[36];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 36) {
+    float t = dprobs ? dprobs[(int64_t)b * 36 + tid] : 0.f;
+    for (int cidx = 0; cidx < nchunk; ++cidx) t += ws_dots[((int64_t)b * nchunk + cidx) * 36 + tid];
+    dph[tid] = t;
+  }
+  __syncthreads();
+  if (tid < 6) {
+    const int i = tid;
+    float g[6], S = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      g[j] = gates[((int64_t)j * B + b) * 6 + i];
+      S += g[j];
+    }
+    const float inv = 1.f / (S + EPS_NORM);
+    float dotp = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dotp += dph[i * 6 + j] * (g[j] * inv);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) d_gates[((int64_t)j * B + b) * 6 + i] = (dph[i * 6 + j] - dotp) * inv;
+  }
+  for (int cidx = tid; cidx < 2 * D; cidx += 256) {
+    float t = 0.f;
+    for (int k = 0; k < nchunk; ++k) t += ws_bc[((int64_t)b * nchunk + k) * 2 * D + cidx];
+    if (cidx < D) demb1[(int64_t)b * D + cidx] = from_f<T>(t);
+    else demb5[(int64_t)b * D + cidx - D] = from_f<T>(t);
+  }
+}
+
+// final layer backward (P = 1)
+template <typename T>
+__global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, const float* __restrict__ gates,
+                                                       const T* __restrict__ dout, const T* __restrict__ out, int B,
+                                                       int L, int D, MPtrs8 dembs, MPtrs8 drefs,
+                                                       float* __restrict__ ws_dots, float* __restrict__ ws_bc) {
+  constexpr int VEC = PackOf<T>::N;
+  extern __shared__ float dsh[];  // [RG][D]
+  __shared__ float cg[6], cs[6];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, tid = threadIdx.x;
+  if (tid == 0) {
+    float g[6], s[6], sg = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      g[j] = gates[(int64_t)j * B + b];
+      s[j] = g[j] < TH_GATE_FINAL ? 1.f : 0.f;
+      sg += g[j];
+      ss += s[j];
+    }
+    const float inv = 1.f / (ss + sg);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      cg[j] = g[j] * inv;
+      cs[j] = s[j] * inv;
+    }
+  }
+  __syncthreads();
+  const int npk = D / VEC;
+  const int RG = 256 / npk;
+  const int pk = tid % npk, rg = tid / npk;
+  const bool active = rg < RG;
+  float dots[8];  // 0..5: <dout, emb_j>, 6: <dout, out>, 7: unused
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dots[k] = 0.f;
+  float bs[VEC], e1[VEC], e5[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) bs[j] = e1[j] = e5[j] = 0.f;
+  const int l0 = chunk * AGG_LC, l1 = min(L, l0 + AGG_LC);
+  if (active) {
+    const int64_t boff = (int64_t)b * D + pk * VEC;
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[1]) + boff, e1);
+    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
+    for (int l = l0 + rg; l < l1; l += RG) {
+      const int64_t off = ((int64_t)b * L + l) * D + pk * VEC;
+      float dv[VEC], e[VEC], o[VEC];
+      ld_f<T, VEC>(dout + off, dv);
+      ld_f<T, VEC>(out + off, e);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        dots[6] += dv[j] * e[j];
+        dots[1] += dv[j] * e1[j];
+        dots[5] += dv[j] * e5[j];
+        bs[j] += dv[j];
+      }
+      ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, e);  // x0 = ref_0
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        dots[0] += dv[j] * fmaxf(e[j], 0.f);
+        o[j] = e[j] > 0.f ? cg[0] * dv[j] : 0.f;
+      }
+      st_f<T, VEC>(reinterpret_cast<T*>(dembs.p[0]) + off, o);
+#pragma unroll
+      for (int k = 2; k <= 4; ++k) {
+        ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, e);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          dots[k] += dv[j] * e[j];
+          o[j] = cg[k] * dv[j];
+        }
+        st_f<T, VEC>(reinterpret_cast<T*>(dembs.p[k]) + off, o);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = cs[k] * dv[j];
+        st_f<T, VEC>(reinterpret_cast<T*>(drefs.p[k]) + off, o);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dsh[rg * D + pk * VEC + j] = bs[j];
+  }
+  __syncthreads();
+  float* wb = ws_bc + ((int64_t)b * nchunk + chunk) * D;
+  for (int cidx = tid; cidx < D; cidx += 256) {
+    float t = 0.f;
+    for (int r = 0; r < RG; ++r) t += dsh[r * D + cidx];
+    wb[cidx] = t;
+  }
+  __syncthreads();
+  block_reduce_store<8>(dots, dsh, ws_dots + ((int64_t)b * nchunk + chunk) * 8);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __restrict__ gates,
+                                                              const float* __restrict__ dprobs,
+                                                              const float* __restrict__ ws_dots,
+                                                              const float* __restrict__ ws_bc, int B, int D, int nchunk,
+                                                              T* __restrict__ demb1, T* __restrict__ demb5,
+                                                              float* __restrict__ d_gates) {
+  __shared__ float dt[8], cgs[6];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 8) {
+    float t = 0.f;
+    for (int k = 0; k < nchunk; ++k) t += ws_dots[((int64_t)b * nchunk + k) * 8 + tid];
+    dt[tid] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float g[6], sg = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      g[j] = gates[(int64_t)j * B + b];
+      ss += g[j] < TH_GATE_FINAL ? 1.f : 0.f;
+      sg += g[j];
+    }
+    const float inv = 1.f / (ss + sg);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      cgs[j] = g[j] * inv;
+      d_gates[(int64_t)j * B + b] = (dt[j] - dt[6]) * inv + (dprobs ? dprobs[(int64_t)b * 6 + j] : 0.f);
+    }
+  }
+  __syncthreads();
+  for (int cidx = tid; cidx < D; cidx += 256) {
+    float t = 0.f;
+    for (int k = 0; k < nchunk; ++k) t += ws_bc[((int64_t)b * nchunk + k) * D + cidx];
+    demb1[(int64_t)b * D + cidx] = from_f<T>(cgs[1] * t);
+    demb5[(int64_t)b * D + cidx] = from_f<T>(cgs[5] * t);
+  }
+}
+
+extern "C" size_t d2r_route_aggregate_bwd_workspace(int B, int L, int D, int P) {
+  const size_t nchunk = (size_t)((L + AGG_LC - 1) / AGG_LC);
+  return (size_t)B * nchunk * ((P == 6 ? 36 : 8) + (size_t)(P == 6 ? 2 : 1) * D) * sizeof(float);
+}
+
+// d_probs: gradient flowing into the returned path probabilities (sim_paths -> JS loss), may be NULL;
+// h_outs: the forward outputs (only outs[0] of the final layer is read).
+extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, const void* const* h_refs,
+                                          const float* gates, const void* const* h_douts, const void* const* h_outs,
+                                          const float* d_probs, int B, int L, int D, int P, void* const* h_dembs,
+                                          void* const* h_drefs, float* d_gates, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  D2R_REQUIRE(h_embs && gates && h_douts && h_dembs && d_gates, "d2r_route_aggregate_bwd: null pointer");
+  D2R_REQUIRE(P == 6 || P == 1, "d2r_route_aggregate_bwd: P=%d (must be 6 or 1)", P);
+  D2R_REQUIRE(P == 6 || (h_refs && h_drefs && h_outs), "d2r_route_aggregate_bwd: the final layer needs refs, d_refs and outs");
+  D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_route_aggregate_bwd: bad dtype %d", dtype);
+  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  D2R_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D % VEC == 0 && D / VEC <= 256, "d2r_route_aggregate_bwd: bad shape B=%d L=%d D=%d", B, L, D);
+  if (!workspace || workspace_bytes < d2r_route_aggregate_bwd_workspace(B, L, D, P))
+    return d2r_fail(D2R_ERR_WORKSPACE, "d2r_route_aggregate_bwd: workspace %zu < %zu", workspace_bytes, d2r_route_aggregate_bwd_workspace(B, L, D, P));
+  Ptrs8 e{}, r{}, dv{};
+  MPtrs8 de{}, dr{};
+  for (int j = 0; j < 6; ++j) {
+    e.p[j] = h_embs[j];
+    de.p[j] = h_dembs[j];
+    D2R_REQUIRE(e.p[j] && de.p[j] && d2r_aligned16(e.p[j]) && d2r_aligned16(de.p[j]), "d2r_route_aggregate_bwd: emb/d_emb %d null or unaligned", j);
+    if (P == 1) {
+      r.p[j] = h_refs[j];
+      dr.p[j] = h_drefs[j];
+      D2R_REQUIRE(r.p[j] && dr.p[j] && d2r_aligned16(r.p[j]) && d2r_aligned16(dr.p[j]), "d2r_route_aggregate_bwd: ref/d_ref %d null or unaligned", j);
+    }
+  }
+  for (int i = 0; i < P; ++i) {
+    dv.p[i] = h_douts[i];
+    D2R_REQUIRE(dv.p[i] && d2r_aligned16(dv.p[i]), "d2r_route_aggregate_bwd: dout %d null or unaligned", i);
+  }
+  const int nchunk = (L + AGG_LC - 1) / AGG_LC;
+  const int RG = 256 / (D / VEC);
+  float* ws_dots = (float*)workspace;
+  float* ws_bc = ws_dots + (size_t)B * nchunk * (P == 6 ? 36 : 8);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nchunk, B), block(256);
+  if (P == 6) {
+    size_t shmem = (size_t)RG * 2 * D * sizeof(float);
+    if (shmem < 4 * 36 * sizeof(float)) shmem = 4 * 36 * sizeof(float);
+    if (dtype == D2R_BF16) {
+      hipLaunchKernelGGL((agg_bwd6_kernel<bf16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, de, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+    } else {
+      hipLaunchKernelGGL((agg_bwd6_kernel<float>), grid, block, shmem, st, e, gates, dv, B, L, D, de, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (float*)de.p[1], (float*)de.p[5], d_gates);
+    }
+  } else {
+    const void* outp = h_outs[0];
+    D2R_REQUIRE(outp && d2r_aligned16(outp), "d2r_route_aggregate_bwd: out null or unaligned");
+    size_t shmem = (size_t)RG * D * sizeof(float);
+    if (shmem < 4 * 8 * sizeof(float)) shmem = 4 * 8 * sizeof(float);
+    if (dtype == D2R_BF16) {
+      hipLaunchKernelGGL((agg_bwd1_kernel<bf16_t>), grid, block, shmem, st, e, r, gates, (const bf16_t*)dv.p[0], (const bf16_t*)outp, B, L, D, de, dr, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<bf16_t>), dim3(B), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+    } else {
+      hipLaunchKernelGGL((agg_bwd1_kernel<float>), grid, block, shmem, st, e, r, gates, (const float*)dv.p[0], (const float*)outp, B, L, D, de, dr, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<float>), dim3(B), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (float*)de.p[1], (float*)de.p[5], d_gates);
+    }
+  }
+  return d2r_check_launch("d2r_route_aggregate_bwd");
+}

@@ -1,0 +1,155 @@
+"""Data parallelism: one process per GPU, minibatch sharded on dim 0, full replica per rank, gradients summed
+with RCCL (torch.distributed backend "nccl" on ROCm) over xGMI in buckets of the flat gradient buffer.
+
+The reference has no distributed code at all; semantics are those DDP would give it:
+local-batch BatchNorm statistics and local [b,b] JS loss per rank, gradients averaged.
+The 1/world factor is folded into the fused AdamW kernel (``grad_scale``), so the collective is a plain SUM.
+
+Buckets are contiguous slices of ``ParamStore.flat_g``.  With ``overlap=True`` a bucket's all-reduce is issued
+on a side stream as soon as every parameter in it has its gradient (readiness is counted from autograd's
+post-accumulate hooks and from the dW-sink callback of functional._Linear), overlapping with the rest of
+backward; ``finish()`` joins them before the optimiser step.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .params import ParamStore
+
+
+def init_process_group_from_env(backend: Optional[str] = None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from torch.distributed.run."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def shard_batch(batch, rank: int, world: int):
+    """Splits every tensor of a batch tuple on dim 0 into `world` equal shards and returns shard `rank`."""
+    out = []
+    for t in batch:
+        if isinstance(t, torch.Tensor) and t.dim() > 0:
+            n = t.shape[0]
+            if n % world != 0:
+                raise ValueError(f"global batch {n} is not divisible by world size {world}")
+            k = n // world
+            out.append(t[rank * k:(rank + 1) * k])
+        else:
+            out.append(t)
+    return tuple(out)
+
+
+class FlatGradReducer:
+    """Bucketed SUM all-reduce of a flat fp32 gradient buffer."""
+
+    def __init__(self, flat_g: torch.Tensor, bucket_elems: int, group=None):
+        self.flat_g, self.group = flat_g, group
+        n = flat_g.numel()
+        self.bounds = [(a, min(n, a + bucket_elems)) for a in range(0, n, bucket_elems)]
+        self.handles = []
+        self.comm_stream = torch.cuda.Stream() if flat_g.is_cuda else None
+
+    def launch_bucket(self, i: int):
+        a, b = self.bounds[i]
+        view = self.flat_g[a:b]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reduce_all(self):
+        # reverse order = roughly reverse execution order (head and routing modules first)
+        for i in reversed(range(len(self.bounds))):
+            self.launch_bucket(i)
+        self.finish()
+
+    def finish(self):
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+class DataParallel:
+    def __init__(self, store: ParamStore, optimizer, model: torch.nn.Module, bucket_mb: int = 128, group=None,
+                 overlap: bool = False):
+        self.store, self.opt, self.model, self.group = store, optimizer, model, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.reducer = FlatGradReducer(store.flat_g, bucket_mb * (1 << 20) // 4, group) if self.world > 1 else None
+        optimizer.grad_scale = 1.0 / self.world
+        self.overlap = overlap and self.world > 1
+        self._pending: List[int] = []
+        self._bucket_of = {}
+        if self.overlap:
+            self._install_hooks()
+
+    # -- start-up: identical replicas ---------------------------------------------------------------
+    def broadcast_parameters(self, src: int = 0):
+        if self.world == 1:
+            return
+        dist.broadcast(self.store.flat_w, src=src, group=self.group)
+        for _, p in self.store.dead:
+            dist.broadcast(p.data, src=src, group=self.group)
+        for b in self.model.buffers():
+            dist.broadcast(b, src=src, group=self.group)
+        self.store.refresh_lowp()
+
+    # -- readiness counting for overlap ---------------------------------------------------------------
+    def _install_hooks(self):
+        bounds = self.reducer.bounds
+        self._count0 = [0] * len(bounds)
+        for name, p, off, k, g in self.store.entries:
+            bi = next(i for i, (a, b) in enumerate(bounds) if a <= off < b)
+            # a parameter straddling two buckets belongs to the later one (its tail is reduced there)
+            be = next(i for i, (a, b) in enumerate(bounds) if a <= off + k - 1 < b)
+            for i in range(bi, be + 1):
+                self._count0[i] += 1
+            self._bucket_of[id(p)] = (bi, be)
+            p._d2r_ready_cb = self._ready
+            p.register_post_accumulate_grad_hook(self._ready)
+        self.begin_step()
+
+    def begin_step(self):
+        if self.overlap:
+            self._pending = list(self._count0)
+            self._seen = set()
+
+    def _ready(self, p):
+        if not self.overlap or id(p) in self._seen:
+            return
+        self._seen.add(id(p))
+        bi, be = self._bucket_of[id(p)]
+        for i in range(bi, be + 1):
+            self._pending[i] -= 1
+            if self._pending[i] == 0:
+                self.reducer.launch_bucket(i)
+
+    # -- per step -------------------------------------------------------------------------------------
+    def reduce_gradients(self):
+        if self.world == 1:
+            return
+        if self.overlap:
+            # buckets whose parameters never reported (unused this step) are reduced now
+            for i, c in enumerate(self._pending):
+                if c > 0:
+                    self.reducer.launch_bucket(i)
+            self.reducer.finish()
+        else:
+            self.reducer.reduce_all()

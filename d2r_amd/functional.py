@@ -1,0 +1,835 @@
+"""Differentiable ops of the D2R hot path: thin ``torch.autograd.Function`` wrappers whose forward AND backward
+are launches of the hand-written gfx950 kernels in libd2r_hip.so (C ABI: include/d2r_hip.h).
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape — no arithmetic.  Nothing here
+falls back to ATen: a missing library or a failing launch raises ``d2r_amd._lib.D2RError``.
+
+dtype policy: activations and GEMM weights are ``T`` in {float32, bfloat16}; accumulation, softmax logits and
+statistics, router gates, biases, LayerNorm parameters, losses and every reduction are fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_TANH_RELU, BF16, F32,
+                   GEMM_NN, GEMM_NT, GEMM_TN, GemmDesc)
+
+_ACT_FROM_OUTPUT = (ACT_RELU, ACT_TANH, ACT_TANH_RELU, ACT_SIGMOID)
+_ACT_FROM_PREACT = (ACT_GELU, ACT_QUICK_GELU)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"d2r_amd supports float32/bfloat16 tensors, got {t.dtype}")
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.D2RError("d2r_amd ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _parr(ts: Sequence[Optional[torch.Tensor]]):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+_WS = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (all kernels run stream-ordered on the current stream)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _rows2d(x: torch.Tensor):
+    """Describes x as [M, K] rows with a uniform row stride (last-dim stride 1). Returns (M, K, ld) or None."""
+    if x.stride(-1) != 1 and x.shape[-1] != 1:
+        return None
+    K = x.shape[-1]
+    if x.dim() == 1:
+        return 1, K, K
+    if x.dim() == 2:
+        ld = x.stride(0) if x.shape[0] > 1 else max(K, 1)
+        return x.shape[0], K, max(ld, K)
+    if x.is_contiguous():
+        return x.numel() // K, K, K
+    return None
+
+
+def _as_rows(x: torch.Tensor):
+    r = _rows2d(x)
+    if r is None:
+        x = x.contiguous()
+        r = _rows2d(x)
+    return x, r
+
+
+# ------------------------------------------------------------------------------------------------------
+# raw GEMM launcher
+# ------------------------------------------------------------------------------------------------------
+def gemm(layout, M, N, K, A, lda, B, ldb, Cc, ldc, *, dtype, c_dtype, nb=1, nh=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
+         alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, residual=None, ldr=0, sR=(0, 0), preact=None, tag=None,
+         splitk_ws=None):
+    d = GemmDesc(dtype=dtype, c_dtype=c_dtype, layout=layout, act=act, M=M, N=N, K=K, nb=nb, nh=nh, alpha=alpha,
+                 beta=beta, A=A, lda=lda, sAb=sA[0], sAh=sA[1], B=B, ldb=ldb, sBb=sB[0], sBh=sB[1], C=Cc, ldc=ldc,
+                 sCb=sC[0], sCh=sC[1], bias=bias, residual=residual, ldr=ldr, sRb=sR[0], sRh=sR[1], preact=preact)
+    if splitk_ws is not None:  # deterministic split-K scratch (dW GEMMs): fp32 partial slabs
+        d.workspace, d.workspace_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
+    meta = None
+    if _lib._timer is not None:  # algorithmic flops / bytes of this launch for bench.py's roofline
+        z, es, cs = nb * nh, (2 if dtype == BF16 else 4), (2 if c_dtype == BF16 else 4)
+        meta = dict(group=tag or f"gemm_{'bf16' if dtype == BF16 else 'f32'}_{('NT', 'NN', 'TN')[layout]}",
+                    flops=2.0 * M * N * K * z,
+                    bytes=float(z) * ((M * K + N * K) * es + M * N * cs * (2 if (beta != 0.0 or residual) else 1)))
+    _lib.call("d2r_gemm", C.byref(d), _stream(), meta=meta)
+
+
+def colsum(g: torch.Tensor, M: int, N: int, ld: int) -> torch.Tensor:
+    out = torch.empty(N, dtype=torch.float32, device=g.device)
+    nbytes = _lib.load().d2r_colsum_workspace(M, N)
+    ws = _workspace(nbytes, g.device)
+    _lib.call("d2r_colsum", _dt(g), g.data_ptr(), ld, M, N, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty_like(x, dtype=dtype)
+    _lib.call("d2r_cast", _dt(x), x.data_ptr(), _dt(out), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+class _Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast(g.contiguous(), ctx.src), None
+
+
+def cast_ad(x, dtype):
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
+
+
+# ------------------------------------------------------------------------------------------------------
+# K11 linear: y = act(x W^T + b) (+ residual)
+# ------------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_master, bias, w_compute, act, residual, out_dtype):
+        _require_cuda(x, w_compute)
+        x, (M, K, lda) = _as_rows(x)
+        N = w_compute.shape[0]
+        assert w_compute.shape[1] == K and w_compute.is_contiguous(), "weight must be contiguous [N,K]"
+        assert x.dtype == w_compute.dtype, f"activation {x.dtype} vs weight {w_compute.dtype}"
+        assert not (act != ACT_NONE and residual is not None), "activation + residual in one epilogue is unused on this path"
+        odt = out_dtype or x.dtype
+        y = torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
+        pre = torch.empty_like(y) if act in _ACT_FROM_PREACT else None
+        if residual is not None:
+            residual = residual.contiguous()
+            assert residual.shape == y.shape and residual.dtype == odt
+        gemm(GEMM_NT, M, N, K, x.data_ptr(), lda, w_compute.data_ptr(), K, y.data_ptr(), N, dtype=_dt(x),
+             c_dtype=_dt(y), bias=_ptr(bias), act=act, residual=_ptr(residual), ldr=N, preact=_ptr(pre),
+             splitk_ws=_workspace(64 << 20, x.device) if M <= 64 else None)
+        ctx.act, ctx.dims, ctx.has_bias, ctx.has_res = act, (M, N, K, lda), bias is not None, residual is not None
+        ctx.save_for_backward(x, w_compute, pre if pre is not None else (y if act in _ACT_FROM_OUTPUT else None))
+        ctx.w_needs = w_master.requires_grad
+        ctx.w_master = w_master
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, ref = ctx.saved_tensors
+        M, N, K, lda = ctx.dims
+        g = g.contiguous()
+        gres = g if ctx.has_res else None
+        if ctx.act != ACT_NONE:
+            gg = torch.empty_like(g)
+            _lib.call("d2r_act_bwd", _dt(g), ctx.act, g.data_ptr(), ref.data_ptr(), gg.data_ptr(), g.numel(), _stream())
+            g = gg
+        if g.dtype != x.dtype:  # fp32-output GEMMs (router logits, SAF scores): operands must share a dtype
+            g = cast(g, x.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxc = torch.empty(M, K, dtype=x.dtype, device=x.device)
+            gemm(GEMM_NN, M, K, N, g.data_ptr(), N, w.data_ptr(), K, dxc.data_ptr(), K, dtype=_dt(x), c_dtype=_dt(x),
+                 splitk_ws=_workspace(64 << 20, x.device) if M <= 64 else None)
+            dx = dxc.view(*x.shape[:-1], K) if x.dim() != 2 else dxc
+        if ctx.w_needs:
+            sink = getattr(ctx.w_master, "_d2r_grad", None)  # flat fp32 gradient buffer (d2r_amd.params.ParamStore)
+            if sink is not None:
+                # dW accumulates straight into the zero-initialised flat buffer: no temp, no autograd add kernel
+                gemm(GEMM_TN, N, K, M, g.data_ptr(), N, x.data_ptr(), lda, sink.data_ptr(), K, dtype=_dt(x),
+                     c_dtype=F32, beta=1.0, splitk_ws=_workspace(64 << 20, x.device))
+                cb = getattr(ctx.w_master, "_d2r_ready_cb", None)  # data-parallel bucket readiness (d2r_amd.dp)
+                if cb is not None:
+                    cb(ctx.w_master)
+            else:
+                dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
+                gemm(GEMM_TN, N, K, M, g.data_ptr(), N, x.data_ptr(), lda, dw.data_ptr(), K, dtype=_dt(x), c_dtype=F32,
+                     splitk_ws=_workspace(64 << 20, x.device))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(g, M, N, N)
+        return dx, dw, db, None, None, gres, None
+
+
+def linear(x, w_master, bias, w_compute=None, act=ACT_NONE, residual=None, out_dtype=None):
+    """F.linear with fused bias/activation/residual epilogue.  ``w_master`` is the fp32 parameter that receives
+    the gradient; ``w_compute`` the (possibly bf16) copy multiplied with."""
+    return _Linear.apply(x, w_master, bias, w_master if w_compute is None else w_compute, act, residual, out_dtype)
+
+
+class _MatmulNT(torch.autograd.Function):
+    """C = A B^T for 2-D row-major A [M,K], B [N,K]; fp32 output (similarity matrices, [B,B])."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        M, K = a.shape
+        N = b.shape[0]
+        c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        gemm(GEMM_NT, M, N, K, a.data_ptr(), K, b.data_ptr(), K, c.data_ptr(), N, dtype=_dt(a), c_dtype=F32)
+        ctx.save_for_backward(a, b)
+        return c
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        M, K = a.shape
+        N = b.shape[0]
+        g = cast(g.contiguous(), a.dtype)
+        da = torch.empty_like(a)
+        db = torch.empty_like(b)
+        gemm(GEMM_NN, M, K, N, g.data_ptr(), N, b.data_ptr(), K, da.data_ptr(), K, dtype=_dt(a), c_dtype=_dt(a))
+        gemm(GEMM_TN, N, K, M, g.data_ptr(), N, a.data_ptr(), K, db.data_ptr(), K, dtype=_dt(a), c_dtype=_dt(a))
+        return da, db
+
+
+def matmul_nt(a, b):
+    return _MatmulNT.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------
+# attention: O = softmax(scale * Q K^T + mask) V (+ residual), H heads; logits kept fp32
+# ------------------------------------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, H, scale, mask, residual):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, Lq, E = q.shape
+        Lk = k.shape[1]
+        d = E // H
+        Lkp = (Lk + 7) // 8 * 8
+        dt = _dt(q)
+        tag = "xattn_core_fwd" if H == 1 else "mha_core_fwd"
+        S = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=q.device)
+        gemm(GEMM_NT, Lq, Lk, d, q.data_ptr(), E, k.data_ptr(), E, S.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B, nh=H,
+             sA=(Lq * E, d), sB=(Lk * E, d), sC=(H * Lq * Lkp, Lq * Lkp), tag=tag)
+        if _lib._timer is not None:  # algorithmic bytes of the fused core = B(2Lq+2Lk)D s
+            _lib._timer.records[-1][1]["algo_bytes"] = float(B * (2 * Lq + 2 * Lk) * E * q.element_size())
+        if q.dtype == torch.float32:
+            P = S
+        else:
+            P = torch.empty(B, H, Lq, Lkp, dtype=q.dtype, device=q.device)
+        _lib.call("d2r_softmax_fwd", F32, dt, S.data_ptr(), P.data_ptr(), Lkp, B * H * Lq, Lk, scale, _ptr(mask),
+                  H * Lq, _stream(), meta=dict(group=tag))
+        if Lkp != Lk and q.dtype != torch.float32:
+            pass  # padding columns of P are never read (K = Lk in the GEMMs below)
+        o = torch.empty(B, Lq, E, dtype=q.dtype, device=q.device)
+        if residual is not None:
+            residual = residual.contiguous()
+        gemm(GEMM_NN, Lq, d, Lk, P.data_ptr(), Lkp, v.data_ptr(), E, o.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
+             sA=(H * Lq * Lkp, Lq * Lkp), sB=(Lk * E, d), sC=(Lq * E, d), residual=_ptr(residual), ldr=E,
+             sR=(Lq * E, d), tag=tag)
+        ctx.save_for_backward(q, k, v, P)
+        ctx.cfg = (B, Lq, Lk, Lkp, E, H, d, scale, residual is not None)
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, P = ctx.saved_tensors
+        B, Lq, Lk, Lkp, E, H, d, scale, has_res = ctx.cfg
+        g = g.contiguous()
+        dt = _dt(q)
+        tag = "xattn_core_bwd" if H == 1 else "mha_core_bwd"
+        sP = (H * Lq * Lkp, Lq * Lkp)
+        dv = torch.empty_like(v)
+        gemm(GEMM_TN, Lk, d, Lq, P.data_ptr(), Lkp, g.data_ptr(), E, dv.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
+             sA=sP, sB=(Lq * E, d), sC=(Lk * E, d), tag=tag)
+        dP = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=q.device)
+        gemm(GEMM_NT, Lq, Lk, d, g.data_ptr(), E, v.data_ptr(), E, dP.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B,
+             nh=H, sA=(Lq * E, d), sB=(Lk * E, d), sC=sP, tag=tag)
+        dS = dP if q.dtype == torch.float32 else torch.empty(B, H, Lq, Lkp, dtype=q.dtype, device=q.device)
+        _lib.call("d2r_softmax_bwd", dt, F32, P.data_ptr(), dP.data_ptr(), dS.data_ptr(), Lkp, B * H * Lq, Lk, scale,
+                  _stream(), meta=dict(group=tag))
+        dq = torch.empty_like(q)
+        gemm(GEMM_NN, Lq, d, Lk, dS.data_ptr(), Lkp, k.data_ptr(), E, dq.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
+             sA=sP, sB=(Lk * E, d), sC=(Lq * E, d), tag=tag)
+        dk = torch.empty_like(k)
+        gemm(GEMM_TN, Lk, d, Lq, dS.data_ptr(), Lkp, q.data_ptr(), E, dk.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
+             sA=sP, sB=(Lq * E, d), sC=(Lk * E, d), tag=tag)
+        return dq, dk, dv, None, None, None, (g if has_res else None)
+
+
+def attention(q, k, v, num_heads, scale, mask=None, residual=None):
+    """q [B,Lq,E], k/v [B,Lk,E]; mask: fp32 additive [B,Lk] or None; residual [B,Lq,E] added to the output."""
+    return _Attention.apply(q, k, v, num_heads, float(scale), mask, residual)
+
+
+# ------------------------------------------------------------------------------------------------------
+# row kernels
+# ------------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _lib.call("d2r_layernorm_fwd", _dt(x), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, rows, D,
+                  y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        g = g.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        dx = torch.empty_like(x)
+        dg = torch.empty(D, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        nbytes = _lib.load().d2r_layernorm_bwd_workspace(rows, D)
+        ws = _workspace(nbytes, x.device)
+        _lib.call("d2r_layernorm_bwd", _dt(x), g.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), rows, D, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                  _stream())
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        norm = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.call("d2r_l2norm_fwd", _dt(x), x.data_ptr(), y.data_ptr(), norm.data_ptr(), rows, D, _stream())
+        ctx.save_for_backward(x, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, norm = ctx.saved_tensors
+        g = g.contiguous()
+        D = x.shape[-1]
+        dx = torch.empty_like(x)
+        _lib.call("d2r_l2norm_bwd", _dt(x), g.data_ptr(), x.data_ptr(), norm.data_ptr(), dx.data_ptr(), x.numel() // D,
+                  D, _stream())
+        return dx
+
+
+def l2norm(x):
+    return _L2Norm.apply(x)
+
+
+class _SoftmaxRows(torch.autograd.Function):
+    """softmax over the last dim of a 2-D tensor (GESC feature gate, models/Cells.py:204)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        _lib.call("d2r_softmax_fwd", _dt(x), _dt(x), x.data_ptr(), y.data_ptr(), cols, rows, cols, 1.0, None, 1,
+                  _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        rows, cols = y.shape
+        dx = torch.empty_like(y)
+        _lib.call("d2r_softmax_bwd", _dt(y), _dt(y), y.data_ptr(), g.data_ptr(), dx.data_ptr(), cols, rows, cols, 1.0,
+                  _stream())
+        return dx
+
+
+def softmax_rows(x):
+    return _SoftmaxRows.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------------
+# elementwise
+# ------------------------------------------------------------------------------------------------------
+class _SqDiff(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        _lib.call("d2r_sqdiff_fwd", _dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        _lib.call("d2r_sqdiff_bwd", _dt(a), a.data_ptr(), b.data_ptr(), g.data_ptr(), da.data_ptr(), db.data_ptr(),
+                  a.numel(), _stream())
+        return da, db
+
+
+def sqdiff(a, b):
+    return _SqDiff.apply(a, b)
+
+
+class _MulAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, s, h):
+        a, s, h = a.contiguous(), s.contiguous(), h.contiguous()
+        out = torch.empty_like(a)
+        _lib.call("d2r_muladd_fwd", _dt(a), a.data_ptr(), s.data_ptr(), h.data_ptr(), out.data_ptr(), a.numel(), _stream())
+        ctx.save_for_backward(a, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, s = ctx.saved_tensors
+        g = g.contiguous()
+        da, ds = torch.empty_like(a), torch.empty_like(s)
+        _lib.call("d2r_muladd_bwd", _dt(a), a.data_ptr(), s.data_ptr(), g.data_ptr(), da.data_ptr(), ds.data_ptr(),
+                  a.numel(), _stream())
+        return da, ds, g
+
+
+def muladd(a, s, h):
+    """a * s + h (FiLM modulation, models/Refinement.py:136)."""
+    return _MulAdd.apply(a, s, h)
+
+
+class _Lerp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_, a, b):
+        g_, a, b = g_.contiguous(), a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        _lib.call("d2r_lerp_fwd", _dt(a), g_.data_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+        ctx.save_for_backward(g_, a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        g_, a, b = ctx.saved_tensors
+        d = d.contiguous()
+        dg, da, db = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        _lib.call("d2r_lerp_bwd", _dt(a), g_.data_ptr(), a.data_ptr(), b.data_ptr(), d.data_ptr(), dg.data_ptr(),
+                  da.data_ptr(), db.data_ptr(), a.numel(), _stream())
+        return dg, da, db
+
+
+def lerp_gate(g, a, b):
+    """g*a + (1-g)*b (models/Cells.py:205)."""
+    return _Lerp.apply(g, a, b)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        _lib.call("d2r_add", _dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _LinComb(torch.autograd.Function):
+    """out = sum_k c_k x_k for fp32 device scalars (total loss)."""
+
+    @staticmethod
+    def forward(ctx, coefs, *xs):
+        out = torch.empty((), dtype=torch.float32, device=xs[0].device)
+        carr = (C.c_float * len(xs))(*coefs)
+        _lib.call("d2r_lincomb", _parr(xs), carr, len(xs), out.data_ptr(), _stream())
+        ctx.coefs = coefs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        outs = []
+        for c in ctx.coefs:
+            d = torch.empty_like(g)
+            _lib.call("d2r_axpby", F32, float(c), g.data_ptr(), 0.0, d.data_ptr(), 1, _stream())
+            outs.append(d)
+        return (None, *outs)
+
+
+def lincomb(coefs, xs):
+    return _LinComb.apply(tuple(float(c) for c in coefs), *xs)
+
+
+# ------------------------------------------------------------------------------------------------------
+# K1 router pooling and K8 route aggregation
+# ------------------------------------------------------------------------------------------------------
+class _MeanPool(torch.autograd.Function):
+    """mean over tokens of n sources [B,L,D] -> fp32 [n,B,D] in one launch (models/Router.py:23)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [x.contiguous() for x in xs]
+        B, L, D = xs[0].shape
+        pooled = torch.empty(len(xs), B, D, dtype=torch.float32, device=xs[0].device)
+        _lib.call("d2r_meanpool_fwd", _dt(xs[0]), _parr(xs), len(xs), B, L, D, pooled.data_ptr(), _stream(),
+                  meta=dict(group="router_pool_fwd", bytes=float(len(xs) * B * L * D * xs[0].element_size() + len(xs) * B * D * 4)))
+        ctx.meta = (B, L, D, xs[0].dtype, len(xs))
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        B, L, D, dtype, n = ctx.meta
+        g = g.contiguous()
+        outs = []
+        for i in range(n):
+            dx = torch.empty(B, L, D, dtype=dtype, device=g.device)
+            _lib.call("d2r_meanpool_bwd", BF16 if dtype == torch.bfloat16 else F32, g[i].data_ptr(), B, L, D,
+                      dx.data_ptr(), 0, _stream())
+            outs.append(dx)
+        return tuple(outs)
+
+
+def mean_pool(xs: Sequence[torch.Tensor]) -> torch.Tensor:
+    return _MeanPool.apply(*xs)
+
+
+class _RouteAggregate(torch.autograd.Function):
+    """K8: outs_i = sum_j p_hat[i,j] emb_j + gate_i relu(x0)  (P=6), or the final-layer rule (P=1)."""
+
+    @staticmethod
+    def forward(ctx, gates, x0, e1, e2, e3, e4, e5, *refs):
+        embs = [t.contiguous() for t in (x0, e1, e2, e3, e4, e5)]
+        gates = gates.contiguous()
+        B, L, D = embs[0].shape
+        P = gates.shape[2]
+        final = P == 1
+        refs = [r.contiguous() for r in refs]
+        if final:
+            assert len(refs) == 5, "the final layer takes ref_1..ref_5 (ref_0 is x0)"
+            all_refs = [embs[0]] + refs
+        outs = [torch.empty(B, L, D, dtype=embs[0].dtype, device=embs[0].device) for _ in range(P)]
+        probs = torch.empty(B, P, 6, dtype=torch.float32, device=gates.device)
+        _lib.call("d2r_route_aggregate_fwd", _dt(embs[0]), _parr(embs), _parr(all_refs) if final else None,
+                  gates.data_ptr(), B, L, D, P, _parr(outs), probs.data_ptr(), _stream(),
+                  meta=dict(group=f"route_aggregate_fwd_P{P}",
+                            bytes=float(((4 + P) * B * L * D + 2 * B * D) * embs[0].element_size() + 4 * B * P * 12)))
+        ctx.meta = (B, L, D, P)
+        ctx.save_for_backward(gates, *embs, *refs, *(outs if final else []))
+        ctx.mark_non_differentiable()
+        return (probs, *outs)
+
+    @staticmethod
+    def backward(ctx, dprobs, *douts):
+        B, L, D, P = ctx.meta
+        final = P == 1
+        saved = ctx.saved_tensors
+        gates, embs = saved[0], list(saved[1:7])
+        refs = list(saved[7:12]) if final else []
+        out_saved = [saved[12]] if final else []
+        dev, dtype = embs[0].device, embs[0].dtype
+        douts = [(d if d is not None else torch.zeros(B, L, D, dtype=dtype, device=dev)).contiguous() for d in douts]
+        dprobs = None if dprobs is None else dprobs.contiguous()
+        dembs = [torch.empty_like(e) for e in embs]
+        drefs = [torch.empty(B, L, D, dtype=dtype, device=dev) for _ in range(6)] if final else None
+        dgates = torch.empty_like(gates)
+        nbytes = _lib.load().d2r_route_aggregate_bwd_workspace(B, L, D, P)
+        ws = _workspace(nbytes, dev)
+        _lib.call("d2r_route_aggregate_bwd", _dt(embs[0]), _parr(embs), _parr([embs[0]] + refs) if final else None,
+                  gates.data_ptr(), _parr(douts), _parr(out_saved) if final else None, _ptr(dprobs), B, L, D, P,
+                  _parr(dembs), _parr(drefs) if final else None, dgates.data_ptr(), ws.data_ptr(), ws.numel(),
+                  _stream(), meta=dict(group=f"route_aggregate_bwd_P{P}",
+                                       bytes=float(((P + 4 + 4 + (6 if final else 0) + (1 if final else 0)) * B * L * D
+                                                    + 4 * B * D) * embs[0].element_size())))
+        if final:
+            # ref_0 is x0 itself: relu path + skip path
+            dx0 = add(dembs[0], drefs[0])
+            return (dgates, dx0, *dembs[1:], *drefs[1:])
+        return (dgates, *dembs)
+
+
+def route_aggregate(gates, x0, e1, e2, e3, e4, e5, refs: Optional[Sequence[torch.Tensor]] = None):
+    """gates fp32 [6,B,P]; returns (probs [B,P,6], [outs])."""
+    res = _RouteAggregate.apply(gates, x0, e1, e2, e3, e4, e5, *(refs or ()))
+    return res[0], list(res[1:])
+
+
+# ------------------------------------------------------------------------------------------------------
+# K6 SAF gate, weighted row sum
+# ------------------------------------------------------------------------------------------------------
+class _SafGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, bn_w, bn_b, running_mean, running_var, train):
+        a = a.contiguous()
+        B, n = a.shape
+        w = torch.empty_like(a)
+        saved = torch.empty(2, dtype=torch.float32, device=a.device)
+        _lib.call("d2r_saf_gate_fwd", a.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(), running_mean.data_ptr(),
+                  running_var.data_ptr(), 1 if train else 0, w.data_ptr(), saved.data_ptr(), _stream())
+        ctx.save_for_backward(a, bn_w, bn_b, saved)
+        ctx.train = train
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        a, bn_w, bn_b, saved = ctx.saved_tensors
+        dw = dw.contiguous()
+        B, n = a.shape
+        da = torch.empty_like(a)
+        dbw, dbb = torch.empty_like(bn_w), torch.empty_like(bn_b)
+        _lib.call("d2r_saf_gate_bwd", a.data_ptr(), dw.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(),
+                  saved.data_ptr(), 1 if ctx.train else 0, da.data_ptr(), dbw.data_ptr(), dbb.data_ptr(), _stream())
+        return da, dbw, dbb, None, None, None
+
+
+def saf_gate(a, bn_w, bn_b, running_mean, running_var, train: bool):
+    """l1norm(sigmoid(BatchNorm1d(1)(a))) over the last dim of fp32 a [B,n] (models/XModules.py:380-381)."""
+    return _SafGate.apply(a, bn_w, bn_b, running_mean, running_var, bool(train))
+
+
+class _WeightedRowSum(torch.autograd.Function):
+    """out[b] = w[b] @ S[b]  (w [B,n] in S's dtype, S [B,n,D]) — torch.matmul(sim_attn, sim_emb), XModules.py:382."""
+
+    @staticmethod
+    def forward(ctx, w, S):
+        w, S = w.contiguous(), S.contiguous()
+        B, n, D = S.shape
+        out = torch.empty(B, D, dtype=S.dtype, device=S.device)
+        gemm(GEMM_NN, 1, D, n, w.data_ptr(), n, S.data_ptr(), D, out.data_ptr(), D, dtype=_dt(S), c_dtype=_dt(S), nb=B,
+             sA=(n, 0), sB=(n * D, 0), sC=(D, 0))
+        ctx.save_for_backward(w, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, S = ctx.saved_tensors
+        g = g.contiguous()
+        B, n, D = S.shape
+        dw = torch.empty_like(w)
+        gemm(GEMM_NT, 1, n, D, g.data_ptr(), D, S.data_ptr(), D, dw.data_ptr(), n, dtype=_dt(S), c_dtype=_dt(S), nb=B,
+             sA=(D, 0), sB=(n * D, 0), sC=(n, 0))
+        dS = torch.empty_like(S)
+        gemm(GEMM_TN, n, D, 1, w.data_ptr(), n, g.data_ptr(), D, dS.data_ptr(), D, dtype=_dt(S), c_dtype=_dt(S), nb=B,
+             sA=(n, 0), sB=(D, 0), sC=(n * D, 0))
+        return dw, dS
+
+
+def weighted_row_sum(w, S):
+    return _WeightedRowSum.apply(w, S)
+
+
+# ------------------------------------------------------------------------------------------------------
+# losses and Block fusion core
+# ------------------------------------------------------------------------------------------------------
+class _JsDiv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, q):
+        p, q = p.contiguous(), q.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=p.device)
+        _lib.call("d2r_jsdiv_fwd", p.data_ptr(), q.data_ptr(), p.shape[0], out.data_ptr(), _stream())
+        ctx.save_for_backward(p, q)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, q = ctx.saved_tensors
+        g = g.contiguous()
+        dp, dq = torch.empty_like(p), torch.empty_like(q)
+        _lib.call("d2r_jsdiv_bwd", p.data_ptr(), q.data_ptr(), p.shape[0], g.data_ptr(), dp.data_ptr(), dq.data_ptr(),
+                  _stream())
+        return dp, dq
+
+
+def js_div(p_logits, q_logits):
+    assert p_logits.dtype == torch.float32 and q_logits.dtype == torch.float32
+    return _JsDiv.apply(p_logits, q_logits)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = logits.contiguous()
+        labels = labels.contiguous().long()
+        B, Cn = logits.shape
+        out = torch.empty((), dtype=torch.float32, device=logits.device)
+        _lib.call("d2r_ce_fwd", logits.data_ptr(), labels.data_ptr(), B, Cn, out.data_ptr(), _stream())
+        ctx.save_for_backward(logits, labels)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels = ctx.saved_tensors
+        g = g.contiguous()
+        B, Cn = logits.shape
+        d = torch.empty_like(logits)
+        _lib.call("d2r_ce_bwd", logits.data_ptr(), labels.data_ptr(), B, Cn, g.data_ptr(), d.data_ptr(), _stream())
+        return d, None
+
+
+def cross_entropy(logits, labels):
+    assert logits.dtype == torch.float32
+    return _CrossEntropy.apply(logits, labels)
+
+
+class _BlockMerge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m0, m1, Cn, R, S):
+        m0, m1 = m0.contiguous(), m1.contiguous()
+        B = m0.shape[0]
+        out = torch.empty(B, Cn * S, dtype=m0.dtype, device=m0.device)
+        zraw = torch.empty(B, Cn * S, dtype=torch.float32, device=m0.device)
+        _lib.call("d2r_block_merge_fwd", _dt(m0), m0.data_ptr(), m1.data_ptr(), B, Cn, R, S, out.data_ptr(),
+                  zraw.data_ptr(), _stream())
+        ctx.save_for_backward(m0, m1, zraw)
+        ctx.meta = (B, Cn, R, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m0, m1, zraw = ctx.saved_tensors
+        B, Cn, R, S = ctx.meta
+        g = g.contiguous()
+        d0, d1 = torch.empty_like(m0), torch.empty_like(m1)
+        _lib.call("d2r_block_merge_bwd", _dt(m0), m0.data_ptr(), m1.data_ptr(), zraw.data_ptr(), g.data_ptr(), B, Cn, R,
+                  S, d0.data_ptr(), d1.data_ptr(), _stream())
+        return d0, d1, None, None, None
+
+
+def block_merge(m0, m1, chunks, rank, size):
+    """m0, m1: [B, chunks, rank*size] -> [B, chunks*size] (models/XModules.py:541-549)."""
+    return _BlockMerge.apply(m0, m1, chunks, rank, size)
+
+
+# ------------------------------------------------------------------------------------------------------
+# K12 embeddings
+# ------------------------------------------------------------------------------------------------------
+class _BertEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, tt, word, pos, typ, dtype):
+        ids, tt = ids.contiguous().long(), tt.contiguous().long()
+        B, L = ids.shape
+        D = word.shape[1]
+        out = torch.empty(B, L, D, dtype=dtype, device=word.device)
+        _lib.call("d2r_bert_embed_fwd", _dt(out), ids.data_ptr(), tt.data_ptr(), word.data_ptr(), pos.data_ptr(),
+                  typ.data_ptr(), B, L, D, word.shape[0], typ.shape[0], out.data_ptr(), _stream())
+        ctx.save_for_backward(ids, tt)
+        ctx.shapes = (word.shape, pos.shape, typ.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, tt = ctx.saved_tensors
+        g = g.contiguous()
+        B, L, D = g.shape
+        ws, ps, ts = ctx.shapes
+        dword = torch.zeros(ws, dtype=torch.float32, device=g.device)
+        dpos = torch.zeros(ps, dtype=torch.float32, device=g.device)
+        dtyp = torch.zeros(ts, dtype=torch.float32, device=g.device)
+        _lib.call("d2r_bert_embed_bwd", _dt(g), g.data_ptr(), ids.data_ptr(), tt.data_ptr(), B, L, D, 0,
+                  dword.data_ptr(), dpos.data_ptr(), dtyp.data_ptr(), _stream())
+        return None, None, dword, dpos, dtyp, None
+
+
+def bert_embed(ids, tt, word, pos, typ, dtype):
+    return _BertEmbed.apply(ids, tt, word, pos, typ, dtype)
+
+
+class _ClipEmbed(torch.autograd.Function):
+    """CLIPVisionEmbeddings (models/modeling_unimo.py:108-118): patch conv as a GEMM on unfolded patches."""
+
+    @staticmethod
+    def forward(ctx, pixels, w_master, w_compute, cls, pos, patch):
+        pixels = pixels.contiguous().float()
+        B, _, Hh, Ww = pixels.shape
+        E = w_compute.shape[0]
+        K = 3 * patch * patch
+        npatch = (Hh // patch) * (Ww // patch)
+        ntok = npatch + 1
+        dtype = w_compute.dtype
+        patches = torch.empty(B * npatch, K, dtype=dtype, device=pixels.device)
+        _lib.call("d2r_patchify", _dt(patches), pixels.data_ptr(), B, Hh, Ww, patch, patches.data_ptr(), _stream())
+        x = torch.empty(B, ntok, E, dtype=dtype, device=pixels.device)
+        w2 = w_compute.view(E, K)
+        es = x.element_size()
+        gemm(GEMM_NT, npatch, E, K, patches.data_ptr(), K, w2.data_ptr(), K, x.data_ptr() + E * es, E, dtype=_dt(x),
+             c_dtype=_dt(x), nb=B, sA=(npatch * K, 0), sC=(ntok * E, 0))
+        _lib.call("d2r_clip_embed_finish", _dt(x), x.data_ptr(), cls.data_ptr(), pos.data_ptr(), B, ntok, E, _stream())
+        ctx.save_for_backward(patches)
+        ctx.meta = (B, npatch, ntok, E, K, tuple(w_master.shape))
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (patches,) = ctx.saved_tensors
+        B, npatch, ntok, E, K, wshape = ctx.meta
+        g = g.contiguous()
+        dcls = torch.empty(E, dtype=torch.float32, device=g.device)
+        dpos = torch.empty(ntok, E, dtype=torch.float32, device=g.device)
+        _lib.call("d2r_clip_embed_bwd", _dt(g), g.data_ptr(), B, ntok, E, dcls.data_ptr(), dpos.data_ptr(), _stream())
+        # dW[E,K] = sum_b dY_b^T patches_b : B accumulating TN GEMMs would serialise; batch them through beta
+        dw = torch.empty(E, K, dtype=torch.float32, device=g.device)
+        es = g.element_size()
+        for b in range(B):
+            gemm(GEMM_TN, E, K, npatch, g.data_ptr() + (b * ntok + 1) * E * es, E,
+                 patches.data_ptr() + b * npatch * K * es, K, dw.data_ptr(), K, dtype=_dt(g), c_dtype=F32,
+                 beta=0.0 if b == 0 else 1.0)
+        return None, dw.view(wshape), None, dcls, dpos, None
+
+
+def clip_embed(pixels, w_master, w_compute, cls, pos, patch):
+    return _ClipEmbed.apply(pixels, w_master, w_compute, cls, pos, patch)

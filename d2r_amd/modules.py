@@ -1,0 +1,663 @@
+"""Host-side mirror of the reference's model classes for the D2R hot path, computing through libd2r_hip.so.
+
+Class / attribute names reproduce the reference's ``state_dict`` keys exactly (1,210 keys at DR_step=3) so that
+``best_model.pth`` checkpoints and the weight-ingest rename rule (modules/train.py:92-111) interchange.  All
+arithmetic is done by the HIP kernels behind ``d2r_amd.functional``; these classes only own parameters and
+sequence launches.
+
+Reference map (file:line under the reference tree):
+  Router                           models/Router.py:10-26
+  *Cell                            models/Cells.py:30-40,42-60,76-87,131-175,179-218,222-255
+  SelfAttention / Refinement       models/SelfAttention.py:11-70, models/Refinement.py:86-154
+  CrossModalAlignment / SAF / Block  models/XModules.py:277-328,366-394,478-555
+  DynamicInteraction layers        models/DynamicInteraction.py:20-254
+  (Reversed_)InteractionModule     models/InteractionModule.py:9-108
+  encoders, UnimoModel             models/modeling_unimo.py:87-527,649-894
+  UnimoModelF                      models/unimo_model.py:138-162
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_TANH, ACT_TANH_RELU)
+
+E = 768  # the routing cells are hard-wired to 768 features (models/Cells.py:140-143)
+CELL_ORDER = ("ric", "glac", "imrc", "cmrc", "crcmc", "gesc")  # index j of models/DynamicInteraction.py:41-48
+
+
+class D2RModule(nn.Module):
+    """Base: carries the compute dtype of the HIP path (fp32 or bf16 activations/weights)."""
+
+    cdtype = torch.float32
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        for m in self.modules():
+            if isinstance(m, D2RModule):
+                m.cdtype = dtype
+        return self
+
+
+def _compute_weight(p: nn.Parameter, dtype: torch.dtype) -> torch.Tensor:
+    if dtype == torch.float32:
+        return p
+    lp = getattr(p, "_d2r_lp", None)  # bf16 shadow maintained by d2r_amd.params.ParamStore / the fused AdamW
+    if lp is not None:
+        return lp
+    return F.cast(p.detach(), dtype)  # un-prepared model: cast on the fly (still a HIP kernel)
+
+
+class Linear(D2RModule):
+    """nn.Linear parameters (fp32 masters) + fused GEMM epilogue."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        bound = 1.0 / math.sqrt(in_features)
+        self.weight = nn.Parameter(torch.empty(out_features, in_features).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound)) if bias else None
+
+    def forward(self, x, act=ACT_NONE, residual=None, fp32=False, out_dtype=None):
+        """fp32=True keeps the whole product in fp32 (router / gate logits)."""
+        if fp32:
+            return F.linear(x, self.weight, self.bias, None, act, residual, out_dtype)
+        return F.linear(x, self.weight, self.bias, _compute_weight(self.weight, self.cdtype), act, residual, out_dtype)
+
+
+class LayerNorm(D2RModule):
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        return F.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class BatchNorm1dScalar(nn.Module):
+    """BatchNorm1d(1) parameters/buffers of AttentionFiltration (models/XModules.py:376)."""
+
+    def __init__(self, num_features=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _Sequential(nn.Module):
+    """Index-named children ('0', '2', ...) like nn.Sequential, without its forward."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for k, v in children.items():
+            self.add_module(k, v)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+
+# ------------------------------------------------------------------------------------------------------
+# router + cells
+# ------------------------------------------------------------------------------------------------------
+class Router(D2RModule):
+    """relu(tanh(W2 relu(W1 mean_tokens(x)))) — fp32 end to end so that routing decisions are exact."""
+
+    def __init__(self, num_out_path, embed_size, hid):
+        super().__init__()
+        self.num_out_path = num_out_path
+        self.mlp = _Sequential(**{"0": Linear(embed_size, hid), "2": Linear(hid, num_out_path)})
+        with torch.no_grad():
+            self.mlp[2].bias.fill_(1.5)  # models/Router.py:19-20
+
+    def gate_from_pooled(self, pooled):  # pooled: fp32 [B, 768]
+        h = self.mlp[0](pooled, act=ACT_RELU, fp32=True)
+        return self.mlp[2](h, act=ACT_TANH_RELU, fp32=True)
+
+    def forward(self, x):
+        return self.gate_from_pooled(F.mean_pool([x])[0])
+
+
+class BertPooler(D2RModule):
+    def __init__(self, hidden=E):
+        super().__init__()
+        self.dense = Linear(hidden, hidden)
+
+    def forward(self, hidden_states):
+        return self.dense(hidden_states[:, 0], act=ACT_TANH)  # strided rows, no copy
+
+
+class CrossModalAlignment(D2RModule):
+    """softmax(100 (Wq t)(Wk i)^T / sqrt(768)) (Wv i): the live part of models/XModules.py:300-310 (identical in
+    models/Refinement.py:105-115).  fc_1/fc_2 are kept as (dead) parameters; the discarded reverse-attention /
+    contrastive branch (XModules.py:312-326) is not computed."""
+
+    def __init__(self):
+        super().__init__()
+        self.query, self.key, self.value = Linear(E, E), Linear(E, E), Linear(E, E)
+        self.fc_1, self.fc_2 = Linear(E, E), Linear(E, E)
+
+    def forward(self, own, other):
+        return F.attention(self.query(own), self.key(other), self.value(other), 1, 100.0 / math.sqrt(E))
+
+
+class RectifiedIdentityCell(D2RModule):
+    """emb = relu(x): the relu is fused into the route_aggregate kernel, so the cell returns its input."""
+
+    def __init__(self, args, num_out_path):
+        super().__init__()
+        self.router = Router(num_out_path, args.embed_size, args.hid_router)
+
+    def forward(self, x, other=None):
+        return x
+
+
+class AttentionLayer(D2RModule):
+    def __init__(self, embed_size, h):
+        super().__init__()
+        self.h = h
+        self.linears = nn.ModuleList([Linear(embed_size, embed_size) for _ in range(3)])
+
+
+class FeedForward(D2RModule):
+    def __init__(self, embed_size, hidden):
+        super().__init__()
+        self.fc1, self.fc2 = Linear(embed_size, hidden), Linear(hidden, embed_size)
+
+
+class SelfAttention(D2RModule):
+    """IMRC body (models/SelfAttention.py:56-70): y = x + MHA16(x) (no out-proj); y + W2 relu(W1 y)."""
+
+    def __init__(self, embed_size, hid_size, h):
+        super().__init__()
+        self.h = h
+        self.att_layer = AttentionLayer(embed_size, h)
+        self.feed_forward_layer = FeedForward(embed_size, hid_size)
+
+    def forward(self, x):
+        q, k, v = (lin(x) for lin in self.att_layer.linears)
+        y = F.attention(q, k, v, self.h, 1.0 / math.sqrt(x.shape[-1] // self.h), residual=x)
+        return self.feed_forward_layer.fc2(self.feed_forward_layer.fc1(y, act=ACT_RELU), residual=y)
+
+
+class IntraModelReasoningCell(D2RModule):
+    def __init__(self, args, num_out_path):
+        super().__init__()
+        self.router = Router(num_out_path, args.embed_size, args.hid_router)
+        self.sa = SelfAttention(args.embed_size, args.hid_IMRC, args.num_head_IMRC)
+
+    def forward(self, x, other=None):
+        return self.sa(x)
+
+
+class Refinement(D2RModule):
+    """CMRC body (models/Refinement.py:133-154)."""
+
+    def __init__(self, embed_size):
+        super().__init__()
+        self.fc_scale, self.fc_shift = Linear(embed_size, embed_size), Linear(embed_size, embed_size)
+        self.fc_1, self.fc_2 = Linear(embed_size, embed_size), Linear(embed_size, embed_size)
+        self.CrossModalAlignment = CrossModalAlignment()
+
+    def forward(self, own, other):
+        c = self.CrossModalAlignment(own, other)
+        mod = F.muladd(own, self.fc_scale(c, act=ACT_TANH), self.fc_shift(c))
+        return self.fc_2(self.fc_1(mod, act=ACT_RELU), residual=own)
+
+
+class CrossModalRefinementCell(D2RModule):
+    def __init__(self, args, num_out_path):
+        super().__init__()
+        self.refine = Refinement(args.embed_size)
+        self.router = Router(num_out_path, args.embed_size, args.hid_router)
+
+    def forward(self, own, other):
+        return self.refine(own, other)
+
+
+class AttentionFiltration(D2RModule):
+    """SAF (models/XModules.py:366-394): l2norm(l1norm(sigmoid(BN1(w.S))) @ S)."""
+
+    def __init__(self, sim_dim):
+        super().__init__()
+        self.attn_sim_w = Linear(sim_dim, 1)
+        self.bn = BatchNorm1dScalar(1)
+        r = math.sqrt(6.0) / math.sqrt(sim_dim + 1)
+        with torch.no_grad():
+            self.attn_sim_w.weight.uniform_(-r, r)
+            self.attn_sim_w.bias.zero_()
+
+    def forward(self, S):
+        B, n, _ = S.shape
+        a = self.attn_sim_w(S, out_dtype=torch.float32).view(B, n)
+        w = F.saf_gate(a, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, self.training)
+        if self.training:
+            self.bn.num_batches_tracked += 1
+        return F.l2norm(F.weighted_row_sum(F.cast_ad(w, S.dtype), S))
+
+
+class GlobalLocalAlignmentCell(D2RModule):
+    def __init__(self, args, num_out_path):
+        super().__init__()
+        self.router = Router(num_out_path, args.embed_size, args.hid_router)
+        self.CrossModalAlignment = CrossModalAlignment()
+        self.SAF_module = AttentionFiltration(E)
+        self.text_cls_pool, self.image_cls_pool = BertPooler(), BertPooler()
+        self.fc_sim_tranloc, self.fc_sim_tranglo = Linear(E, E), Linear(E, E)
+        self.fc_1, self.fc_2 = Linear(E, E), Linear(E, E)
+
+    def forward(self, own, other):
+        c = self.CrossModalAlignment(own, other)
+        sl = self.fc_1(F.l2norm(self.fc_sim_tranloc(F.sqdiff(own, c))))  # [B,Lq,768]
+        dg = F.sqdiff(self.text_cls_pool(own), self.image_cls_pool(other))
+        sg = self.fc_2(F.l2norm(self.fc_sim_tranglo(dg)))  # [B,768]
+        S = torch.cat([sg.unsqueeze(1), sl], dim=1)  # memory plumbing only
+        return self.SAF_module(S)  # [B,768], broadcast over Lq by the aggregate kernel
+
+
+class GlobalEnhancedSemanticCell(D2RModule):
+    def __init__(self, args, num_out_path):
+        super().__init__()
+        self.router = Router(num_out_path, args.embed_size, args.hid_router)
+        self.text_cls_pool, self.image_cls_pool = BertPooler(), BertPooler()
+        self.fc_mlp = _Sequential(**{"0": Linear(E, E), "2": Linear(E, E)})
+
+    def forward(self, own, other):
+        a, b = self.text_cls_pool(own), self.image_cls_pool(other)
+        z = self.fc_mlp[2](self.fc_mlp[0](F.add(a, b), act=ACT_TANH))
+        return F.lerp_gate(F.softmax_rows(z), a, b)  # [B,768]
+
+
+class ContextRichCrossModalCell(D2RModule):
+    def __init__(self, args, num_out_path):
+        super().__init__()
+        self.router = Router(num_out_path, args.embed_size, args.hid_router)
+        self.CrossModalAlignment = CrossModalAlignment()
+        self.fc_mlp_1 = _Sequential(**{"0": Linear(E, E)})
+        self.fc_mlp_2 = _Sequential(**{"0": Linear(E, E)})
+        self.fc_1, self.fc_2 = Linear(E, E), Linear(E, E)
+
+    def forward(self, own, other):
+        c = self.CrossModalAlignment(own, other)
+        Qs = self.fc_mlp_1[0](c, act=ACT_TANH)
+        Ks = self.fc_mlp_2[0](own, act=ACT_TANH)
+        return F.attention(self.fc_1(Qs), self.fc_2(Ks), Ks, 1, 1.0, residual=Qs)  # unscaled softmax(QK^T)
+
+
+# ------------------------------------------------------------------------------------------------------
+# routing layers
+# ------------------------------------------------------------------------------------------------------
+class _RoutingLayer(D2RModule):
+    """One DynamicInteraction layer; ``swap`` selects the reversed (image-branch) variant."""
+
+    first_layer = False
+    swap = False
+
+    def __init__(self, args, num_cell, num_out_path):
+        super().__init__()
+        assert num_cell == 6, "the reference hard-indexes six cells (models/DynamicInteraction.py:39-48)"
+        self.num_cell, self.num_out_path = num_cell, num_out_path
+        self.threshold, self.eps = 1e-4, 1e-8
+        self.ric = RectifiedIdentityCell(args, num_out_path)
+        self.imrc = IntraModelReasoningCell(args, num_out_path)
+        self.glac = GlobalLocalAlignmentCell(args, num_out_path)
+        self.cmrc = CrossModalRefinementCell(args, num_out_path)
+        self.crcmc = ContextRichCrossModalCell(args, num_out_path)
+        self.gesc = GlobalEnhancedSemanticCell(args, num_out_path)
+
+    def _cells(self):
+        return [getattr(self, n) for n in CELL_ORDER]
+
+    def _route(self, refs: List[torch.Tensor], other: torch.Tensor):
+        cells = self._cells()
+        if self.first_layer:  # six routers read the same tensor: pool once
+            pooled = F.mean_pool([refs[0]])[0]
+            gates = [c.router.gate_from_pooled(pooled) for c in cells]
+        else:
+            pooled = F.mean_pool(refs)  # [6,B,768] in one launch
+            gates = [c.router.gate_from_pooled(pooled[j]) for j, c in enumerate(cells)]
+        G = torch.stack(gates, dim=0)  # fp32 [6,B,P]
+        embs = [c(refs[j], other) for j, c in enumerate(cells)]
+        if self.num_out_path == 1:
+            probs, outs = F.route_aggregate(G, *embs, refs=refs[1:])
+        else:
+            probs, outs = F.route_aggregate(G, *embs)
+        return outs, probs
+
+
+class DynamicInteraction_Layer0(_RoutingLayer):
+    first_layer = True
+
+    def forward(self, text, image):
+        own, other = (image, text) if self.swap else (text, image)
+        return self._route([own] * 6, other)
+
+
+class DynamicInteraction_Layer(_RoutingLayer):
+    def forward(self, ref_wrd, text, image):
+        return self._route(list(ref_wrd), text if self.swap else image)
+
+
+class Reversed_DynamicInteraction_Layer0(DynamicInteraction_Layer0):
+    swap = True
+
+
+class Reversed_DynamicInteraction_Layer(DynamicInteraction_Layer):
+    swap = True
+
+
+class _InteractionBase(D2RModule):
+    layer0_cls = DynamicInteraction_Layer0
+    layer_cls = DynamicInteraction_Layer
+
+    def __init__(self, args, num_layer_routing=3, num_cells=4, path_hid=128):
+        super().__init__()
+        if num_layer_routing < 2:
+            raise ValueError("DR_step must be >= 2")
+        self.num_cells = num_cells
+        self.dynamic_itr_l0 = self.layer0_cls(args, num_cells, num_cells)
+        self.dynamic_itr_l1 = nn.ModuleList(
+            [self.layer_cls(args, num_cells, num_cells) for _ in range(num_layer_routing - 2)])
+        self.dynamic_itr_l2 = self.layer_cls(args, num_cells, 1)
+        total_paths = num_cells ** 2 * (num_layer_routing - 1) + num_cells
+        self.path_mapping = Linear(total_paths, path_hid)  # dead parameter (models/InteractionModule.py:19)
+        self.bn = nn.BatchNorm1d(args.embed_size)  # dead module (:20)
+
+    def forward(self, text, image):
+        B = text.shape[0]
+        refs, p0 = self.dynamic_itr_l0(text, image)
+        plist = [p0.reshape(B, -1)]
+        for layer in self.dynamic_itr_l1:
+            refs, pm = layer(refs, text, image)
+            plist.append(pm.reshape(B, -1))
+        out, pf = self.dynamic_itr_l2(refs, text, image)
+        plist.append(pf.reshape(B, -1))
+        paths = torch.cat(plist, dim=-1)  # fp32 [B, 36(DR-1)+6]; DR_step=2 (extension): cat(l0, l2)
+        return out, F.matmul_nt(paths, paths)
+
+
+class InteractionModule(_InteractionBase):
+    pass
+
+
+class Reversed_InteractionModule(_InteractionBase):
+    layer0_cls = Reversed_DynamicInteraction_Layer0
+    layer_cls = Reversed_DynamicInteraction_Layer
+
+
+# ------------------------------------------------------------------------------------------------------
+# encoders
+# ------------------------------------------------------------------------------------------------------
+def _check_dropout(p: float, training: bool, what: str):
+    if training and p > 0.0:
+        raise NotImplementedError(
+            f"{what}={p}: dropout is not implemented in the HIP path yet; build the config with dropout 0 "
+            "(BASELINE.md section 3) or call model.eval()")
+
+
+class BertSelfAttention(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        self.num_attention_heads = config.num_attention_heads
+        self.query, self.key, self.value = (Linear(config.hidden_size, config.hidden_size) for _ in range(3))
+        self.p_drop = config.attention_probs_dropout_prob
+
+
+class BertSelfOutput(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class BertAttention(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+
+class BertIntermediate(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.intermediate_size)
+        self.fusion_dense = Linear(config.hidden_size, config.intermediate_size)  # dead (modeling_unimo.py:447)
+
+
+class BertOutput(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class BertLayer(D2RModule):
+    """Post-LN BERT layer (models/modeling_unimo.py:473-512)."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_act != "gelu":
+            raise NotImplementedError(f"BERT hidden_act={config.hidden_act!r} (only 'gelu' is implemented)")
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+        self.p_hidden = config.hidden_dropout_prob
+
+    def forward(self, x, key_mask=None):
+        sa = self.attention.self
+        _check_dropout(sa.p_drop, self.training, "attention_probs_dropout_prob")
+        _check_dropout(self.p_hidden, self.training, "hidden_dropout_prob")
+        H = sa.num_attention_heads
+        ctx = F.attention(sa.query(x), sa.key(x), sa.value(x), H, 1.0 / math.sqrt(x.shape[-1] // H), mask=key_mask)
+        a = self.attention.output.LayerNorm(self.attention.output.dense(ctx, residual=x))
+        h = self.intermediate.dense(a, act=ACT_GELU)
+        return self.output.LayerNorm(self.output.dense(h, residual=a))
+
+
+class CLIPAttention(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        self.num_heads = config.num_attention_heads
+        d = config.hidden_size
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = Linear(d, d), Linear(d, d), Linear(d, d), Linear(d, d)
+        self.p_drop = config.attention_dropout
+
+
+class CLIPMLP(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_act != "quick_gelu":
+            raise NotImplementedError(f"CLIP hidden_act={config.hidden_act!r} (only 'quick_gelu' is implemented)")
+        self.fc1 = Linear(config.hidden_size, config.intermediate_size)
+        self.fc2 = Linear(config.intermediate_size, config.hidden_size)
+
+
+class CLIPEncoderLayer(D2RModule):
+    """Pre-LN ViT layer with quick_gelu (models/modeling_unimo.py:222-268)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.self_attn = CLIPAttention(config)
+        self.layer_norm1 = LayerNorm(config.hidden_size, eps=1e-5)  # the reference builds nn.LayerNorm(dim): eps 1e-5
+        self.mlp = CLIPMLP(config)
+        self.layer_norm2 = LayerNorm(config.hidden_size, eps=1e-5)
+
+    def forward(self, x):
+        at = self.self_attn
+        _check_dropout(at.p_drop, self.training, "attention_dropout")
+        h = self.layer_norm1(x)
+        d = x.shape[-1] // at.num_heads
+        ctx = F.attention(at.q_proj(h), at.k_proj(h), at.v_proj(h), at.num_heads, d ** -0.5)
+        x = at.out_proj(ctx, residual=x)
+        h = self.mlp.fc1(self.layer_norm2(x), act=ACT_QUICK_GELU)
+        return self.mlp.fc2(h, residual=x)
+
+
+class _PatchEmbedding(nn.Module):
+    def __init__(self, embed_dim, patch):
+        super().__init__()
+        bound = 1.0 / math.sqrt(3 * patch * patch)
+        self.weight = nn.Parameter(torch.empty(embed_dim, 3, patch, patch).uniform_(-bound, bound))
+
+
+class _Embedding(nn.Module):
+    def __init__(self, n, dim, padding_idx=None):
+        super().__init__()
+        w = torch.randn(n, dim)
+        if padding_idx is not None:
+            w[padding_idx].zero_()
+        self.weight = nn.Parameter(w)
+
+
+class CLIPVisionEmbeddings(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        self.embed_dim, self.image_size, self.patch_size = config.hidden_size, config.image_size, config.patch_size
+        self.class_embedding = nn.Parameter(torch.randn(self.embed_dim))
+        self.patch_embedding = _PatchEmbedding(self.embed_dim, self.patch_size)
+        self.num_patches = (self.image_size // self.patch_size) ** 2
+        self.num_positions = self.num_patches + 1
+        self.position_embedding = _Embedding(self.num_positions, self.embed_dim)
+        self.register_buffer("position_ids", torch.arange(self.num_positions).expand((1, -1)))
+
+    def forward(self, pixel_values):
+        w = self.patch_embedding.weight
+        return F.clip_embed(pixel_values, w, _compute_weight(w, self.cdtype), self.class_embedding,
+                            self.position_embedding.weight, self.patch_size)
+
+
+class BertEmbeddings(D2RModule):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = _Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        self.position_embeddings = _Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = _Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.p_drop = config.hidden_dropout_prob
+        if getattr(config, "position_embedding_type", "absolute") != "absolute":
+            raise NotImplementedError("only absolute position embeddings")
+        if config.pad_token_id != 0:
+            raise NotImplementedError("pad_token_id must be 0")
+        self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
+
+    def forward(self, input_ids, token_type_ids):
+        _check_dropout(self.p_drop, self.training, "hidden_dropout_prob")
+        x = F.bert_embed(input_ids, token_type_ids, self.word_embeddings.weight, self.position_embeddings.weight,
+                         self.token_type_embeddings.weight, self.cdtype)
+        return self.LayerNorm(x)
+
+
+class UnimoEncoder(D2RModule):
+    def __init__(self, vision_config, text_config):
+        super().__init__()
+        assert vision_config.num_hidden_layers == text_config.num_hidden_layers  # models/modeling_unimo.py:670
+        self.vision_layers = nn.ModuleList([CLIPEncoderLayer(vision_config) for _ in range(vision_config.num_hidden_layers)])
+        self.text_layer = nn.ModuleList([BertLayer(text_config) for _ in range(text_config.num_hidden_layers)])
+
+    def forward(self, vision_embeds, text_embeds, key_mask):
+        v, t = vision_embeds, text_embeds
+        for layer in self.vision_layers:
+            v = layer(v)
+        for layer in self.text_layer:
+            t = layer(t, key_mask)
+        return t, v
+
+
+class Block(D2RModule):
+    """Bilinear Block fusion (models/XModules.py:478-555), pos_norm='before_cat', no dropout."""
+
+    def __init__(self, input_dims, output_dim, mm_dim=1600, chunks=20, rank=15):
+        super().__init__()
+        self.mm_dim, self.chunks, self.rank = mm_dim, chunks, rank
+        assert mm_dim % chunks == 0, "uneven chunking is not used by the model"
+        self.size = mm_dim // chunks
+        self.linear0, self.linear1 = Linear(input_dims[0], mm_dim), Linear(input_dims[1], mm_dim)
+        self.merge_linears0 = nn.ModuleList([Linear(self.size, self.size * rank) for _ in range(chunks)])
+        self.merge_linears1 = nn.ModuleList([Linear(self.size, self.size * rank) for _ in range(chunks)])
+        self.linear_out = Linear(mm_dim, output_dim)
+
+    def forward(self, x):
+        x0, x1 = self.linear0(x[0]), self.linear1(x[1])
+        s = self.size
+        m0 = torch.stack([self.merge_linears0[c](x0[:, c * s:(c + 1) * s]) for c in range(self.chunks)], dim=1)
+        m1 = torch.stack([self.merge_linears1[c](x1[:, c * s:(c + 1) * s]) for c in range(self.chunks)], dim=1)
+        return self.linear_out(F.block_merge(m0, m1, self.chunks, self.rank, s))
+
+
+class UnimoModel(D2RModule):
+    def __init__(self, args, vision_config, text_config, add_pooling_layer=True, num_self_layer=1):
+        super().__init__()
+        self.args, self.vision_config, self.text_config = args, vision_config, text_config
+        if vision_config.hidden_size != E or text_config.hidden_size != E:
+            raise ValueError("the routing cells are hard-wired to hidden size 768")
+        self.vision_embeddings = CLIPVisionEmbeddings(vision_config)
+        self.vision_pre_layrnorm = LayerNorm(E, eps=1e-5)
+        self.vision_post_layernorm = LayerNorm(E, eps=1e-5)  # dead
+        self.text_embeddings = BertEmbeddings(text_config)
+        self.encoder = UnimoEncoder(vision_config, text_config)
+        self.self_text = nn.ModuleList([BertLayer(text_config) for _ in range(num_self_layer)])
+        self.text_cls_pool = BertPooler()
+        self.self_vision = nn.ModuleList([CLIPEncoderLayer(vision_config) for _ in range(num_self_layer)])
+        self.vision_cls_pool = BertPooler()
+        self.block_fusion = Block([E, E], E)
+        self.text_pool, self.vision_pool = BertPooler(), BertPooler()
+        self.itr_module = InteractionModule(args, num_layer_routing=args.DR_step, num_cells=6, path_hid=128)
+        self.Reversed_itr_module = Reversed_InteractionModule(args, num_layer_routing=args.DR_step, num_cells=6,
+                                                              path_hid=128)
+        self.text_pooler = BertPooler() if add_pooling_layer else None  # dead (ingest assert needs it)
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, pixel_values=None):
+        """-> (pooler_output [B,768], js_loss, aux) — models/modeling_unimo.py:786-894."""
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if token_type_ids is None:
+            raise ValueError("token_type_ids is None!")  # models/modeling_unimo.py:808-809
+        # additive key mask (1-m)*-10000 (:58-59): tiny integer->float plumbing on [B,L]
+        key_mask = ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
+        v = self.vision_pre_layrnorm(self.vision_embeddings(pixel_values))
+        t = self.text_embeddings(input_ids, token_type_ids)
+        t_enc, v_enc = self.encoder(v, t, key_mask)
+        t_out = t_enc
+        for layer in self.self_text:
+            t_out = layer(t_out, key_mask)
+        t_cls = self.text_cls_pool(t_out)
+        v_out = v_enc
+        for layer in self.self_vision:
+            v_out = layer(v_out)
+        v_cls = self.vision_cls_pool(v_out)
+        (emb_t,), sim_paths = self.itr_module(t_enc, v_enc)
+        (emb_v,), rev_sim_paths = self.Reversed_itr_module(t_enc, v_enc)
+        js1 = F.js_div(sim_paths, F.matmul_nt(t_cls, t_cls))
+        js2 = F.js_div(rev_sim_paths, F.matmul_nt(v_cls, v_cls))
+        js_loss = F.lincomb([-self.args.weight_js_1, -self.args.weight_js_2], [js1, js2])
+        pooled = self.block_fusion([self.text_pool(emb_t), self.vision_pool(emb_v)])
+        aux = dict(emb_text=emb_t, emb_image=emb_v, sim_paths=sim_paths, rev_sim_paths=rev_sim_paths,
+                   text_encode_out=t_enc, vision_encode_out=v_enc)
+        return pooled, js_loss, aux
+
+
+class UnimoModelF(D2RModule):
+    """Drop-in surface: forward(input_ids, attention_mask, token_type_ids, labels, images) -> (loss, logits)."""
+
+    def __init__(self, args, vision_config, text_config, num_classes: int = 3):
+        super().__init__()
+        self.args, self.vision_config, self.text_config = args, vision_config, text_config
+        self.model = UnimoModel(args, vision_config, text_config)
+        self.fc = Linear(text_config.hidden_size, num_classes)
+        self.last_aux = None
+
+    def forward(self, input_ids, attention_mask, token_type_ids, labels, images):
+        pooled, js_loss, aux = self.model(input_ids=input_ids, attention_mask=attention_mask,
+                                          token_type_ids=token_type_ids, pixel_values=images)
+        logits = self.fc(pooled, out_dtype=torch.float32)
+        loss = F.lincomb([1.0, 1.0], [F.cross_entropy(logits, labels), js_loss])
+        aux["js_loss"] = js_loss
+        self.last_aux = aux
+        return loss, logits

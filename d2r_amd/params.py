@@ -1,0 +1,169 @@
+"""Flat parameter / gradient storage, the fused AdamW optimiser and the linear warm-up schedule.
+
+Memory layout in HBM (one allocation each, 288 GB/GPU makes this trivially affordable):
+    flat_w  fp32 [n_live]   master weights, every live parameter is a view into it
+    flat_g  fp32 [n_live]   gradients (``p.grad`` are views; zeroed once per step by one memset; the dW GEMMs
+                            accumulate straight into it — see functional._Linear.backward)
+    flat_m, flat_v fp32     AdamW moments
+    flat_lp bf16 [n_live]   bf16 shadow of the weights (bf16 compute only), rewritten by the AdamW kernel
+Live parameters are ordered by the reference's four optimiser groups (modules/train.py:287-322) so each group is
+one contiguous range = one kernel launch per group.  The 52.6 M parameters that never receive a gradient in the
+reference stay outside the store and are never updated nor all-reduced (AdamW skips ``grad is None`` there too).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .functional import _stream
+
+ALIGN = 8  # elements: 32 B for fp32, 16 B for the bf16 shadow
+
+
+def is_dead_param(name: str) -> bool:
+    """Parameters that are never used by the reference's forward."""
+    if "fusion_dense" in name or "vision_post_layernorm" in name or ".text_pooler." in name:
+        return True
+    if ".path_mapping." in name or name.endswith("itr_module.bn.weight") or name.endswith("itr_module.bn.bias"):
+        return True
+    return "CrossModalAlignment.fc_1" in name or "CrossModalAlignment.fc_2" in name
+
+
+def group_of(name: str) -> int:
+    """0 other, 1 text (bert lr), 2 vision (vit lr), 3 fc head — modules/train.py:287-322."""
+    if name.startswith("fc"):
+        return 3
+    if "text" in name:
+        return 1
+    if "vision" in name:
+        return 2
+    return 0
+
+
+class ParamStore:
+    def __init__(self, model: torch.nn.Module, compute_dtype: torch.dtype = torch.float32):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError("model has no trainable parameters")
+        device = named[0][1].device
+        if device.type != "cuda":
+            raise _lib.D2RError("ParamStore needs the model on the GPU (model.to('cuda') first)")
+        self.compute_dtype = compute_dtype
+        self.device = device
+        self.dead = [(n, p) for n, p in named if is_dead_param(n)]
+        live = sorted([(n, p) for n, p in named if not is_dead_param(n)], key=lambda np_: group_of(np_[0]))
+        for n, p in live:
+            if group_of(n) in (1, 2) and "text" in n and "vision" in n:
+                raise ValueError(f"parameter {n!r} would fall into two optimiser groups")
+        self.entries = []  # (name, param, offset, numel, group)
+        off = 0
+        self.group_ranges: Dict[int, List[int]] = {}
+        for n, p in live:
+            g = group_of(n)
+            if g not in self.group_ranges:
+                self.group_ranges[g] = [off, off]
+            self.entries.append((n, p, off, p.numel(), g))
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.group_ranges[g][1] = off
+        self.n = off
+        self.flat_w = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_lp = torch.zeros(off, dtype=torch.bfloat16, device=device) if compute_dtype == torch.bfloat16 else None
+        with torch.no_grad():
+            for n, p, o, k, g in self.entries:
+                w = self.flat_w[o:o + k].view(p.shape)
+                w.copy_(p.data)
+                p.data = w
+                gv = self.flat_g[o:o + k].view(p.shape)
+                p.grad = gv
+                p._d2r_grad = gv
+                p._d2r_lp = None if self.flat_lp is None else self.flat_lp[o:o + k].view(p.shape)
+        for n, p in self.dead:
+            p.requires_grad_(False)
+        self.refresh_lowp()
+
+    # -- bf16 shadow -------------------------------------------------------------------------------
+    def refresh_lowp(self):
+        """Re-derives the bf16 shadow from the fp32 masters (after load_state_dict / broadcast)."""
+        if self.flat_lp is not None:
+            _lib.call("d2r_cast", _lib.F32, self.flat_w.data_ptr(), _lib.BF16, self.flat_lp.data_ptr(), self.n, _stream())
+
+    def zero_grad(self):
+        self.flat_g.zero_()  # one memset node
+
+    def live_numel(self) -> int:
+        return sum(k for _, _, _, k, _ in self.entries)
+
+
+class FusedAdamW:
+    """torch.optim.AdamW semantics (betas 0.9/0.999, eps 1e-8, decoupled weight decay) as one HIP launch per
+    parameter group over the flat buffers (K14)."""
+
+    def __init__(self, store: ParamStore, lr: float, fc_lr: float = 5e-2, weight_decay: float = 1e-2,
+                 betas=(0.9, 0.999), eps: float = 1e-8):
+        self.store = store
+        self.betas, self.eps = betas, eps
+        self.m = torch.zeros_like(store.flat_w)
+        self.v = torch.zeros_like(store.flat_w)
+        self.step_count = 0
+        self.grad_scale = 1.0  # 1/world_size under data parallelism (gradients are SUM-reduced)
+        names = {0: "other", 1: "text", 2: "vision", 3: "fc"}
+        self.param_groups = []
+        for g, (a, b) in sorted(store.group_ranges.items()):
+            base = fc_lr if g == 3 else lr
+            self.param_groups.append(dict(name=names[g], range=(a, b), lr=base, initial_lr=base,
+                                          weight_decay=weight_decay))
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.store.zero_grad()
+
+    def step(self):
+        self.step_count += 1
+        st = self.store
+        for pg in self.param_groups:
+            a, b = pg["range"]
+            if b <= a:
+                continue
+            lp = None if st.flat_lp is None else st.flat_lp.data_ptr() + 2 * a
+            _lib.call("d2r_adamw_step", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
+                      self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, b - a, pg["lr"], self.betas[0],
+                      self.betas[1], self.eps, pg["weight_decay"], self.step_count, self.grad_scale, _stream())
+
+    def state_dict(self):
+        return dict(m=self.m, v=self.v, step=self.step_count, lrs=[pg["lr"] for pg in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"])
+        for pg, lr in zip(self.param_groups, sd["lrs"]):
+            pg["lr"] = lr
+
+
+class LinearWarmupSchedule:
+    """``transformers.get_linear_schedule_with_warmup`` (modules/train.py:326-328), including the reference's float
+    ``num_warmup_steps = warmup_ratio * steps`` and LambdaLR's "lr(0) at construction, then step()" ordering."""
+
+    def __init__(self, optimizer: FusedAdamW, num_warmup_steps: float, num_training_steps: int):
+        self.opt, self.warm, self.total = optimizer, num_warmup_steps, num_training_steps
+        self.last_epoch = 0
+        self._apply()
+
+    def factor(self, step: int) -> float:
+        if step < self.warm:
+            return float(step) / float(max(1, self.warm))
+        return max(0.0, float(self.total - step) / float(max(1, self.total - self.warm)))
+
+    def _apply(self):
+        f = self.factor(self.last_epoch)
+        for pg in self.opt.param_groups:
+            pg["lr"] = pg["initial_lr"] * f
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [pg["lr"] for pg in self.opt.param_groups]

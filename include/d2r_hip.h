@@ -1,0 +1,248 @@
+/*
+ * d2r_hip.h — C ABI of libd2r_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the D2R
+ * dual-branch dynamic-routing forward/backward hot path.
+ *
+ * The reference (SorF520/D2R) has NO plugin / operator / FFI layer: its boundary is two Python classes
+ * (`UnimoModelF.forward`, models/unimo_model.py:149-162; `MSDTrainer`, modules/train.py:53-328) and every
+ * op is an ATen call.  This header is therefore the seam a maintainer of the reference would bind with
+ * `ctypes`: each entry point replaces one ATen op *sequence* of the reference, cited
+ * per function as reference file:line.
+ *
+ * Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless named `h_*`;
+ *   - kernels are enqueued on the caller's `stream` (a hipStream_t passed as void*); the library never
+ *     allocates, frees, synchronises or takes ownership — workspaces are caller-provided;
+ *   - return 0 on success, a negative d2r_status on error; d2r_last_error() gives a thread-local message;
+ *   - dtype of activations/weights `T` is D2R_F32 or D2R_BF16; accumulation, softmax statistics, router
+ *     logits, biases, LayerNorm parameters and all reductions are fp32;
+ *   - deterministic: fixed reduction order, no float atomics except the embedding-table scatter-add.
+ */
+#ifndef D2R_HIP_H
+#define D2R_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { D2R_F32 = 0, D2R_BF16 = 1 } d2r_dtype;
+
+typedef enum {
+  D2R_OK = 0,
+  D2R_ERR_INVALID = -1,     /* bad argument (shape, alignment, null pointer, unsupported combination) */
+  D2R_ERR_LAUNCH = -2,      /* hipGetLastError() after launch */
+  D2R_ERR_WORKSPACE = -3    /* caller-provided workspace too small */
+} d2r_status;
+
+typedef enum {
+  D2R_ACT_NONE = 0,
+  D2R_ACT_RELU = 1,
+  D2R_ACT_TANH = 2,
+  D2R_ACT_GELU = 3,        /* erf GELU  (BertIntermediate, models/modeling_unimo.py:443-456) */
+  D2R_ACT_QUICK_GELU = 4,  /* x*sigmoid(1.702x) (CLIPMLP, models/modeling_unimo.py:121-133) */
+  D2R_ACT_TANH_RELU = 5,   /* relu(tanh(x)) = Router activateFunc (models/Router.py:6-8) */
+  D2R_ACT_SIGMOID = 6
+} d2r_act;
+
+/* A-operand / B-operand storage of d2r_gemm: C[M,N] = sum_k A(m,k) * B(k,n) */
+typedef enum {
+  D2R_GEMM_NT = 0,  /* A stored [M,K] (k contiguous), B stored [N,K] (k contiguous): y = x W^T (nn.Linear fwd) */
+  D2R_GEMM_NN = 1,  /* A stored [M,K], B stored [K,N] (n contiguous): dX = dY W ; O = P V             */
+  D2R_GEMM_TN = 2   /* A stored [K,M] (m contiguous), B stored [K,N]: dW = dY^T X ; dV = P^T dO        */
+} d2r_gemm_layout;
+
+const char* d2r_version(void);
+const char* d2r_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K11  gemm_bias_act — every nn.Linear of the path, and the attention matmuls, as one MFMA kernel family.
+ * Replaces: F.linear (+ReLU/tanh/GELU/quick_gelu, + residual add) e.g. models/SelfAttention.py:29-31,52-53,
+ * models/Refinement.py:105-107,133-137, models/XModules.py:300-302, models/Cells.py:145-160,236-246,
+ * models/modeling_unimo.py:173-176,217,353-355,411,451,466; torch.bmm/matmul at models/XModules.py:305,310,
+ * models/SelfAttention.py:33,39, models/Cells.py:244-246; and their autograd backward (NN / TN layouts).
+ *
+ *   C[b,h] = epilogue( alpha * A[b,h] x B[b,h] )      batch index z = b*nh + h, pointer offset b*s?b + h*s?h
+ *   epilogue(v) = act(v + bias[n]) + residual[m,n]     (then  C = v + beta*C_old  when beta != 0)
+ * `preact` (optional) receives v + bias before the activation (needed by GELU backward).
+ * All leading dimensions / strides are in ELEMENTS.  A and B have dtype `dtype`; C/residual/preact have
+ * `c_dtype`.  bias is fp32 [N] or NULL.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int dtype;      /* d2r_dtype of A and B */
+  int c_dtype;    /* d2r_dtype of C, residual, preact */
+  int layout;     /* d2r_gemm_layout */
+  int act;        /* d2r_act */
+  int M, N, K;
+  int nb, nh;     /* batch = nb*nh (use 1,1 for a plain GEMM) */
+  float alpha, beta;
+  const void* A; int64_t lda, sAb, sAh;
+  const void* B; int64_t ldb, sBb, sBh;
+  void* C;       int64_t ldc, sCb, sCh;
+  const float* bias;
+  const void* residual; int64_t ldr, sRb, sRh;
+  void* preact;  /* same ld/strides as C */
+  /* optional scratch for deterministic split-K (GEMMs with few output tiles and a long reduction: weight
+   * gradients, M<=32 router/pooler products); used only when batch == 1.  NULL disables split-K. */
+  void* workspace; size_t workspace_bytes;
+} d2r_gemm_desc;
+
+int d2r_gemm(const d2r_gemm_desc* d, void* stream);
+/* tuning switches for A/B measurements (tests/bench_gemm.py): LDS buffers (1|2), vectorised bf16 epilogue (0|1),
+ * forced tile (-1 auto, 1: 64x64, 2: 128x64, 3: 128x128).  Defaults are the measured winners. */
+void d2r_gemm_tuning(int nbuf, int vepi, int tile);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row kernels (fp32 statistics, wave-shuffle reductions)
+ * ------------------------------------------------------------------------------------------------ */
+/* softmax over the last dim of X[rows, cols] (row stride ld): Y = softmax(scale*X + mask[row / rows_per_mask]).
+ * Replaces torch.softmax at models/XModules.py:309 (scale 100/sqrt(768)), models/SelfAttention.py:36,
+ * models/Cells.py:245,204 and models/modeling_unimo.py:194,376-385 (additive -10000 key mask, fp32 [*,cols]). */
+int d2r_softmax_fwd(int x_dtype, int y_dtype, const void* X, void* Y, int64_t ld, int64_t rows, int cols,
+                    float scale, const float* mask, int64_t rows_per_mask, void* stream);
+/* dS = scale * P o (dP - rowsum(dP o P)); dS has P's dtype, dP may be fp32 */
+int d2r_softmax_bwd(int p_dtype, int dp_dtype, const void* P, const void* dP, void* dS, int64_t ld, int64_t rows,
+                    int cols, float scale, void* stream);
+
+/* LayerNorm over D (models/modeling_unimo.py:231,250,283,408,463,742). mean/rstd: fp32 [rows]. */
+int d2r_layernorm_fwd(int dtype, const void* X, const float* gamma, const float* beta, float eps, int64_t rows,
+                      int D, void* Y, float* mean, float* rstd, void* stream);
+size_t d2r_layernorm_bwd_workspace(int64_t rows, int D);
+/* dX always; dgamma/dbeta (fp32 [D]) are OVERWRITTEN. workspace: d2r_layernorm_bwd_workspace bytes. */
+int d2r_layernorm_bwd(int dtype, const void* dY, const void* X, const float* gamma, const float* mean,
+                      const float* rstd, int64_t rows, int D, void* dX, float* dgamma, float* dbeta,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* l2norm rows: y = x / (sqrt(sum x^2) + 1e-8)  (eps OUTSIDE the root; models/Cells.py:23-27).  norm: fp32 [rows] */
+int d2r_l2norm_fwd(int dtype, const void* X, void* Y, float* norm, int64_t rows, int D, void* stream);
+int d2r_l2norm_bwd(int dtype, const void* dY, const void* X, const float* norm, void* dX, int64_t rows, int D,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise kernels (16-byte vectorised)
+ * ------------------------------------------------------------------------------------------------ */
+/* dX = dY * act'(.)  — `ref` is the activation OUTPUT for relu/tanh/tanh_relu/sigmoid and the PRE-activation
+ * for gelu/quick_gelu. */
+int d2r_act_bwd(int dtype, int act, const void* dY, const void* ref, void* dX, int64_t n, void* stream);
+int d2r_act_fwd(int dtype, int act, const void* X, void* Y, int64_t n, void* stream);
+/* out = (a - b)^2 ; da = 2(a-b)dout, db = -da   (models/Cells.py:147,156) */
+int d2r_sqdiff_fwd(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
+int d2r_sqdiff_bwd(int dtype, const void* a, const void* b, const void* dout, void* da, void* db, int64_t n,
+                   void* stream);
+/* out = a*s + h  (FiLM modulation, models/Refinement.py:136) ; backward gives da, ds (dh = dout) */
+int d2r_muladd_fwd(int dtype, const void* a, const void* s, const void* h, void* out, int64_t n, void* stream);
+int d2r_muladd_bwd(int dtype, const void* a, const void* s, const void* dout, void* da, void* ds, int64_t n,
+                   void* stream);
+/* out = g*a + (1-g)*b (GESC gate, models/Cells.py:205) ; backward gives dg, da, db */
+int d2r_lerp_fwd(int dtype, const void* g, const void* a, const void* b, void* out, int64_t n, void* stream);
+int d2r_lerp_bwd(int dtype, const void* g, const void* a, const void* b, const void* dout, void* dg, void* da,
+                 void* db, int64_t n, void* stream);
+int d2r_add(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
+/* out[0] = sum_k h_coef[k] * x_k[0]  (n <= 8 fp32 device scalars): loss = CE - w1*JS1 - w2*JS2 */
+int d2r_lincomb(const float* const* h_x, const float* h_coef, int n, float* out, void* stream);
+/* y = alpha*x + beta*y (dtype T), used for gradient accumulation ; cast between dtypes */
+int d2r_axpby(int dtype, float alpha, const void* x, float beta, void* y, int64_t n, void* stream);
+int d2r_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+/* column sums: out[n] (fp32, OVERWRITTEN) = sum_m X[m, n]   (bias gradients). workspace via query. */
+size_t d2r_colsum_workspace(int64_t M, int N);
+int d2r_colsum(int dtype, const void* X, int64_t ld, int64_t M, int N, float* out, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  router pooling  (models/Router.py:23: x.mean(-2));  pooled: fp32 [B, D]
+ * nsrc sources pooled in ONE launch (layer >= 1 pools the six aggregated tensors at once).
+ * ------------------------------------------------------------------------------------------------ */
+int d2r_meanpool_fwd(int dtype, const void* const* h_srcs, int nsrc, int B, int L, int D, float* pooled /*[nsrc,B,D]*/,
+                     void* stream);
+/* dX[b,l,:] (+)= dpooled[b,:]/L ; accumulate!=0 adds into dX */
+int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, int D, void* dX, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8  route_aggregate — path normalisation, threshold gate and aggregation of the six cell outputs.
+ * Replaces models/DynamicInteraction.py:50-67 (=:119-132, :170-187, :239-252) and the final-layer rule
+ * :104-117 (=:224-237).  Cell order [RIC, GLAC, IMRC, CMRC, CRCMC, GESC] (:41-48).
+ *   embs[j]  : cell outputs; j=1 (GLAC) and j=5 (GESC) are per-sample [B,D] broadcasts, the rest [B,L,D];
+ *              embs[0] is the RIC *input* x0 — relu (models/Cells.py:38) is applied in-kernel.
+ *   gates    : fp32 [6, B, P] raw router outputs g_j (P = 6, or 1 for the final layer)
+ *   refs     : (final layer only) the six layer inputs ref_j [B,L,D] used by the skip term
+ *   outs[i]  : P output tensors [B,L,D];  probs: fp32 [B, P, 6] (normalised for P=6, raw for P=1)
+ * ------------------------------------------------------------------------------------------------ */
+int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs /*6*/, const void* const* h_refs /*6 or NULL*/,
+                            const float* gates, int B, int L, int D, int P, void* const* h_outs /*P*/,
+                            float* probs, void* stream);
+size_t d2r_route_aggregate_bwd_workspace(int B, int L, int D, int P);
+/* d_embs[j] are OVERWRITTEN (d_embs[0] is w.r.t. the RIC input x0, relu' applied; broadcast ones are [B,D]);
+ * d_refs[j] (final layer: gradient of the skip term) OVERWRITTEN, d_gates fp32 [6,B,P] OVERWRITTEN.
+ * d_probs: fp32 [B,P,6] gradient flowing into the returned `probs` (sim_paths -> JS loss) or NULL;
+ * h_outs: forward outputs (only outs[0] of the final layer is read; may be NULL for P=6). */
+int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, const void* const* h_refs, const float* gates,
+                            const void* const* h_douts /*P*/, const void* const* h_outs, const float* d_probs,
+                            int B, int L, int D, int P, void* const* h_dembs /*6*/,
+                            void* const* h_drefs /*6 or NULL*/, float* d_gates, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6  SAF gate — BatchNorm1d(1) + sigmoid + l1norm over the Lq+1 alignment scores of every sample
+ * (models/XModules.py:380-381).  a: fp32 [B, n] pre-BN scores.  train!=0: batch statistics over all B*n
+ * scalars and running-stat update (momentum 0.1, unbiased running var); else running stats.
+ * stats (fp32[4]) receives {mean, biased var, rstd, sum-of-sigmoid...}; w: fp32 [B, n] attention weights.
+ * ------------------------------------------------------------------------------------------------ */
+int d2r_saf_gate_fwd(const float* a, int B, int n, const float* bn_weight, const float* bn_bias,
+                     float* running_mean, float* running_var, int train, float* w, float* saved /*[2]: mean,rstd*/,
+                     void* stream);
+int d2r_saf_gate_bwd(const float* a, const float* dw, int B, int n, const float* bn_weight, const float* bn_bias,
+                     const float* saved, int train, float* da, float* d_bn_weight, float* d_bn_bias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K9  js_div on two [B,B] logit matrices (models/XModules.py:32-41) and K13 cross-entropy
+ * (models/unimo_model.py:147,160).  All fp32; single-workgroup latency kernels.
+ * ------------------------------------------------------------------------------------------------ */
+int d2r_jsdiv_fwd(const float* p_logits, const float* q_logits, int B, float* out /*[1]*/, void* stream);
+int d2r_jsdiv_bwd(const float* p_logits, const float* q_logits, int B, const float* dout /*[1]*/, float* dp,
+                  float* dq, void* stream);
+int d2r_ce_fwd(const float* logits, const int64_t* labels, int B, int C, float* loss /*[1]*/, void* stream);
+int d2r_ce_bwd(const float* logits, const int64_t* labels, int B, int C, const float* dloss /*[1]*/,
+               float* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K10 Block fusion core (models/XModules.py:541-549): z[b,c,s] = sum_r m0[b,c,r,s]*m1[b,c,r,s];
+ * signed sqrt; L2-normalise over s.  m0,m1: [B, C, R*S] (dtype T), out: [B, C*S] (dtype T), zraw fp32 [B,C*S].
+ * ------------------------------------------------------------------------------------------------ */
+int d2r_block_merge_fwd(int dtype, const void* m0, const void* m1, int B, int C, int R, int S, void* out,
+                        float* zraw, void* stream);
+int d2r_block_merge_bwd(int dtype, const void* m0, const void* m1, const float* zraw, const void* dout, int B,
+                        int C, int R, int S, void* dm0, void* dm1, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K12 embeddings (models/modeling_unimo.py:87-118, 272-331)
+ * ------------------------------------------------------------------------------------------------ */
+/* out[b,l,:] = word[ids[b,l]] + pos[l] + type[tt[b,l]]   (tables fp32, out dtype T; LayerNorm separately) */
+int d2r_bert_embed_fwd(int dtype, const int64_t* ids, const int64_t* tt, const float* word, const float* pos,
+                       const float* type, int B, int L, int D, int vocab, int ntype, void* out, void* stream);
+/* scatter-add (fp32 atomics) of dY into dword/dtype tables (pre-zeroed by caller), dpos[l] = sum_b dY[b,l];
+ * rows with ids == pad_id get no gradient (padding_idx, models/modeling_unimo.py:277). */
+int d2r_bert_embed_bwd(int dtype, const void* dY, const int64_t* ids, const int64_t* tt, int B, int L, int D,
+                       int64_t pad_id, float* dword, float* dpos, float* dtype_tab, void* stream);
+/* im2col for the stride=kernel patch conv: pixels fp32 [B,3,H,W] -> patches T [B*(H/p)*(W/p), 3*p*p] */
+int d2r_patchify(int dtype, const float* pixels, int B, int H, int W, int p, void* patches, void* stream);
+/* x[b,0,:] = cls + pos[0]; x[b,1+i,:] = patch_emb[b,i,:] + pos[1+i]  (in place on x [B,1+np,D], rows 1.. already
+ * hold the patch GEMM output) */
+int d2r_clip_embed_finish(int dtype, void* x, const float* cls, const float* pos, int B, int ntok, int D,
+                          void* stream);
+/* dcls[d] = sum_b dX[b,0,d]; dpos[t,d] = sum_b dX[b,t,d]  (fp32, OVERWRITTEN) */
+int d2r_clip_embed_bwd(int dtype, const void* dX, int B, int ntok, int D, float* dcls, float* dpos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K14 fused AdamW over a flat fp32 parameter range (modules/train.py:287-322: torch.optim.AdamW defaults
+ * betas=(0.9,0.999), eps=1e-8, weight_decay=1e-2, decoupled) + optional bf16 shadow copy of the weights.
+ * lr already includes the schedule factor; step is the 1-based step count (bias correction).
+ * ------------------------------------------------------------------------------------------------ */
+int d2r_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16 /*or NULL*/, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2R_HIP_H */

@@ -1,0 +1,75 @@
+"""A/B micro-benchmark of the MFMA GEMM family on the workload's shapes (not a pytest; run on the GPU box):
+    python tests/bench_gemm.py
+Interleaves the tuning variants in ONE process (cdna_hip_programming.md rule 24) and prints TFLOP/s per variant."""
+import itertools
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from d2r_amd import _lib
+from d2r_amd import functional as F
+from d2r_amd._lib import BF16, F32, GEMM_NN, GEMM_NT, GEMM_TN
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+
+# (layout, M, N, K): forward linears, dX, dW of the C2 workload (B=32, L=128 / 197 tokens)
+SHAPES = [
+    (GEMM_NT, 4096, 768, 768), (GEMM_NT, 6304, 768, 768), (GEMM_NT, 6304, 3072, 768), (GEMM_NT, 6304, 768, 3072),
+    (GEMM_NN, 4096, 768, 768), (GEMM_NN, 6304, 768, 3072), (GEMM_NN, 6304, 3072, 768),
+    (GEMM_TN, 768, 768, 4096), (GEMM_TN, 768, 768, 6304), (GEMM_TN, 3072, 768, 6304), (GEMM_TN, 768, 3072, 6304),
+]
+NAMES = {GEMM_NT: "NT", GEMM_NN: "NN", GEMM_TN: "TN"}
+
+
+def operands(layout, M, N, K, dtype):
+    a = torch.randn((M, K) if layout != GEMM_TN else (K, M), device=dev).to(dtype)
+    b = torch.randn((N, K) if layout == GEMM_NT else (K, N), device=dev).to(dtype)
+    c = torch.empty(M, N, device=dev, dtype=torch.float32 if layout == GEMM_TN else dtype)
+    return a, b, c
+
+
+def run(layout, M, N, K, a, b, c, use_ws):
+    F.gemm(layout, M, N, K, a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], c.data_ptr(), N,
+           dtype=BF16 if a.dtype == torch.bfloat16 else F32, c_dtype=F32 if c.dtype == torch.float32 else BF16,
+           beta=1.0 if layout == GEMM_TN else 0.0, splitk_ws=ws if use_ws else None)
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+variants = [(nbuf, vepi, tile) for nbuf in (1, 2) for vepi in (0, 1) for tile in (-1, 1, 2, 3)]
+dtype = torch.bfloat16
+print("variant = (lds_buffers, vector_epilogue, tile[-1 auto,1:64x64,2:128x64,3:128x128]); TFLOP/s")
+for layout, M, N, K in SHAPES:
+    a, b, c = operands(layout, M, N, K, dtype)
+    res = {}
+    for rnd in range(2):
+        for v in variants:
+            lib.d2r_gemm_tuning(*v)
+            t = timeit(lambda: run(layout, M, N, K, a, b, c, layout == GEMM_TN))
+            res.setdefault(v, []).append(2.0 * M * N * K / t / 1e12)
+    best = max(res, key=lambda v: min(res[v]))
+    line = " ".join(f"{v}:{min(r):.0f}" for v, r in res.items())
+    # hipBLASLt through torch as a yard-stick (same shapes, same data)
+    if layout == GEMM_NT:
+        tt = timeit(lambda: torch.matmul(a, b.t()))
+    elif layout == GEMM_NN:
+        tt = timeit(lambda: torch.matmul(a, b))
+    else:
+        tt = timeit(lambda: torch.matmul(a.t(), b))
+    print(f"{NAMES[layout]} M={M} N={N} K={K}: best {best} {min(res[best]):.0f} TF/s | hipBLASLt {2.0 * M * N * K / tt / 1e12:.0f} TF/s\n    {line}", flush=True)
+lib.d2r_gemm_tuning(1, 1, -1)

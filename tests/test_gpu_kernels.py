@@ -1,0 +1,337 @@
+"""GPU parity of every HIP op (forward AND backward, through the C ABI) against a plain PyTorch CPU fp64
+expression of the same op.  fp32 mode is checked tightly; bf16 mode within bf16 rounding of the fp64 truth."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, scale=1.0):
+    return (2e-5 if dtype == torch.float32 else 2.5e-2) * scale
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (scale * torch.randn(tuple(shape), generator=g)).to(dtype)
+
+
+def check(name, got, ref, dtype, scale=None, loosen=1.0):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double()
+    s = max(float(ref.abs().max()), 1e-6) if scale is None else scale
+    err = float((got - ref).abs().max())
+    assert err <= loosen * tol(dtype) * s + 1e-7, f"{name}: max err {err:.3e} vs scale {s:.3e} ({dtype})"
+
+
+def run_both(fn_gpu, fn_ref, inputs, dtype, gpu, wrt=None, name="op", out_scale=None, grad_loosen=1.0):
+    """inputs: list of CPU tensors (fp32 master values).  Runs fwd+bwd on the GPU op and the fp64 reference."""
+    wrt = range(len(inputs)) if wrt is None else wrt
+    xs_g = []
+    for i, x in enumerate(inputs):
+        t = x.to(dtype) if x.is_floating_point() and getattr(x, "_keep32", False) is False else x
+        t = t.to(gpu)
+        if i in wrt:
+            t.requires_grad_(True)
+        xs_g.append(t)
+    xs_r = []
+    for i, x, xg in zip(range(len(inputs)), inputs, xs_g):
+        t = xg.detach().double().cpu() if x.is_floating_point() else x.clone()
+        if i in wrt:
+            t.requires_grad_(True)
+        xs_r.append(t)
+    out_g = fn_gpu(*xs_g)
+    out_r = fn_ref(*xs_r)
+    if not isinstance(out_g, (tuple, list)):
+        out_g, out_r = [out_g], [out_r]
+    loss_g, loss_r = 0, 0
+    for k, (og, orr) in enumerate(zip(out_g, out_r)):
+        check(f"{name}.out{k}", og, orr, og.dtype if og.dtype == torch.bfloat16 else dtype, out_scale)
+        w = rnd(*orr.shape, seed=100 + k).double()
+        loss_g = loss_g + (og.float() * w.float().to(gpu)).sum()
+        loss_r = loss_r + (orr * w).sum()
+    loss_g.backward()
+    loss_r.backward()
+    for i in wrt:
+        assert xs_g[i].grad is not None, f"{name}: no grad for input {i}"
+        check(f"{name}.grad{i}", xs_g[i].grad, xs_r[i].grad, dtype, loosen=grad_loosen)
+
+
+def keep32(t):
+    t._keep32 = True
+    return t
+
+
+def wt(*shape, dtype, seed=0, scale=1.0):
+    """fp32 master weight whose values are exactly representable in `dtype` (so the bf16 shadow is exact)."""
+    return keep32(rnd(*shape, seed=seed, scale=scale).to(dtype).float())
+
+
+def lp(w, dtype):
+    from d2r_amd import functional as F
+    return F.cast(w.detach(), dtype)
+
+
+ACTS = {"none": (0, lambda x: x), "relu": (1, torch.relu), "tanh": (2, torch.tanh),
+        "gelu": (3, torch.nn.functional.gelu), "quick_gelu": (4, lambda x: x * torch.sigmoid(1.702 * x)),
+        "tanh_relu": (5, lambda x: torch.relu(torch.tanh(x)))}
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("act", list(ACTS))
+def test_linear(gpu, dtype, act):
+    from d2r_amd import functional as F
+    code, ref = ACTS[act]
+    x, w, b = rnd(3, 37, 96, dtype=torch.float32), wt(72, 96, dtype=dtype, scale=0.2), keep32(rnd(72, scale=0.5))
+
+    def f(x, w, b):
+        return F.linear(x, w, b, lp(w, dtype), act=code)
+
+    run_both(f, lambda x, w, b: ref(x @ w.t() + b), [x, w, b], dtype, gpu, name=f"linear[{act}]")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_linear_residual_and_strided(gpu, dtype):
+    from d2r_amd import functional as F
+    x, w, b, r = rnd(4, 9, 768), wt(768, 768, dtype=dtype, scale=0.05), keep32(rnd(768)), rnd(4, 9, 768)
+    run_both(lambda x, w, b, r: F.linear(x, w, b, lp(w, dtype), residual=r), lambda x, w, b, r: x @ w.t() + b + r,
+             [x, w, b, r], dtype, gpu, name="linear+res")
+    # strided rows: x[:, 0] (BertPooler) without a copy
+    run_both(lambda x, w, b: F.linear(x[:, 0], w, b, lp(w, dtype), act=2), lambda x, w, b: torch.tanh(x[:, 0] @ w.t() + b),
+             [x, w, b], dtype, gpu, name="linear cls rows")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_linear_fp32_out(gpu, dtype):
+    from d2r_amd import functional as F
+    x, w, b = rnd(5, 11, 768), wt(1, 768, dtype=dtype, scale=0.1), keep32(rnd(1))
+    run_both(lambda x, w, b: F.linear(x, w, b, lp(w, dtype), out_dtype=torch.float32), lambda x, w, b: x @ w.t() + b,
+             [x, w, b], dtype, gpu, name="linear N=1 fp32 out")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", [(2, 8, 8, 4, 0.3, False, False), (3, 16, 5, 1, 100 / math.sqrt(768), False, True),
+                                 (2, 197, 197, 12, 0.125, True, False), (2, 40, 40, 16, 1 / math.sqrt(48), False, True)])
+def test_attention(gpu, dtype, cfg):
+    from d2r_amd import functional as F
+    B, Lq, Lk, H, scale, use_mask, use_res = cfg
+    E = 768
+    q, k, v = rnd(B, Lq, E, scale=0.5), rnd(B, Lk, E, scale=0.5, seed=1), rnd(B, Lk, E, seed=2)
+    mask = torch.zeros(B, Lk)
+    if use_mask:
+        mask[0, Lk // 2:] = -10000.0
+        mask[1, Lk - 3:] = -10000.0
+    res = rnd(B, Lq, E, seed=3)
+
+    def f(q, k, v, res):
+        return F.attention(q, k, v, H, scale, mask=mask.to(gpu) if use_mask else None, residual=res if use_res else None)
+
+    def r(q, k, v, res):
+        d = E // H
+        qh, kh, vh = (t.view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+        s = scale * qh @ kh.transpose(-1, -2)
+        if use_mask:
+            s = s + mask.double()[:, None, None, :]
+        o = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, E)
+        return o + res if use_res else o + 0 * res
+
+    run_both(f, r, [q, k, v, res], dtype, gpu, wrt=[0, 1, 2] + ([3] if use_res else []), name=f"attention{cfg}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layernorm_l2norm_softmax(gpu, dtype):
+    from d2r_amd import functional as F
+    x, g, b = rnd(3, 7, 768, scale=2.0), keep32(1 + 0.1 * rnd(768)), keep32(0.1 * rnd(768, seed=1))
+    run_both(lambda x, g, b: F.layer_norm(x, g, b, 1e-12), lambda x, g, b: torch.nn.functional.layer_norm(x, (768,), g, b, 1e-12),
+             [x, g, b], dtype, gpu, name="layernorm")
+    run_both(lambda x: F.l2norm(x), lambda x: x / (x.pow(2).sum(-1, keepdim=True).sqrt() + 1e-8), [x], dtype, gpu, name="l2norm")
+    z = rnd(5, 768, scale=3.0)
+    run_both(lambda z: F.softmax_rows(z), lambda z: torch.softmax(z, -1), [z], dtype, gpu, name="softmax_rows",
+             out_scale=1.0 if dtype == torch.float32 else 0.05)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_elementwise(gpu, dtype):
+    from d2r_amd import functional as F
+    a, b, c = rnd(2, 5, 768), rnd(2, 5, 768, seed=1), rnd(2, 5, 768, seed=2)
+    run_both(F.sqdiff, lambda a, b: (a - b) ** 2, [a, b], dtype, gpu, name="sqdiff")
+    run_both(F.muladd, lambda a, s, h: a * s + h, [a, b, c], dtype, gpu, name="muladd")
+    g = torch.rand(2, 768)
+    run_both(F.lerp_gate, lambda g, a, b: g * a + (1 - g) * b, [g, rnd(2, 768), rnd(2, 768, seed=5)], dtype, gpu, name="lerp")
+    run_both(F.add, lambda a, b: a + b, [a, b], dtype, gpu, name="add")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_meanpool_and_router(gpu, dtype):
+    from d2r_amd import functional as F
+    xs = [rnd(3, 13, 768, seed=i) for i in range(6)]
+    run_both(lambda *x: F.mean_pool(list(x)), lambda *x: torch.stack([t.mean(1) for t in x]), xs, dtype, gpu, name="meanpool6")
+    run_both(lambda x: F.mean_pool([x])[0], lambda x: x.mean(1), [xs[0]], dtype, gpu, name="meanpool1")
+
+
+def _agg_ref(gates, x0, e1, e2, e3, e4, e5, *refs):
+    B, L, D = x0.shape
+    P = gates.shape[2]
+    embs = [torch.relu(x0), e1[:, None].expand(B, L, D), e2, e3, e4, e5[:, None].expand(B, L, D)]
+    G = gates.permute(1, 2, 0)  # [B,P,6]
+    thr, thr_f = float(torch.tensor(1e-4, dtype=torch.float32)), float(torch.tensor(1e-4 / 6, dtype=torch.float32))
+    if P == 1:
+        rr = [x0] + list(refs)
+        skip = (G < thr_f).double()
+        num = sum(G[:, 0, j, None, None] * embs[j] + skip[:, 0, j, None, None] * rr[j] for j in range(6))
+        den = (skip.sum(-1) + G.sum(-1))[:, :, None]
+        return (G, num / den)
+    skip = (G.sum(-1) < thr).double()
+    probs = G / (G.sum(-1, keepdim=True) + float(torch.tensor(1e-8, dtype=torch.float32)))
+    outs = [sum(probs[:, i, j, None, None] * embs[j] for j in range(6)) + skip[:, i, None, None] * embs[0] for i in range(6)]
+    return (probs, *outs)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("P,regime", [(6, "open"), (6, "mixed"), (6, "closed"), (1, "open"), (1, "mixed"), (1, "closed")])
+def test_route_aggregate(gpu, dtype, P, regime):
+    from d2r_amd import functional as F
+    B, L, D = 4, 19, 768
+    g = torch.Generator().manual_seed(5)
+    gates = torch.rand(6, B, P, generator=g)
+    if regime == "mixed":
+        gates = gates * (torch.rand(6, B, P, generator=g) > 0.5)
+        gates[:, 0, :] = 0.0  # one sample with every path closed -> skip connection
+    elif regime == "closed":
+        gates.zero_()
+    gates = keep32(gates.float())
+    x0, e2, e3, e4 = (rnd(B, L, D, seed=i) for i in range(4))
+    e1, e5 = rnd(B, D, seed=7), rnd(B, D, seed=8)
+    refs = [rnd(B, L, D, seed=10 + i) for i in range(5)] if P == 1 else []
+    inputs = [gates, x0, e1, e2, e3, e4, e5] + refs
+
+    def f(gates, x0, e1, e2, e3, e4, e5, *refs):
+        probs, outs = F.route_aggregate(gates, x0, e1, e2, e3, e4, e5, refs=list(refs) if refs else None)
+        return (probs, *outs)
+
+    if P == 1 and regime == "closed":
+        wrt = list(range(1, len(inputs)))  # d/dgate at g=0 with every path closed is well defined but huge
+    else:
+        wrt = None
+    run_both(f, _agg_ref, inputs, dtype, gpu, wrt=wrt, name=f"aggregate P={P} {regime}")
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_saf_gate(gpu, train):
+    from d2r_amd import functional as F
+    B, n = 5, 33
+    a, bw, bb = rnd(B, n, scale=2.0), torch.tensor([1.3]), torch.tensor([-0.2])
+    rm, rv = torch.tensor([0.1]), torch.tensor([1.5])
+    rm_g, rv_g = rm.clone().to(gpu), rv.clone().to(gpu)
+
+    def ref(a, bw, bb):
+        if train:
+            mu, var = a.mean(), a.var(unbiased=False)
+        else:
+            mu, var = rm.double()[0], rv.double()[0]
+        s = torch.sigmoid((a - mu) / torch.sqrt(var + 1e-5) * bw + bb)
+        return s / (s.abs().sum(-1, keepdim=True) + 1e-8)
+
+    run_both(lambda a, bw, bb: F.saf_gate(a, bw, bb, rm_g, rv_g, train), ref, [a, bw, bb], torch.float32, gpu, name="saf_gate")
+    if train:
+        N = B * n
+        assert abs(float(rm_g[0]) - (0.9 * 0.1 + 0.1 * float(a.mean()))) < 1e-5
+        assert abs(float(rv_g[0]) - (0.9 * 1.5 + 0.1 * float(a.var(unbiased=False)) * N / (N - 1))) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_weighted_row_sum(gpu, dtype):
+    from d2r_amd import functional as F
+    w, S = torch.rand(3, 21), rnd(3, 21, 768)
+    run_both(F.weighted_row_sum, lambda w, S: torch.bmm(w[:, None], S)[:, 0], [w, S], dtype, gpu, name="weighted_row_sum")
+
+
+def test_losses(gpu):
+    from d2r_amd import functional as F
+    p, q = rnd(7, 7, scale=3.0), rnd(7, 7, scale=2.0, seed=3)
+
+    def js(p, q):
+        pp, qq = torch.softmax(p, -1), torch.softmax(q, -1)
+        lm = ((pp + qq) / 2).log()
+        kl = torch.nn.KLDivLoss(reduction="batchmean")
+        return (kl(lm, pp) + kl(lm, qq)) / 2
+
+    run_both(F.js_div, js, [p, q], torch.float32, gpu, name="js_div")
+    logits, labels = rnd(9, 3, scale=2.0), torch.tensor([0, 2, 1, 1, 0, 2, 2, 0, 1])
+    run_both(lambda l: F.cross_entropy(l, labels.to(gpu)), lambda l: torch.nn.functional.cross_entropy(l, labels),
+             [logits], torch.float32, gpu, name="cross_entropy")
+    a, b = rnd(), rnd(seed=4)
+    run_both(lambda a, b: F.lincomb([1.0, -0.3], [a, b]), lambda a, b: a - 0.3 * b, [a, b], torch.float32, gpu, name="lincomb")
+    x = rnd(6, 768, scale=0.2)
+    run_both(lambda x: F.matmul_nt(x, x), lambda x: x @ x.t(), [x], torch.float32, gpu, name="matmul_nt")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_block_merge(gpu, dtype):
+    from d2r_amd import functional as F
+    B, Cn, R, S = 3, 20, 15, 80
+    m0, m1 = rnd(B, Cn, R * S, scale=0.5), rnd(B, Cn, R * S, scale=0.5, seed=1)
+
+    def ref(m0, m1):
+        z = (m0 * m1).view(B, Cn, R, S).sum(2)
+        z = torch.sqrt(torch.relu(z)) - torch.sqrt(torch.relu(-z))
+        return torch.nn.functional.normalize(z, p=2, dim=-1).reshape(B, Cn * S)
+
+    # d/dz sqrt|z| is unbounded near z = 0: the largest gradients carry the fp32 rounding of 1/sqrt|z|
+    run_both(lambda a, b: F.block_merge(a, b, Cn, R, S), ref, [m0, m1], dtype, gpu, name="block_merge", grad_loosen=5.0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_embeddings(gpu, dtype):
+    from d2r_amd import functional as F
+    B, L, D = 3, 9, 768
+    ids = torch.randint(0, 50, (B, L))
+    ids[0, 5:] = 0
+    tt = torch.randint(0, 2, (B, L))
+    word, pos, typ = keep32(rnd(50, D)), keep32(rnd(16, D, seed=1)), keep32(rnd(2, D, seed=2))
+
+    def ref(word, pos, typ):
+        return torch.nn.functional.embedding(ids, word, padding_idx=0) + typ[tt] + pos[:L][None]
+
+    run_both(lambda w, p, t: F.bert_embed(ids.to(gpu), tt.to(gpu), w, p, t, dtype), ref, [word, pos, typ], dtype, gpu,
+             name="bert_embed")
+    px = keep32(rnd(2, 3, 64, 64))
+    w, cls, pe = wt(D, 3, 32, 32, dtype=dtype, scale=0.05), keep32(rnd(D, seed=3)), keep32(rnd(5, D, seed=4))
+
+    def refc(px, w, cls, pe):
+        pt = torch.nn.functional.conv2d(px, w, stride=32).flatten(2).transpose(1, 2)
+        return torch.cat([cls.expand(2, 1, -1), pt], 1) + pe[None]
+
+    run_both(lambda px, w, cls, pe: F.clip_embed(px, w, lp(w, dtype), cls, pe, 32), refc, [px, w, cls, pe], dtype, gpu,
+             wrt=[1, 2, 3], name="clip_embed")
+
+
+def test_adamw_matches_torch(gpu):
+    from d2r_amd import _lib
+    from d2r_amd.functional import _stream
+    n = 1000 + 3
+    w0, g = rnd(n), rnd(n, seed=1)
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.AdamW([p], lr=3e-3, weight_decay=1e-2)
+    w = w0.clone().to(gpu)
+    m, v = torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+    w16 = torch.zeros(n, dtype=torch.bfloat16, device=gpu)
+    for step in range(1, 4):
+        gs = g * step
+        p.grad = gs.clone()
+        opt.step()
+        gg = (gs * 2.0).to(gpu)  # grad_scale 0.5 undoes the doubling (data-parallel SUM -> mean)
+        _lib.call("d2r_adamw_step", w.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), w16.data_ptr(), n, 3e-3, 0.9,
+                  0.999, 1e-8, 1e-2, step, 0.5, _stream())
+    assert float((w.cpu() - p.detach()).abs().max()) < 1e-6
+    assert float((w16.float().cpu() - p.detach()).abs().max()) < 1e-2
+
+
+def test_ops_refuse_cpu_tensors():
+    from d2r_amd import functional as F
+    from d2r_amd import D2RError
+    with pytest.raises(D2RError):
+        F.linear(torch.zeros(2, 8), torch.zeros(4, 8), None)
