@@ -130,7 +130,9 @@ class BertPooler(D2RModule):
         super().__init__()
         self.dense = Linear(hidden, hidden)
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states, fp32=False):
+        if fp32:  # loss-side poolers: [B,768] only, kept fp32 (the Block signed-sqrt amplifies bf16 rounding)
+            return self.dense(F.cast_ad(hidden_states[:, 0].contiguous(), torch.float32), act=ACT_TANH, fp32=True)
         return self.dense(hidden_states[:, 0], act=ACT_TANH)  # strided rows, no copy
 
 
@@ -584,11 +586,13 @@ class Block(D2RModule):
         self.linear_out = Linear(mm_dim, output_dim)
 
     def forward(self, x):
-        x0, x1 = self.linear0(x[0]), self.linear1(x[1])
+        """x: two fp32 [B,768] pooled vectors.  The whole fusion runs in fp32 (per-sample vectors only): the signed
+        square root has an unbounded derivative at 0, which would amplify bf16 rounding into every gradient."""
+        x0, x1 = self.linear0(x[0], fp32=True), self.linear1(x[1], fp32=True)
         s = self.size
-        m0 = torch.stack([self.merge_linears0[c](x0[:, c * s:(c + 1) * s]) for c in range(self.chunks)], dim=1)
-        m1 = torch.stack([self.merge_linears1[c](x1[:, c * s:(c + 1) * s]) for c in range(self.chunks)], dim=1)
-        return self.linear_out(F.block_merge(m0, m1, self.chunks, self.rank, s))
+        m0 = torch.stack([self.merge_linears0[c](x0[:, c * s:(c + 1) * s], fp32=True) for c in range(self.chunks)], dim=1)
+        m1 = torch.stack([self.merge_linears1[c](x1[:, c * s:(c + 1) * s], fp32=True) for c in range(self.chunks)], dim=1)
+        return self.linear_out(F.block_merge(m0, m1, self.chunks, self.rank, s), fp32=True)
 
 
 class UnimoModel(D2RModule):
@@ -627,17 +631,17 @@ class UnimoModel(D2RModule):
         t_out = t_enc
         for layer in self.self_text:
             t_out = layer(t_out, key_mask)
-        t_cls = self.text_cls_pool(t_out)
+        t_cls = self.text_cls_pool(t_out, fp32=True)
         v_out = v_enc
         for layer in self.self_vision:
             v_out = layer(v_out)
-        v_cls = self.vision_cls_pool(v_out)
+        v_cls = self.vision_cls_pool(v_out, fp32=True)
         (emb_t,), sim_paths = self.itr_module(t_enc, v_enc)
         (emb_v,), rev_sim_paths = self.Reversed_itr_module(t_enc, v_enc)
         js1 = F.js_div(sim_paths, F.matmul_nt(t_cls, t_cls))
         js2 = F.js_div(rev_sim_paths, F.matmul_nt(v_cls, v_cls))
         js_loss = F.lincomb([-self.args.weight_js_1, -self.args.weight_js_2], [js1, js2])
-        pooled = self.block_fusion([self.text_pool(emb_t), self.vision_pool(emb_v)])
+        pooled = self.block_fusion([self.text_pool(emb_t, fp32=True), self.vision_pool(emb_v, fp32=True)])
         aux = dict(emb_text=emb_t, emb_image=emb_v, sim_paths=sim_paths, rev_sim_paths=rev_sim_paths,
                    text_encode_out=t_enc, vision_encode_out=v_enc)
         return pooled, js_loss, aux
@@ -656,7 +660,7 @@ class UnimoModelF(D2RModule):
     def forward(self, input_ids, attention_mask, token_type_ids, labels, images):
         pooled, js_loss, aux = self.model(input_ids=input_ids, attention_mask=attention_mask,
                                           token_type_ids=token_type_ids, pixel_values=images)
-        logits = self.fc(pooled, out_dtype=torch.float32)
+        logits = self.fc(pooled, fp32=True)
         loss = F.lincomb([1.0, 1.0], [F.cross_entropy(logits, labels), js_loss])
         aux["js_loss"] = js_loss
         self.last_aux = aux

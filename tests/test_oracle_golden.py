@@ -1,0 +1,106 @@
+"""CPU: the oracle (oracle/d2r_oracle.py) against the committed golden fixtures produced by the REAL reference
+(tests/golden/*.npz; generator: oracle/make_goldens.py).  No reference and no GPU needed."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import d2r_oracle as O
+from oracle.golden_cases import MODEL_CASES, ROUTING_CASES
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _err(a, b):
+    return float((a.detach().double() - b.double()).abs().max())
+
+
+def _layers(dr):
+    return ["dynamic_itr_l0"] + [f"dynamic_itr_l1.{i}" for i in range(dr - 2)] + ["dynamic_itr_l2"]
+
+
+@pytest.mark.parametrize("case", ROUTING_CASES, ids=lambda c: c.name)
+def test_oracle_routing_module_matches_reference_fixture(case):
+    g = load_golden(case.name)
+    cfg = O.OracleConfig(DR_step=case.DR_step)
+    sd = O.seeded_state_dict(cfg, seed=case.seed, router_bias=case.router_bias, spec=O.interaction_spec(cfg),
+                             seed_prefix="rev." if case.reversed_branch else "fwd.")
+    osd = {"M." + k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    own = _t(g["own"]).double().requires_grad_(True)
+    other = _t(g["other"]).double().requires_grad_(True)
+    st, trace = O.BNState(case.train), {}
+    emb, sim = O.interaction_module(osd, "M", own, other, case.DR_step, st, trace)
+    ((emb * _t(g["r_emb"]).double()).sum() + (sim * _t(g["r_sim"]).double()).sum()).backward()
+    # fixtures store big activations as fp32: compare at fp32 resolution
+    assert _err(emb, _t(g["emb"])) <= 1e-6 * max(1.0, float(np.abs(g["emb"]).max()))
+    assert _err(sim, _t(g["sim_paths"])) <= 1e-9 * max(1.0, float(np.abs(g["sim_paths"]).max()))
+    assert _err(own.grad, _t(g["d_own"])) <= 1e-6 * max(1.0, float(np.abs(g["d_own"]).max()))
+    assert _err(other.grad, _t(g["d_other"])) <= 1e-6 * max(1.0, float(np.abs(g["d_other"]).max()))
+    for ln in _layers(case.DR_step):
+        raw = _t(g[f"raw_gates/{ln}"])
+        assert _err(trace[f"M.{ln}.raw_gates"], raw) <= 1e-10
+        assert _err(trace[f"M.{ln}.probs"], _t(g[f"probs/{ln}"])) <= 1e-10
+        assert torch.equal(trace[f"M.{ln}.gate_mask"].double(), _t(g[f"gate_mask/{ln}"]).double()), ln  # decisions: exact
+        assert torch.equal(trace[f"M.{ln}.raw_gates"] > 0, raw > 0), ln
+    names, norms = [str(k) for k in g["grad_names"]], g["grad_norms"]
+    scale = float(norms.max()) if len(norms) and norms.max() > 0 else 1.0
+    for k, nr in zip(names, norms):
+        mine = float(osd["M." + k].grad.norm())
+        assert abs(mine - nr) <= 1e-8 * (nr + 1e-3 * scale), k
+    for key in [k for k in g if k.startswith("grad/")]:
+        # (fixtures above 4096 elements are stored as fp32)
+        assert _err(osd["M." + key[5:]].grad, _t(g[key])) <= 2e-7 * (float(np.abs(g[key]).max()) + 1e-3 * scale), key
+    for key in [k for k in g if k.startswith("bn_after/")]:
+        assert _err(st.updates["M." + key[9:]].double(), _t(g[key])) <= 1e-10, key
+
+
+@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c.layers <= 2], ids=lambda c: c.name)
+def test_oracle_full_model_matches_reference_fixture(case):
+    g = load_golden(case.name)
+    cfg = case.cfg()
+    sd = O.seeded_state_dict(cfg, seed=case.seed, router_bias=case.router_bias)
+    assert abs(float(sd["fc.weight"].double().sum()) - float(g["wsum/fc.weight"])) < 1e-9  # generator drift guard
+    assert abs(float(sd["model.text_embeddings.word_embeddings.weight"].double().sum()) - float(g["wsum/word_emb"])) < 1e-6
+    osd = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running_" not in k else
+               (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    batch = [_t(g[k]) for k in ("input_ids", "attention_mask", "token_type_ids", "labels", "images")]
+    loss, logits, aux = O.forward(osd, cfg, batch[0], batch[1], batch[2], batch[3], batch[4].double(), train=case.train)
+    loss.backward()
+    assert _err(loss, _t(g["loss"])) <= 1e-10
+    assert _err(logits, _t(g["logits"])) <= 1e-10
+    assert _err(aux["js_loss"], _t(g["js_loss"])) <= 1e-10
+    for k in ("emb_text", "emb_image"):
+        assert _err(aux[k], _t(g[k])) <= 1e-6 * max(1.0, float(np.abs(g[k]).max())), k  # fp32-stored fixture
+    for k in ("sim_paths", "rev_sim_paths"):
+        assert _err(aux[k], _t(g[k])) <= 1e-9 * max(1.0, float(np.abs(g[k]).max())), k
+    names, norms = [str(k) for k in g["grad_names"]], g["grad_norms"]
+    scale = float(norms.max())
+    for k, nr in zip(names, norms):
+        assert abs(float(osd[k].grad.norm()) - nr) <= 1e-7 * (nr + 1e-3 * scale), k
+    live = set(names)
+    for k, v in osd.items():  # the dead-parameter list is exactly the set the reference leaves without gradient
+        if v.is_floating_point() and v.requires_grad:
+            assert (k in live) == (not O.is_dead_param(k)), k
+    for key in [k for k in g if k.startswith("grad/")]:
+        assert _err(osd[key[5:]].grad, _t(g[key])) <= 2e-7 * (float(np.abs(g[key]).max()) + 1e-3 * scale), key
+
+
+def test_param_spec_counts():
+    spec = O.param_spec(O.OracleConfig())
+    assert len(spec) == 1210  # 1,210 state-dict keys at DR_step=3
+    n = sum(int(np.prod(s)) for k, s in spec.items() if not k.endswith(("position_ids", "num_batches_tracked", "running_mean", "running_var")))
+    assert abs(n - 407.8e6) < 0.1e6  # 407.8 M parameters
+    dead = sum(int(np.prod(s)) for k, s in spec.items() if O.is_dead_param(k))
+    assert abs(dead - 52.6e6) < 0.1e6  # 52.6 M never receive a gradient
+    assert len(O.param_spec(O.OracleConfig(DR_step=2))) < len(spec) < len(O.param_spec(O.OracleConfig(DR_step=4)))
+
+
+def test_dr_step_2_extension_runs():
+    """DR_step=2 crashes in the reference (InteractionModule.py:38-47); the natural extension is cat(l0, l2)."""
+    cfg = O.OracleConfig(DR_step=2)
+    sd = O.seeded_state_dict(cfg, seed=3, router_bias="normal", spec=O.interaction_spec(cfg))
+    own, other = torch.randn(2, 6, 768), torch.randn(2, 4, 768)
+    emb, sim = O.interaction_module({"M." + k: v for k, v in sd.items()}, "M", own, other, 2, O.BNState(False))
+    assert emb.shape == (2, 6, 768) and sim.shape == (2, 2) and torch.isfinite(emb).all()
