@@ -34,7 +34,9 @@ def sources():
 
 def _digest(path: str) -> str:
     h = hashlib.sha256()
-    for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "d2r_hip.h")]:
+    deps = [path, os.path.join(INCLUDE, "d2r_hip.h")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for dep in deps:
         with open(dep, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())

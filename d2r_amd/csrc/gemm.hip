@@ -18,47 +18,7 @@
 // include/d2r_hip.h, section K11.
 #include <stdlib.h>
 
-#include "common.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-struct GemmArgs {
-  const void* A;
-  const void* B;
-  void* C;
-  const float* bias;
-  const void* R;
-  void* P;
-  float* ws;  // split-K partial slabs [splits][M][N] (fp32) or null
-  int M, N, K, nh, splits, tiles_per_split;
-  int64_t lda, ldb, ldc, ldr;
-  int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh;
-  float alpha, beta;
-  int act, c_dtype, vecA, vecB, vecC;
-};
-
-// Loads VEC consecutive elements [c0, c0+VEC) of a row; zero outside [0, climit) or when !row_ok.
-template <typename T, int VEC>
-__device__ __forceinline__ Pack<T, VEC> load_guard(const T* rowp, int c0, int climit, bool row_ok, bool vec_ok) {
-  Pack<T, VEC> r;
-  if (row_ok && vec_ok && c0 + VEC <= climit) {
-    r = ld_pack<T, VEC>(rowp + c0);
-  } else {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) r.v[j] = (row_ok && c0 + j < climit) ? rowp[c0 + j] : from_f<T>(0.f);
-  }
-  return r;
-}
-
-__device__ __forceinline__ void store_c(void* C, int c_dtype, int64_t idx, float v) {
-  if (c_dtype == D2R_BF16) reinterpret_cast<bf16_t*>(C)[idx] = (bf16_t)v;
-  else reinterpret_cast<float*>(C)[idx] = v;
-}
-__device__ __forceinline__ float load_c(const void* C, int c_dtype, int64_t idx) {
-  return c_dtype == D2R_BF16 ? (float)reinterpret_cast<const bf16_t*>(C)[idx] : reinterpret_cast<const float*>(C)[idx];
-}
+#include "gemm_args.h"
 
 template <typename T, int LAYOUT, int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -91,7 +51,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tile_m, tile_n;
+  xcd_tile(g.xcd, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   int z = blockIdx.z, split = 0;
   if (g.splits > 1) {
     split = z;
@@ -392,8 +354,10 @@ static int env_int(const char* name, int dflt) {
 static int g_nbuf = env_int("D2R_GEMM_NBUF", 1);
 static int g_vepi = env_int("D2R_GEMM_VEPI", 1);
 static int g_tile = env_int("D2R_GEMM_TILE", -1);
+static int g_xcd = env_int("D2R_GEMM_XCD", 1);
 extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
-  g_nbuf = nbuf;
+  g_nbuf = nbuf & 0xff;
+  g_xcd = (nbuf >> 8) & 1 ? 0 : 1;  // bit 8 of the first argument disables the XCD-aware tile order (A/B runs)
   g_vepi = vepi;
   g_tile = tile;
 }
@@ -405,8 +369,25 @@ static void launch_tile(const GemmArgs& a, int gz, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_kernel<T, LAYOUT, BM, BN, WM_, WN_, 1>), grid, dim3(256), 0, st, a);
 }
 
+int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st);  // gemm_glds.hip
+static int g_glds = env_int("D2R_GEMM_GLDS", 1);
+
 template <typename T, int LAYOUT>
 static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t ws_bytes) {
+  if constexpr (sizeof(T) == 2) {
+    // large bf16 shapes: LDS-DMA pipelined 128xBN kernel (forced with tile 4 = 128x128, 5 = 128x64 for A/B runs)
+    const int64_t t128 = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 128);
+    const int64_t t64 = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 64);
+    int bn = 0;
+    if (g_tile == 4) bn = 128;
+    else if (g_tile == 5) bn = 64;
+    else if (g_tile < 0 && g_glds && a.K >= 2048) bn = t64 >= 256 ? 64 : 0;  // measured: only the K=3072 shapes win
+    if (bn) {
+      GemmArgs b = a;
+      b.ws = nullptr; b.splits = 1; b.tiles_per_split = 0;
+      if (d2r_gemm_glds_try(b, LAYOUT, batch, bn, st)) return d2r_check_launch("d2r_gemm(glds)");
+    }
+  }
   constexpr int BK = sizeof(T) == 2 ? 64 : 16;
   const int64_t t128 = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 128) * batch;
   const int64_t t12864 = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 64) * batch;
@@ -419,7 +400,7 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
   if (a.M <= 32) tile = 0;
   else if (LAYOUT == D2R_GEMM_TN && batch == 1) tile = ((int64_t)a.M * a.N >= 2000000) ? 3 : 2;
   else tile = 1;
-  if (g_tile >= 0 && a.M > 32) tile = g_tile;
+  if (g_tile >= 0 && g_tile <= 3 && a.M > 32) tile = g_tile;
   if (tile > 1) a.vecC = 0;  // the LDS-staged epilogue only pays on the small tiles (register pressure on the large ones)
   // deterministic split-K for reduction-heavy GEMMs with few output tiles (weight gradients)
   a.splits = 1;
@@ -489,7 +470,7 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   a.sAb = d->sAb; a.sAh = d->sAh; a.sBb = d->sBb; a.sBh = d->sBh;
   a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh;
   a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype;
-  a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0;
+  a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd;
   const int64_t es = (int64_t)d2r_esize(d->dtype);
   auto vec_ok = [&](const void* p, int64_t ld, int64_t sb, int64_t sh) {
     return d2r_aligned16(p) && (ld * es) % 16 == 0 && (sb * es) % 16 == 0 && (sh * es) % 16 == 0;

@@ -1,0 +1,252 @@
+// gemm_glds.hip — bf16 MFMA GEMM for the LARGE shapes of the path (fused q|k|v projections, FFN up/down, their
+// dX / dW): 128 x BN x 64 tiles, operand tiles streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR
+// staging, no ds_write), two LDS buffers, counted vmcnt so the next tile's DMA stays in flight across the barriers.
+//
+// LDS-DMA writes wave-uniform base + lane*16 B, i.e. the LDS image is linear; bank conflicts are avoided by an XOR
+// swizzle applied to the per-lane SOURCE address and, identically, to the read address (cdna_hip_programming.md
+// rule 21):
+//   k-contiguous operand (A of NT/NN, B of NT): image [rows][64 k] (128 B rows); 16-B chunk c of row r sits at
+//       position c ^ (r & 7); fragments are ds_read_b128.
+//   k-strided operand (B of NN, A/B of TN): image [64 k][R rows] (R*2 B rows); chunk c of k-row k sits at position
+//       c ^ (k & (R/8-1)); fragments are two ds_read_b64_tr_b16 (hardware transpose).
+// Rows / columns past the matrix edge are CLAMPED to a valid address instead of zero-filled: they only feed output
+// elements that are never stored.  Requirements (checked by the host dispatcher, else the generic kernel runs):
+// bf16, batch 1, K % 64 == 0, 16-B aligned operands, and M % 8 == N % 8 == 0 for k-strided operands.
+#include "gemm_args.h"
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+template <int LAYOUT, int BN>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
+  constexpr int BM = 128, BK = 64;
+  constexpr bool A_KCONT = (LAYOUT != D2R_GEMM_TN);
+  constexpr bool B_KCONT = (LAYOUT == D2R_GEMM_NT);
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF = A_BYTES + B_BYTES;
+  // LDS-DMA instructions (1 KiB each) per tile and per wave
+  constexpr int IA = A_BYTES / 1024 / 4, IB = B_BYTES / 1024 / 4;
+  constexpr int SZ_EPI = 4 * WM * (WN + 8) * 2;
+  constexpr int SZ_ALL = 2 * BUF > SZ_EPI ? 2 * BUF : SZ_EPI;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SZ_ALL];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  int tile_m, tile_n;
+  xcd_tile(g.xcd, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+
+  // per-lane source offsets (elements) of this wave's DMA instructions, without the k0 term
+  int64_t offA[IA], offB[IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int ins = wave + 4 * i;
+    if constexpr (A_KCONT) {  // 8 rows x 128 B per instruction
+      const int row = ins * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
+      const int grow = min(m0 + row, g.M - 1);
+      offA[i] = (int64_t)grow * g.lda + c * 8;
+    } else {  // [64 k][128 m]: 4 k-rows x 256 B per instruction
+      const int krow = ins * 4 + (lane >> 4), c = (lane & 15) ^ (krow & 15);
+      const int col = min(m0 + c * 8, g.M - 8);
+      offA[i] = (int64_t)krow * g.lda + col;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int ins = wave + 4 * i;
+    if constexpr (B_KCONT) {
+      const int row = ins * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
+      const int grow = min(n0 + row, g.N - 1);
+      offB[i] = (int64_t)grow * g.ldb + c * 8;
+    } else if constexpr (BN == 128) {
+      const int krow = ins * 4 + (lane >> 4), c = (lane & 15) ^ (krow & 15);
+      const int col = min(n0 + c * 8, g.N - 8);
+      offB[i] = (int64_t)krow * g.ldb + col;
+    } else {  // [64 k][64 n]: 8 k-rows x 128 B per instruction
+      const int krow = ins * 8 + (lane >> 3), c = (lane & 7) ^ (krow & 7);
+      const int col = min(n0 + c * 8, g.N - 8);
+      offB[i] = (int64_t)krow * g.ldb + col;
+    }
+  }
+
+  auto issue = [&](int t, int buf) {
+    const int k0 = t * BK;
+    unsigned char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const bf16_t* src = A + offA[i] + (A_KCONT ? (int64_t)k0 : (int64_t)k0 * g.lda);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const bf16_t* src = B + offB[i] + (B_KCONT ? (int64_t)k0 : (int64_t)k0 * g.ldb);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int nk = g.K / BK;
+  issue(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) {
+      issue(t + 1, cur ^ 1);  // buffer cur^1 was last read in iteration t-1; every wave has passed its closing barrier
+      if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (IA + IB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");  // (asm + memory clobber: the compiler may not move LDS reads / DMA issues across it)
+    // tile t has landed for every wave (own counted vmcnt + barrier)
+    const unsigned char* bA = smem + cur * BUF;
+    const unsigned char* bB = bA + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (A_KCONT) {
+          const int row = wm0 + i * 16 + fr, c = kk * 4 + fq;
+          af[i] = *reinterpret_cast<const bf16x8*>(bA + row * 128 + ((c ^ (row & 7)) << 4));
+        } else {
+          const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
+          const int c = col >> 3, h = (col & 7) >> 2;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8));
+          af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (B_KCONT) {
+          const int row = wn0 + j * 16 + fr, c = kk * 4 + fq;
+          bfr[j] = *reinterpret_cast<const bf16x8*>(bB + row * 128 + ((c ^ (row & 7)) << 4));
+        } else {
+          constexpr int ROWB = BN * 2, PM = BN / 8 - 1;
+          const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
+          const int c = col >> 3, h = (col & 7) >> 2;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8));
+          bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading buffer `cur` before it is refilled at t+1
+  }
+
+  // ---- epilogue (same semantics as the generic kernel) ------------------------------------------------
+  if (g.c_dtype == D2R_BF16 && g.vecC) {
+    constexpr int LDE = WN + 8;
+    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem) + wave * WM * LDE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 16 + fr;
+        const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(i * 16 + fq * 4 + r) * LDE + j * 16 + fr] = (bf16_t)(g.alpha * acc[i][j][r] + bv);
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = WN / 8;
+    bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C);
+    bf16_t* Pg = reinterpret_cast<bf16_t*>(g.P);
+    const bf16_t* Rg = reinterpret_cast<const bf16_t*>(g.R);
+#pragma unroll
+    for (int it = 0; it < WM * CPR / 64; ++it) {
+      const int e = it * 64 + lane;
+      const int rl = e / CPR, ch = e % CPR;
+      const int row = m0 + wm0 + rl, col = n0 + wn0 + ch * 8;
+      if (row >= g.M || col >= g.N) continue;
+      const Pack<bf16_t, 8> pv = ld_pack<bf16_t, 8>(Cs + rl * LDE + ch * 8);
+      const int64_t ci = (int64_t)row * g.ldc + col;
+      const int64_t ri = (int64_t)row * g.ldr + col;
+      if (col + 8 <= g.N) {
+        if (Pg) st_pack<bf16_t, 8>(Pg + ci, pv);
+        Pack<bf16_t, 8> rv, cv, ov;
+        if (Rg) rv = ld_pack<bf16_t, 8>(Rg + ri);
+        if (g.beta != 0.f) cv = ld_pack<bf16_t, 8>(Cg + ci);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float v = act_apply(g.act, (float)pv.v[u]);
+          if (Rg) v += (float)rv.v[u];
+          if (g.beta != 0.f) v += g.beta * (float)cv.v[u];
+          ov.v[u] = (bf16_t)v;
+        }
+        st_pack<bf16_t, 8>(Cg + ci, ov);
+      } else {
+        for (int u = 0; u < 8 && col + u < g.N; ++u) {
+          if (Pg) Pg[ci + u] = pv.v[u];
+          float v = act_apply(g.act, (float)pv.v[u]);
+          if (Rg) v += (float)Rg[ri + u];
+          if (g.beta != 0.f) v += g.beta * (float)Cg[ci + u];
+          Cg[ci + u] = (bf16_t)v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 16 + fr;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm0 + i * 16 + fq * 4 + r;
+        if (row >= g.M) continue;
+        float v = g.alpha * acc[i][j][r] + bv;
+        const int64_t ci = (int64_t)row * g.ldc + col;
+        if (g.P) store_c(g.P, g.c_dtype, ci, v);
+        v = act_apply(g.act, v);
+        if (g.R) v += load_c(g.R, g.c_dtype, (int64_t)row * g.ldr + col);
+        if (g.beta != 0.f) v += g.beta * load_c(g.C, g.c_dtype, ci);
+        store_c(g.C, g.c_dtype, ci, v);
+      }
+    }
+  }
+}
+
+template <int LAYOUT>
+static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
+  if (bn == 128) {
+    dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
+    hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 128));
+    hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 64>), grid, dim3(256), 0, st, a);
+  }
+}
+
+// Returns 1 when the launch was taken by the LDS-DMA kernel, 0 when the shape is not eligible.
+int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st) {
+  if (batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
+  if (!a.vecA || !a.vecB) return 0;
+  const bool a_strided = layout == D2R_GEMM_TN, b_strided = layout != D2R_GEMM_NT;
+  if ((a_strided && a.M % 8 != 0) || (b_strided && a.N % 8 != 0)) return 0;
+  switch (layout) {
+    case D2R_GEMM_NT: launch_glds<D2R_GEMM_NT>(a, bn, st); break;
+    case D2R_GEMM_NN: launch_glds<D2R_GEMM_NN>(a, bn, st); break;
+    case D2R_GEMM_TN: launch_glds<D2R_GEMM_TN>(a, bn, st); break;
+    default: return 0;
+  }
+  return 1;
+}

@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
                                                               float* __restrict__ d_gates) {
   __shared__ float dph[36];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (blockIdx.y == 0) {  // block-uniform: only the first column block finishes the 36 dot products
   if (tid < 36) {
     float t = dprobs ? dprobs[(int64_t)b * 36 + tid] : 0.f;
     for (int cidx = 0; cidx < nchunk; ++cidx) t += ws_dots[((int64_t)b * nchunk + cidx) * 36 + tid];
@@ -429,9 +430,20 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 6; ++j) d_gates[((int64_t)j * B + b) * 6 + i] = (dph[i * 6 + j] - dotp) * inv;
   }
-  for (int cidx = tid; cidx < 2 * D; cidx += 256) {
-    float t = 0.f;
-    for (int k = 0; k < nchunk; ++k) t += ws_bc[((int64_t)b * nchunk + k) * 2 * D + cidx];
+  }
+  const int cidx = blockIdx.y * 256 + tid;  // one column of [demb1 | demb5] per thread, grid.y column blocks
+  if (cidx < 2 * D) {
+    const float* w = ws_bc + (int64_t)b * nchunk * 2 * D + cidx;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nchunk; k += 4) {
+      t0 += w[(int64_t)k * 2 * D];
+      t1 += w[(int64_t)(k + 1) * 2 * D];
+      t2 += w[(int64_t)(k + 2) * 2 * D];
+      t3 += w[(int64_t)(k + 3) * 2 * D];
+    }
+    for (; k < nchunk; ++k) t0 += w[(int64_t)k * 2 * D];
+    const float t = (t0 + t1) + (t2 + t3);
     if (cidx < D) demb1[(int64_t)b * D + cidx] = from_f<T>(t);
     else demb5[(int64_t)b * D + cidx - D] = from_f<T>(t);
   }
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
     dt[tid] = t;
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0) {  // every column block recomputes the coefficients; only block y==0 stores d_gates
     float g[6], sg = 0.f, ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -556,13 +568,23 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       cgs[j] = g[j] * inv;
-      d_gates[(int64_t)j * B + b] = (dt[j] - dt[6]) * inv + (dprobs ? dprobs[(int64_t)b * 6 + j] : 0.f);
+      if (blockIdx.y == 0) d_gates[(int64_t)j * B + b] = (dt[j] - dt[6]) * inv + (dprobs ? dprobs[(int64_t)b * 6 + j] : 0.f);
     }
   }
   __syncthreads();
-  for (int cidx = tid; cidx < D; cidx += 256) {
-    float t = 0.f;
-    for (int k = 0; k < nchunk; ++k) t += ws_bc[((int64_t)b * nchunk + k) * D + cidx];
+  const int cidx = blockIdx.y * 256 + tid;
+  if (cidx < D) {
+    const float* w = ws_bc + (int64_t)b * nchunk * D + cidx;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nchunk; k += 4) {
+      t0 += w[(int64_t)k * D];
+      t1 += w[(int64_t)(k + 1) * D];
+      t2 += w[(int64_t)(k + 2) * D];
+      t3 += w[(int64_t)(k + 3) * D];
+    }
+    for (; k < nchunk; ++k) t0 += w[(int64_t)k * D];
+    const float t = (t0 + t1) + (t2 + t3);
     demb1[(int64_t)b * D + cidx] = from_f<T>(cgs[1] * t);
     demb5[(int64_t)b * D + cidx] = from_f<T>(cgs[5] * t);
   }
@@ -615,10 +637,10 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     if (shmem < 4 * 36 * sizeof(float)) shmem = 4 * 36 * sizeof(float);
     if (dtype == D2R_BF16) {
       hipLaunchKernelGGL((agg_bwd6_kernel<bf16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, de, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
     } else {
       hipLaunchKernelGGL((agg_bwd6_kernel<float>), grid, block, shmem, st, e, gates, dv, B, L, D, de, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (float*)de.p[1], (float*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (float*)de.p[1], (float*)de.p[5], d_gates);
     }
   } else {
     const void* outp = h_outs[0];
@@ -627,10 +649,10 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     if (shmem < 4 * 8 * sizeof(float)) shmem = 4 * 8 * sizeof(float);
     if (dtype == D2R_BF16) {
       hipLaunchKernelGGL((agg_bwd1_kernel<bf16_t>), grid, block, shmem, st, e, r, gates, (const bf16_t*)dv.p[0], (const bf16_t*)outp, B, L, D, de, dr, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd1_finish_kernel<bf16_t>), dim3(B), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
     } else {
       hipLaunchKernelGGL((agg_bwd1_kernel<float>), grid, block, shmem, st, e, r, gates, (const float*)dv.p[0], (const float*)outp, B, L, D, de, dr, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd1_finish_kernel<float>), dim3(B), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (float*)de.p[1], (float*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<float>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (float*)de.p[1], (float*)de.p[5], d_gates);
     }
   }
   return d2r_check_launch("d2r_route_aggregate_bwd");

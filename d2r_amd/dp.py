@@ -115,7 +115,7 @@ class DataParallel:
     def _install_hooks(self):
         bounds = self.reducer.bounds
         self._count0 = [0] * len(bounds)
-        for name, p, off, k, g in self.store.entries:
+        for p, off, k in self.store.units():
             bi = next(i for i, (a, b) in enumerate(bounds) if a <= off < b)
             # a parameter straddling two buckets belongs to the later one (its tail is reduced there)
             be = next(i for i, (a, b) in enumerate(bounds) if a <= off + k - 1 < b)

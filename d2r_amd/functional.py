@@ -242,68 +242,151 @@ def matmul_nt(a, b):
 # ------------------------------------------------------------------------------------------------------
 # attention: O = softmax(scale * Q K^T + mask) V (+ residual), H heads; logits kept fp32
 # ------------------------------------------------------------------------------------------------------
+def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device):
+    """q, k, v: (data_ptr, row stride, batch stride) in elements of `dtype`; geo = (B, Lq, Lk, E).  Returns (o, P)."""
+    B, Lq, Lk, E = geo
+    d = E // H
+    Lkp = (Lk + 7) // 8 * 8
+    dt = BF16 if dtype == torch.bfloat16 else F32
+    tag = "xattn_core_fwd" if H == 1 else "mha_core_fwd"
+    S = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=device)
+    gemm(GEMM_NT, Lq, Lk, d, q[0], q[1], k[0], k[1], S.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B, nh=H,
+         sA=(q[2], d), sB=(k[2], d), sC=(H * Lq * Lkp, Lq * Lkp), tag=tag)
+    if _lib._timer is not None:  # SURVEY.md 8d: algorithmic bytes of the fused core = B(2Lq+2Lk)D s
+        _lib._timer.records[-1][1]["algo_bytes"] = float(B * (2 * Lq + 2 * Lk) * E * (2 if dt == BF16 else 4))
+    P = S if dtype == torch.float32 else torch.empty(B, H, Lq, Lkp, dtype=dtype, device=device)
+    _lib.call("d2r_softmax_fwd", F32, dt, S.data_ptr(), P.data_ptr(), Lkp, B * H * Lq, Lk, scale, _ptr(mask), H * Lq,
+              _stream(), meta=dict(group=tag))  # padding columns of P are never read (K = Lk below)
+    o = torch.empty(B, Lq, E, dtype=dtype, device=device)
+    gemm(GEMM_NN, Lq, d, Lk, P.data_ptr(), Lkp, v[0], v[1], o.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
+         sA=(H * Lq * Lkp, Lq * Lkp), sB=(v[2], d), sC=(Lq * E, d), residual=_ptr(residual), ldr=E, sR=(Lq * E, d),
+         tag=tag)
+    return o, P
+
+
+def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device):
+    """g: contiguous [B,Lq,E]; q/k/v and dq/dk/dv: (ptr, row stride, batch stride)."""
+    B, Lq, Lk, E = geo
+    d = E // H
+    Lkp = P.shape[-1]
+    dt = BF16 if dtype == torch.bfloat16 else F32
+    tag = "xattn_core_bwd" if H == 1 else "mha_core_bwd"
+    sP, sG = (H * Lq * Lkp, Lq * Lkp), (Lq * E, d)
+    gemm(GEMM_TN, Lk, d, Lq, P.data_ptr(), Lkp, g.data_ptr(), E, dv[0], dv[1], dtype=dt, c_dtype=dt, nb=B, nh=H,
+         sA=sP, sB=sG, sC=(dv[2], d), tag=tag)
+    dP = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=device)
+    gemm(GEMM_NT, Lq, Lk, d, g.data_ptr(), E, v[0], v[1], dP.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B, nh=H,
+         sA=sG, sB=(v[2], d), sC=sP, tag=tag)
+    dS = dP if dtype == torch.float32 else torch.empty(B, H, Lq, Lkp, dtype=dtype, device=device)
+    _lib.call("d2r_softmax_bwd", dt, F32, P.data_ptr(), dP.data_ptr(), dS.data_ptr(), Lkp, B * H * Lq, Lk, scale,
+              _stream(), meta=dict(group=tag))
+    gemm(GEMM_NN, Lq, d, Lk, dS.data_ptr(), Lkp, k[0], k[1], dq[0], dq[1], dtype=dt, c_dtype=dt, nb=B, nh=H,
+         sA=sP, sB=(k[2], d), sC=(dq[2], d), tag=tag)
+    gemm(GEMM_TN, Lk, d, Lq, dS.data_ptr(), Lkp, q[0], q[1], dk[0], dk[1], dtype=dt, c_dtype=dt, nb=B, nh=H,
+         sA=sP, sB=(q[2], d), sC=(dk[2], d), tag=tag)
+
+
+def _desc(t, col0, ncols_total):
+    """(ptr, row stride, batch stride) of the column block starting at col0 of a contiguous [B,L,ncols_total] tensor."""
+    return (t.data_ptr() + col0 * t.element_size(), ncols_total, t.shape[1] * ncols_total)
+
+
 class _Attention(torch.autograd.Function):
+    """separate q [B,Lq,E], k, v [B,Lk,E]"""
+
     @staticmethod
     def forward(ctx, q, k, v, H, scale, mask, residual):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, Lq, E = q.shape
-        Lk = k.shape[1]
-        d = E // H
-        Lkp = (Lk + 7) // 8 * 8
-        dt = _dt(q)
-        tag = "xattn_core_fwd" if H == 1 else "mha_core_fwd"
-        S = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=q.device)
-        gemm(GEMM_NT, Lq, Lk, d, q.data_ptr(), E, k.data_ptr(), E, S.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B, nh=H,
-             sA=(Lq * E, d), sB=(Lk * E, d), sC=(H * Lq * Lkp, Lq * Lkp), tag=tag)
-        if _lib._timer is not None:  # algorithmic bytes of the fused core = B(2Lq+2Lk)D s
-            _lib._timer.records[-1][1]["algo_bytes"] = float(B * (2 * Lq + 2 * Lk) * E * q.element_size())
-        if q.dtype == torch.float32:
-            P = S
-        else:
-            P = torch.empty(B, H, Lq, Lkp, dtype=q.dtype, device=q.device)
-        _lib.call("d2r_softmax_fwd", F32, dt, S.data_ptr(), P.data_ptr(), Lkp, B * H * Lq, Lk, scale, _ptr(mask),
-                  H * Lq, _stream(), meta=dict(group=tag))
-        if Lkp != Lk and q.dtype != torch.float32:
-            pass  # padding columns of P are never read (K = Lk in the GEMMs below)
-        o = torch.empty(B, Lq, E, dtype=q.dtype, device=q.device)
+        geo = (B, Lq, k.shape[1], E)
         if residual is not None:
             residual = residual.contiguous()
-        gemm(GEMM_NN, Lq, d, Lk, P.data_ptr(), Lkp, v.data_ptr(), E, o.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
-             sA=(H * Lq * Lkp, Lq * Lkp), sB=(Lk * E, d), sC=(Lq * E, d), residual=_ptr(residual), ldr=E,
-             sR=(Lq * E, d), tag=tag)
+        o, P = _attn_fwd(_desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), geo, H, scale, mask, residual, q.dtype, q.device)
         ctx.save_for_backward(q, k, v, P)
-        ctx.cfg = (B, Lq, Lk, Lkp, E, H, d, scale, residual is not None)
+        ctx.cfg = (geo, H, scale, residual is not None)
         return o
 
     @staticmethod
     def backward(ctx, g):
         q, k, v, P = ctx.saved_tensors
-        B, Lq, Lk, Lkp, E, H, d, scale, has_res = ctx.cfg
+        geo, H, scale, has_res = ctx.cfg
+        E = geo[3]
         g = g.contiguous()
-        dt = _dt(q)
-        tag = "xattn_core_bwd" if H == 1 else "mha_core_bwd"
-        sP = (H * Lq * Lkp, Lq * Lkp)
-        dv = torch.empty_like(v)
-        gemm(GEMM_TN, Lk, d, Lq, P.data_ptr(), Lkp, g.data_ptr(), E, dv.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
-             sA=sP, sB=(Lq * E, d), sC=(Lk * E, d), tag=tag)
-        dP = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=q.device)
-        gemm(GEMM_NT, Lq, Lk, d, g.data_ptr(), E, v.data_ptr(), E, dP.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B,
-             nh=H, sA=(Lq * E, d), sB=(Lk * E, d), sC=sP, tag=tag)
-        dS = dP if q.dtype == torch.float32 else torch.empty(B, H, Lq, Lkp, dtype=q.dtype, device=q.device)
-        _lib.call("d2r_softmax_bwd", dt, F32, P.data_ptr(), dP.data_ptr(), dS.data_ptr(), Lkp, B * H * Lq, Lk, scale,
-                  _stream(), meta=dict(group=tag))
-        dq = torch.empty_like(q)
-        gemm(GEMM_NN, Lq, d, Lk, dS.data_ptr(), Lkp, k.data_ptr(), E, dq.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
-             sA=sP, sB=(Lk * E, d), sC=(Lq * E, d), tag=tag)
-        dk = torch.empty_like(k)
-        gemm(GEMM_TN, Lk, d, Lq, dS.data_ptr(), Lkp, q.data_ptr(), E, dk.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
-             sA=sP, sB=(Lq * E, d), sC=(Lk * E, d), tag=tag)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _attn_bwd(g, _desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), P, _desc(dq, 0, E), _desc(dk, 0, E), _desc(dv, 0, E),
+                  geo, H, scale, q.dtype, q.device)
         return dq, dk, dv, None, None, None, (g if has_res else None)
+
+
+class _AttentionQKV(torch.autograd.Function):
+    """packed self-attention input qkv [B,L,3E] = one fused projection GEMM (q | k | v along the last dim); the
+    backward writes dq/dk/dv straight into ONE [B,L,3E] gradient (no slice-backward copies, no adds)."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, scale, mask, residual):
+        qkv = qkv.contiguous()
+        B, L, E3 = qkv.shape
+        E = E3 // 3
+        geo = (B, L, L, E)
+        if residual is not None:
+            residual = residual.contiguous()
+        o, P = _attn_fwd(_desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), geo, H, scale, mask, residual,
+                         qkv.dtype, qkv.device)
+        ctx.save_for_backward(qkv, P)
+        ctx.cfg = (geo, H, scale, residual is not None)
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, P = ctx.saved_tensors
+        geo, H, scale, has_res = ctx.cfg
+        E, E3 = geo[3], 3 * geo[3]
+        g = g.contiguous()
+        d = torch.empty_like(qkv)
+        _attn_bwd(g, _desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), P, _desc(d, 0, E3), _desc(d, E, E3),
+                  _desc(d, 2 * E, E3), geo, H, scale, qkv.dtype, qkv.device)
+        return d, None, None, None, (g if has_res else None)
+
+
+class _AttentionKV(torch.autograd.Function):
+    """cross-attention: q [B,Lq,E] and packed kv [B,Lk,2E] (k | v from one fused projection of the other modality)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, H, scale, mask, residual):
+        q, kv = q.contiguous(), kv.contiguous()
+        B, Lq, E = q.shape
+        geo = (B, Lq, kv.shape[1], E)
+        if residual is not None:
+            residual = residual.contiguous()
+        o, P = _attn_fwd(_desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), geo, H, scale, mask, residual, q.dtype,
+                         q.device)
+        ctx.save_for_backward(q, kv, P)
+        ctx.cfg = (geo, H, scale, residual is not None)
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        q, kv, P = ctx.saved_tensors
+        geo, H, scale, has_res = ctx.cfg
+        E = geo[3]
+        g = g.contiguous()
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        _attn_bwd(g, _desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), P, _desc(dq, 0, E), _desc(dkv, 0, 2 * E),
+                  _desc(dkv, E, 2 * E), geo, H, scale, q.dtype, q.device)
+        return dq, dkv, None, None, None, (g if has_res else None)
 
 
 def attention(q, k, v, num_heads, scale, mask=None, residual=None):
     """q [B,Lq,E], k/v [B,Lk,E]; mask: fp32 additive [B,Lk] or None; residual [B,Lq,E] added to the output."""
     return _Attention.apply(q, k, v, num_heads, float(scale), mask, residual)
+
+
+def attention_qkv(qkv, num_heads, scale, mask=None, residual=None):
+    return _AttentionQKV.apply(qkv, num_heads, float(scale), mask, residual)
+
+
+def attention_kv(q, kv, num_heads, scale, mask=None, residual=None):
+    return _AttentionKV.apply(q, kv, num_heads, float(scale), mask, residual)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -42,6 +42,18 @@ class D2RModule(nn.Module):
                 m.cdtype = dtype
         return self
 
+    def fusion_groups(self):
+        """(owner module, [Linear, ...]) groups of same-input projections that ParamStore lays out back to back
+        so that ONE GEMM serves them (q|k|v of every self-attention, k|v of every cross-modal alignment)."""
+        for m in self.modules():
+            members = getattr(m, "_fusion_members", None)
+            if members is not None:
+                yield m, list(members())
+
+    def _fused_linear(self):
+        """The FusedLinear installed by ParamStore, or None on an un-prepared model (then the members run singly)."""
+        return getattr(self, "_fused", None)
+
 
 def _compute_weight(p: nn.Parameter, dtype: torch.dtype) -> torch.Tensor:
     if dtype == torch.float32:
@@ -146,7 +158,13 @@ class CrossModalAlignment(D2RModule):
         self.query, self.key, self.value = Linear(E, E), Linear(E, E), Linear(E, E)
         self.fc_1, self.fc_2 = Linear(E, E), Linear(E, E)
 
+    def _fusion_members(self):
+        return [self.key, self.value]
+
     def forward(self, own, other):
+        fz = self._fused_linear()
+        if fz is not None:
+            return F.attention_kv(self.query(own), fz(other, self.cdtype), 1, 100.0 / math.sqrt(E))
         return F.attention(self.query(own), self.key(other), self.value(other), 1, 100.0 / math.sqrt(E))
 
 
@@ -167,6 +185,9 @@ class AttentionLayer(D2RModule):
         self.h = h
         self.linears = nn.ModuleList([Linear(embed_size, embed_size) for _ in range(3)])
 
+    def _fusion_members(self):
+        return list(self.linears)
+
 
 class FeedForward(D2RModule):
     def __init__(self, embed_size, hidden):
@@ -184,8 +205,13 @@ class SelfAttention(D2RModule):
         self.feed_forward_layer = FeedForward(embed_size, hid_size)
 
     def forward(self, x):
-        q, k, v = (lin(x) for lin in self.att_layer.linears)
-        y = F.attention(q, k, v, self.h, 1.0 / math.sqrt(x.shape[-1] // self.h), residual=x)
+        fz = self.att_layer._fused_linear()
+        scale = 1.0 / math.sqrt(x.shape[-1] // self.h)
+        if fz is not None:
+            y = F.attention_qkv(fz(x, self.cdtype), self.h, scale, residual=x)
+        else:
+            q, k, v = (lin(x) for lin in self.att_layer.linears)
+            y = F.attention(q, k, v, self.h, scale, residual=x)
         return self.feed_forward_layer.fc2(self.feed_forward_layer.fc1(y, act=ACT_RELU), residual=y)
 
 
@@ -411,6 +437,9 @@ class BertSelfAttention(D2RModule):
         self.query, self.key, self.value = (Linear(config.hidden_size, config.hidden_size) for _ in range(3))
         self.p_drop = config.attention_probs_dropout_prob
 
+    def _fusion_members(self):
+        return [self.query, self.key, self.value]
+
 
 class BertSelfOutput(D2RModule):
     def __init__(self, config):
@@ -457,7 +486,11 @@ class BertLayer(D2RModule):
         _check_dropout(sa.p_drop, self.training, "attention_probs_dropout_prob")
         _check_dropout(self.p_hidden, self.training, "hidden_dropout_prob")
         H = sa.num_attention_heads
-        ctx = F.attention(sa.query(x), sa.key(x), sa.value(x), H, 1.0 / math.sqrt(x.shape[-1] // H), mask=key_mask)
+        fz = sa._fused_linear()
+        if fz is not None:
+            ctx = F.attention_qkv(fz(x, self.cdtype), H, 1.0 / math.sqrt(x.shape[-1] // H), mask=key_mask)
+        else:
+            ctx = F.attention(sa.query(x), sa.key(x), sa.value(x), H, 1.0 / math.sqrt(x.shape[-1] // H), mask=key_mask)
         a = self.attention.output.LayerNorm(self.attention.output.dense(ctx, residual=x))
         h = self.intermediate.dense(a, act=ACT_GELU)
         return self.output.LayerNorm(self.output.dense(h, residual=a))
@@ -470,6 +503,9 @@ class CLIPAttention(D2RModule):
         d = config.hidden_size
         self.k_proj, self.v_proj, self.q_proj, self.out_proj = Linear(d, d), Linear(d, d), Linear(d, d), Linear(d, d)
         self.p_drop = config.attention_dropout
+
+    def _fusion_members(self):
+        return [self.q_proj, self.k_proj, self.v_proj]
 
 
 class CLIPMLP(D2RModule):
@@ -496,7 +532,11 @@ class CLIPEncoderLayer(D2RModule):
         _check_dropout(at.p_drop, self.training, "attention_dropout")
         h = self.layer_norm1(x)
         d = x.shape[-1] // at.num_heads
-        ctx = F.attention(at.q_proj(h), at.k_proj(h), at.v_proj(h), at.num_heads, d ** -0.5)
+        fz = at._fused_linear()
+        if fz is not None:
+            ctx = F.attention_qkv(fz(h, self.cdtype), at.num_heads, d ** -0.5)
+        else:
+            ctx = F.attention(at.q_proj(h), at.k_proj(h), at.v_proj(h), at.num_heads, d ** -0.5)
         x = at.out_proj(ctx, residual=x)
         h = self.mlp.fc1(self.layer_norm2(x), act=ACT_QUICK_GELU)
         return self.mlp.fc2(h, residual=x)

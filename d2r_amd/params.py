@@ -42,6 +42,19 @@ def group_of(name: str) -> int:
     return 0
 
 
+class FusedLinear:
+    """Several nn.Linear modules that read the same input, served by ONE GEMM over their back-to-back weights
+    ([sum N, K] view of the flat buffer).  Created by ParamStore for the groups a model lists in fusion_groups()."""
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor):
+        self.weight, self.bias = weight, bias
+
+    def __call__(self, x: torch.Tensor, cdtype: torch.dtype):
+        from . import functional as F
+        wc = self.weight if cdtype == torch.float32 else self.weight._d2r_lp
+        return F.linear(x, self.weight, self.bias, wc)
+
+
 class ParamStore:
     def __init__(self, model: torch.nn.Module, compute_dtype: torch.dtype = torch.float32):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
@@ -57,16 +70,35 @@ class ParamStore:
         for n, p in live:
             if group_of(n) in (1, 2) and "text" in n and "vision" in n:
                 raise ValueError(f"parameter {n!r} would fall into two optimiser groups")
+        # same-input projections (q|k|v, k|v) are laid out back to back so one GEMM serves them (FusedLinear)
+        fusions = list(model.fusion_groups()) if hasattr(model, "fusion_groups") else []
+        first_of, member_ids = {}, set()
+        for owner, linears in fusions:
+            ws, bs = [l.weight for l in linears], [l.bias for l in linears]
+            first_of[id(ws[0])] = ws + bs
+            member_ids.update(id(t) for t in ws + bs)
+        name_of = {id(p): n for n, p in live}
+        ordered = []
+        for n, p in live:
+            if id(p) in first_of:
+                ordered.extend((name_of[id(t)], t) for t in first_of[id(p)])
+            elif id(p) not in member_ids:
+                ordered.append((n, p))
+        assert len(ordered) == len(live), "fusion groups must consist of live parameters of one optimiser group"
         self.entries = []  # (name, param, offset, numel, group)
         off = 0
         self.group_ranges: Dict[int, List[int]] = {}
-        for n, p in live:
+        offset_of = {}
+        for n, p in ordered:
             g = group_of(n)
             if g not in self.group_ranges:
                 self.group_ranges[g] = [off, off]
             self.entries.append((n, p, off, p.numel(), g))
+            offset_of[id(p)] = off
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
             self.group_ranges[g][1] = off
+        for g, (a, b) in self.group_ranges.items():  # groups must be contiguous ranges
+            assert all(a <= o < b for _, _, o, _, gg in self.entries if gg == g)
         self.n = off
         self.flat_w = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
@@ -82,7 +114,32 @@ class ParamStore:
                 p._d2r_lp = None if self.flat_lp is None else self.flat_lp[o:o + k].view(p.shape)
         for n, p in self.dead:
             p.requires_grad_(False)
+        # fused leaves: autograd leaves aliasing the members' storage; their gradient sinks alias the members' grads
+        self.fused = []  # (leaf tensor, offset, numel)
+        for owner, linears in fusions:
+            ws, bs = [l.weight for l in linears], [l.bias for l in linears]
+            K = ws[0].shape[1]
+            nrows = sum(w.shape[0] for w in ws)
+            ow, ob = offset_of[id(ws[0])], offset_of[id(bs[0])]
+            assert all(offset_of[id(w)] == ow + sum(x.numel() for x in ws[:i]) for i, w in enumerate(ws)), "weights not adjacent"
+            assert all(offset_of[id(b)] == ob + sum(x.numel() for x in bs[:i]) for i, b in enumerate(bs)), "biases not adjacent"
+            fw = self.flat_w[ow:ow + nrows * K].view(nrows, K).detach().requires_grad_(True)
+            fb = self.flat_w[ob:ob + nrows].detach().requires_grad_(True)
+            fw._d2r_grad = self.flat_g[ow:ow + nrows * K].view(nrows, K)
+            fw.grad = fw._d2r_grad
+            fb.grad = self.flat_g[ob:ob + nrows]
+            fw._d2r_lp = None if self.flat_lp is None else self.flat_lp[ow:ow + nrows * K].view(nrows, K)
+            owner._fused = FusedLinear(fw, fb)
+            self.fused.append((fw, ow, nrows * K, [id(w) for w in ws]))
+            self.fused.append((fb, ob, nrows, [id(b) for b in bs]))
         self.refresh_lowp()
+
+    def units(self):
+        """(tensor that reports gradient readiness, offset, numel): fused leaves replace their members."""
+        hidden = set(i for _, _, _, ids in self.fused for i in ids)
+        out = [(p, o, k) for _, p, o, k, _ in self.entries if id(p) not in hidden]
+        out.extend((t, o, k) for t, o, k, _ in self.fused)
+        return out
 
     # -- bf16 shadow -------------------------------------------------------------------------------
     def refresh_lowp(self):

@@ -51,7 +51,8 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-variants = [(nbuf, vepi, tile) for nbuf in (1, 2) for vepi in (0, 1) for tile in (-1, 1, 2, 3)]
+# first field: LDS buffers, +256 = XCD-aware tile order OFF; tile 4/5: LDS-DMA pipelined 128x128 / 128x64
+variants = [(1, 1, -1), (257, 1, -1), (1, 1, 1), (257, 1, 1), (1, 1, 3), (257, 1, 3), (1, 1, 5), (257, 1, 5)]
 dtype = torch.bfloat16
 print("variant = (lds_buffers, vector_epilogue, tile[-1 auto,1:64x64,2:128x64,3:128x128]); TFLOP/s")
 for layout, M, N, K in SHAPES:
@@ -62,6 +63,17 @@ for layout, M, N, K in SHAPES:
             lib.d2r_gemm_tuning(*v)
             t = timeit(lambda: run(layout, M, N, K, a, b, c, layout == GEMM_TN))
             res.setdefault(v, []).append(2.0 * M * N * K / t / 1e12)
+    # correctness of the LDS-DMA variants against hipBLASLt on the same data
+    for tile in (4, 5):
+        lib.d2r_gemm_tuning(1, 1, tile)
+        c.zero_()
+        run(layout, M, N, K, a, b, c, False)
+        ref = (a.float() @ b.float().t()) if layout == GEMM_NT else ((a.float() @ b.float()) if layout == GEMM_NN else (a.float().t() @ b.float()))
+        err = float((c.float() - ref).abs().max() / ref.abs().max())
+        if err >= 2e-2:
+            bad = ((c.float() - ref).abs() > 0.05 * ref.abs().max()).nonzero()
+            print(f"  !! glds tile {tile} WRONG on {NAMES[layout]} {M}x{N}x{K}: rel err {err:.3f}; {len(bad)} bad elements, "
+                  f"rows {int(bad[:, 0].min())}..{int(bad[:, 0].max())} cols {int(bad[:, 1].min())}..{int(bad[:, 1].max())}")
     best = max(res, key=lambda v: min(res[v]))
     line = " ".join(f"{v}:{min(r):.0f}" for v, r in res.items())
     # hipBLASLt through torch as a yard-stick (same shapes, same data)
