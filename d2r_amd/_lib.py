@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("residual", vp), ("ldr", i64), ("sRb", i64), ("sRh", i64),
         ("preact", vp),
         ("workspace", vp), ("workspace_bytes", sz),
+        ("s_bias_b", i64),
     ]
 
 

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 16 + fr;
-        const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+        const float bv = (g.bias && col < g.N) ? g.bias[zb * g.sBiasB + col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Cs[(i * 16 + fq * 4 + r) * LDE + j * 16 + fr] = (bf16_t)(g.alpha * acc[i][j][r] + bv);
       }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn0 + j * 16 + fr;
       if (col >= g.N) continue;
-      const float bv = g.bias ? g.bias[col] : 0.f;
+      const float bv = g.bias ? g.bias[zb * g.sBiasB + col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm0 + i * 16 + fq * 4 + r;
@@ -468,7 +468,7 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   a.M = d->M; a.N = d->N; a.K = d->K; a.nh = d->nh;
   a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldr = d->ldr;
   a.sAb = d->sAb; a.sAh = d->sAh; a.sBb = d->sBb; a.sBh = d->sBh;
-  a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh;
+  a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh; a.sBiasB = d->s_bias_b;
   a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype;
   a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd;
   const int64_t es = (int64_t)d2r_esize(d->dtype);

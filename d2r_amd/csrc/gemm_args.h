@@ -17,7 +17,7 @@ struct GemmArgs {
   float* ws;  // split-K partial slabs [splits][M][N] (fp32) or null
   int M, N, K, nh, splits, tiles_per_split;
   int64_t lda, ldb, ldc, ldr;
-  int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh;
+  int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh, sBiasB;
   float alpha, beta;
   int act, c_dtype, vecA, vecB, vecC, xcd;
 };

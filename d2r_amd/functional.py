@@ -93,10 +93,11 @@ def _as_rows(x: torch.Tensor):
 # ------------------------------------------------------------------------------------------------------
 def gemm(layout, M, N, K, A, lda, B, ldb, Cc, ldc, *, dtype, c_dtype, nb=1, nh=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
          alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, residual=None, ldr=0, sR=(0, 0), preact=None, tag=None,
-         splitk_ws=None):
+         splitk_ws=None, s_bias=0):
     d = GemmDesc(dtype=dtype, c_dtype=c_dtype, layout=layout, act=act, M=M, N=N, K=K, nb=nb, nh=nh, alpha=alpha,
                  beta=beta, A=A, lda=lda, sAb=sA[0], sAh=sA[1], B=B, ldb=ldb, sBb=sB[0], sBh=sB[1], C=Cc, ldc=ldc,
                  sCb=sC[0], sCh=sC[1], bias=bias, residual=residual, ldr=ldr, sRb=sR[0], sRh=sR[1], preact=preact)
+    d.s_bias_b = s_bias
     if splitk_ws is not None:  # deterministic split-K scratch (dW GEMMs): fp32 partial slabs
         d.workspace, d.workspace_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
     meta = None
@@ -207,6 +208,61 @@ def linear(x, w_master, bias, w_compute=None, act=ACT_NONE, residual=None, out_d
     """F.linear with fused bias/activation/residual epilogue.  ``w_master`` is the fp32 parameter that receives
     the gradient; ``w_compute`` the (possibly bf16) copy multiplied with."""
     return _Linear.apply(x, w_master, bias, w_master if w_compute is None else w_compute, act, residual, out_dtype)
+
+
+class _GroupedLinear(torch.autograd.Function):
+    """G independent linears as ONE batched GEMM: y[:, g] = act(x_g W_g^T + b_g).
+    x: [B, G*K] (columns grouped) or, with x_gm, group-major [G, B, K]; W: fused [G*N, K]; b: [G*N]; y: [B, G*N].
+    Serves the 20+20 rank-15 merge projections of Block (models/XModules.py:541-546) and the six routers of a
+    routing layer (models/Router.py:24)."""
+
+    @staticmethod
+    def forward(ctx, x, w_master, bias, w_compute, G, act, x_gm):
+        x = x.contiguous()
+        K = w_compute.shape[1]
+        N = w_compute.shape[0] // G
+        B = x.shape[1] if x_gm else x.shape[0]
+        xs = (K, B * K) if x_gm else (G * K, K)  # (row stride, group stride) of x
+        assert x.dtype == w_compute.dtype and act not in _ACT_FROM_PREACT
+        y = torch.empty(B, G * N, dtype=x.dtype, device=x.device)
+        gemm(GEMM_NT, B, N, K, x.data_ptr(), xs[0], w_compute.data_ptr(), K, y.data_ptr(), G * N, dtype=_dt(x),
+             c_dtype=_dt(y), nb=G, sA=(xs[1], 0), sB=(N * K, 0), sC=(N, 0), bias=bias.data_ptr(), act=act, s_bias=N)
+        ctx.save_for_backward(x, w_compute, y if act in _ACT_FROM_OUTPUT else None)
+        ctx.cfg = (B, G, N, K, xs, act, x_gm)
+        ctx.w_master = w_master
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, ref = ctx.saved_tensors
+        B, G, N, K, xs, act, x_gm = ctx.cfg
+        g = g.contiguous()
+        if act != ACT_NONE:
+            gg = torch.empty_like(g)
+            _lib.call("d2r_act_bwd", _dt(g), act, g.data_ptr(), ref.data_ptr(), gg.data_ptr(), g.numel(), _stream())
+            g = gg
+        dx = torch.empty_like(x)
+        gemm(GEMM_NN, B, K, N, g.data_ptr(), G * N, w.data_ptr(), K, dx.data_ptr(), xs[0], dtype=_dt(x), c_dtype=_dt(x),
+             nb=G, sA=(N, 0), sB=(N * K, 0), sC=(xs[1], 0))
+        sink = getattr(ctx.w_master, "_d2r_grad", None)
+        dw = None
+        if sink is not None:
+            tgt, beta = sink, 1.0
+        else:
+            dw = torch.empty(G * N, K, dtype=torch.float32, device=x.device)
+            tgt, beta = dw, 0.0
+        gemm(GEMM_TN, N, K, B, g.data_ptr(), G * N, x.data_ptr(), xs[0], tgt.data_ptr(), K, dtype=_dt(x), c_dtype=F32,
+             nb=G, sA=(N, 0), sB=(xs[1], 0), sC=(N * K, 0), beta=beta)
+        if sink is not None:
+            cb = getattr(ctx.w_master, "_d2r_ready_cb", None)
+            if cb is not None:
+                cb(ctx.w_master)
+        db = colsum(g, B, G * N, G * N)
+        return dx, dw, db, None, None, None, None
+
+
+def grouped_linear(x, w_master, bias, w_compute, G, act=ACT_NONE, x_gm=False):
+    return _GroupedLinear.apply(x, w_master, bias, w_master if w_compute is None else w_compute, G, act, x_gm)
 
 
 class _MatmulNT(torch.autograd.Function):

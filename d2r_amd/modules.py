@@ -48,11 +48,17 @@ class D2RModule(nn.Module):
         for m in self.modules():
             members = getattr(m, "_fusion_members", None)
             if members is not None:
-                yield m, list(members())
+                got = members()
+                if isinstance(got, dict):
+                    for key, linears in got.items():
+                        yield m, key, list(linears)
+                else:
+                    yield m, None, list(got)
 
-    def _fused_linear(self):
+    def _fused_linear(self, key=None):
         """The FusedLinear installed by ParamStore, or None on an un-prepared model (then the members run singly)."""
-        return getattr(self, "_fused", None)
+        d = getattr(self, "_fused", None)
+        return None if d is None else d.get(key)
 
 
 def _compute_weight(p: nn.Parameter, dtype: torch.dtype) -> torch.Tensor:
@@ -343,15 +349,28 @@ class _RoutingLayer(D2RModule):
     def _cells(self):
         return [getattr(self, n) for n in CELL_ORDER]
 
+    def _fusion_members(self):
+        return {"r0": [c.router.mlp[0] for c in self._cells()], "r2": [c.router.mlp[2] for c in self._cells()]}
+
     def _route(self, refs: List[torch.Tensor], other: torch.Tensor):
         cells = self._cells()
-        if self.first_layer:  # six routers read the same tensor: pool once
-            pooled = F.mean_pool([refs[0]])[0]
-            gates = [c.router.gate_from_pooled(pooled) for c in cells]
+        r0, r2 = self._fused_linear("r0"), self._fused_linear("r2")
+        if r0 is not None:  # the six routers as two GEMMs (fp32): hidden [B, 6*hid] then gates [B, 6*P]
+            if self.first_layer:  # all six read the same pooled vector: one plain GEMM, N = 6*hid
+                h = r0(F.mean_pool([refs[0]])[0], torch.float32, act=ACT_RELU)
+            else:
+                h = r0.grouped(F.mean_pool(refs), torch.float32, act=ACT_RELU, x_gm=True)
+            gb = r2.grouped(h, torch.float32, act=ACT_TANH_RELU)  # [B, 6*P]
+            B = gb.shape[0]
+            G = gb.view(B, 6, self.num_out_path).transpose(0, 1).contiguous()  # [6,B,P] (tiny copy)
         else:
-            pooled = F.mean_pool(refs)  # [6,B,768] in one launch
-            gates = [c.router.gate_from_pooled(pooled[j]) for j, c in enumerate(cells)]
-        G = torch.stack(gates, dim=0)  # fp32 [6,B,P]
+            if self.first_layer:  # six routers read the same tensor: pool once
+                pooled = F.mean_pool([refs[0]])[0]
+                gates = [c.router.gate_from_pooled(pooled) for c in cells]
+            else:
+                pooled = F.mean_pool(refs)  # [6,B,768] in one launch
+                gates = [c.router.gate_from_pooled(pooled[j]) for j, c in enumerate(cells)]
+            G = torch.stack(gates, dim=0)  # fp32 [6,B,P]
         embs = [c(refs[j], other) for j, c in enumerate(cells)]
         if self.num_out_path == 1:
             probs, outs = F.route_aggregate(G, *embs, refs=refs[1:])
@@ -630,9 +649,16 @@ class Block(D2RModule):
         square root has an unbounded derivative at 0, which would amplify bf16 rounding into every gradient."""
         x0, x1 = self.linear0(x[0], fp32=True), self.linear1(x[1], fp32=True)
         s = self.size
-        m0 = torch.stack([self.merge_linears0[c](x0[:, c * s:(c + 1) * s], fp32=True) for c in range(self.chunks)], dim=1)
-        m1 = torch.stack([self.merge_linears1[c](x1[:, c * s:(c + 1) * s], fp32=True) for c in range(self.chunks)], dim=1)
+        f0, f1 = self._fused_linear("m0"), self._fused_linear("m1")
+        if f0 is not None:  # 20 chunk projections = one batched GEMM each
+            m0, m1 = f0.grouped(x0, torch.float32), f1.grouped(x1, torch.float32)
+        else:
+            m0 = torch.stack([self.merge_linears0[c](x0[:, c * s:(c + 1) * s], fp32=True) for c in range(self.chunks)], dim=1)
+            m1 = torch.stack([self.merge_linears1[c](x1[:, c * s:(c + 1) * s], fp32=True) for c in range(self.chunks)], dim=1)
         return self.linear_out(F.block_merge(m0, m1, self.chunks, self.rank, s), fp32=True)
+
+    def _fusion_members(self):
+        return {"m0": list(self.merge_linears0), "m1": list(self.merge_linears1)}
 
 
 class UnimoModel(D2RModule):

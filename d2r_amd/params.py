@@ -46,13 +46,21 @@ class FusedLinear:
     """Several nn.Linear modules that read the same input, served by ONE GEMM over their back-to-back weights
     ([sum N, K] view of the flat buffer).  Created by ParamStore for the groups a model lists in fusion_groups()."""
 
-    def __init__(self, weight: torch.Tensor, bias: torch.Tensor):
-        self.weight, self.bias = weight, bias
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, n_members: int):
+        self.weight, self.bias, self.n = weight, bias, n_members
 
-    def __call__(self, x: torch.Tensor, cdtype: torch.dtype):
+    def _wc(self, cdtype):
+        return self.weight if cdtype == torch.float32 else self.weight._d2r_lp
+
+    def __call__(self, x: torch.Tensor, cdtype: torch.dtype, act: int = 0):
+        """Every member reads the SAME x: one GEMM with N = sum of the members' outputs."""
         from . import functional as F
-        wc = self.weight if cdtype == torch.float32 else self.weight._d2r_lp
-        return F.linear(x, self.weight, self.bias, wc)
+        return F.linear(x, self.weight, self.bias, self._wc(cdtype), act)
+
+    def grouped(self, x: torch.Tensor, cdtype: torch.dtype, act: int = 0, x_gm: bool = False):
+        """Member g reads ITS OWN slice of x ([B, G*K] columns or group-major [G, B, K]): one batched GEMM."""
+        from . import functional as F
+        return F.grouped_linear(x, self.weight, self.bias, self._wc(cdtype), self.n, act, x_gm)
 
 
 class ParamStore:
@@ -72,11 +80,12 @@ class ParamStore:
                 raise ValueError(f"parameter {n!r} would fall into two optimiser groups")
         # same-input projections (q|k|v, k|v) are laid out back to back so one GEMM serves them (FusedLinear)
         fusions = list(model.fusion_groups()) if hasattr(model, "fusion_groups") else []
-        first_of, member_ids = {}, set()
-        for owner, linears in fusions:
+        first_of, member_ids, tight = {}, set(), set()
+        for owner, key, linears in fusions:
             ws, bs = [l.weight for l in linears], [l.bias for l in linears]
             first_of[id(ws[0])] = ws + bs
             member_ids.update(id(t) for t in ws + bs)
+            tight.update(id(t) for t in ws[:-1] + bs[:-1])  # members are packed without alignment padding
         name_of = {id(p): n for n, p in live}
         ordered = []
         for n, p in live:
@@ -95,8 +104,8 @@ class ParamStore:
                 self.group_ranges[g] = [off, off]
             self.entries.append((n, p, off, p.numel(), g))
             offset_of[id(p)] = off
-            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-            self.group_ranges[g][1] = off
+            off = off + p.numel() if id(p) in tight else (off + p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.group_ranges[g][1] = (off + ALIGN - 1) // ALIGN * ALIGN
         for g, (a, b) in self.group_ranges.items():  # groups must be contiguous ranges
             assert all(a <= o < b for _, _, o, _, gg in self.entries if gg == g)
         self.n = off
@@ -116,7 +125,7 @@ class ParamStore:
             p.requires_grad_(False)
         # fused leaves: autograd leaves aliasing the members' storage; their gradient sinks alias the members' grads
         self.fused = []  # (leaf tensor, offset, numel)
-        for owner, linears in fusions:
+        for owner, key, linears in fusions:
             ws, bs = [l.weight for l in linears], [l.bias for l in linears]
             K = ws[0].shape[1]
             nrows = sum(w.shape[0] for w in ws)
@@ -129,7 +138,9 @@ class ParamStore:
             fw.grad = fw._d2r_grad
             fb.grad = self.flat_g[ob:ob + nrows]
             fw._d2r_lp = None if self.flat_lp is None else self.flat_lp[ow:ow + nrows * K].view(nrows, K)
-            owner._fused = FusedLinear(fw, fb)
+            if not isinstance(getattr(owner, "_fused", None), dict):
+                owner._fused = {}
+            owner._fused[key] = FusedLinear(fw, fb, len(linears))
             self.fused.append((fw, ow, nrows * K, [id(w) for w in ws]))
             self.fused.append((fb, ob, nrows, [id(b) for b in bs]))
         self.refresh_lowp()

@@ -67,7 +67,7 @@ const char* d2r_last_error(void);
  *   epilogue(v) = act(v + bias[n]) + residual[m,n]     (then  C = v + beta*C_old  when beta != 0)
  * `preact` (optional) receives v + bias before the activation (needed by GELU backward).
  * All leading dimensions / strides are in ELEMENTS.  A and B have dtype `dtype`; C/residual/preact have
- * `c_dtype`.  bias is fp32 [N] or NULL.
+ * `c_dtype`.  bias is fp32 [N] (row b*s_bias_b for batch b) or NULL.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
   int dtype;      /* d2r_dtype of A and B */
@@ -86,6 +86,7 @@ typedef struct {
   /* optional scratch for deterministic split-K (GEMMs with few output tiles and a long reduction: weight
    * gradients, M<=32 router/pooler products); used only when batch == 1.  NULL disables split-K. */
   void* workspace; size_t workspace_bytes;
+  int64_t s_bias_b;  /* bias stride per outer batch index b (grouped linears: one bias row per group); 0 = shared */
 } d2r_gemm_desc;
 
 int d2r_gemm(const d2r_gemm_desc* d, void* stream);
