@@ -76,11 +76,12 @@ SIGNATURES = {
     "d2r_block_merge_fwd": (i32, [i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "d2r_block_merge_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "d2r_bert_embed_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
-    "d2r_bert_embed_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i64, vp, vp, vp, vp]),
+    "d2r_bert_embed_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i64, vp, vp, vp, vp]),
     "d2r_patchify": (i32, [i32, vp, i32, i32, i32, i32, vp, vp]),
     "d2r_clip_embed_finish": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
     "d2r_clip_embed_bwd": (i32, [i32, vp, i32, i32, i32, vp, vp, vp]),
     "d2r_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
+    "d2r_adamw_step_dev": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]),
 }
 
 

@@ -221,7 +221,14 @@ extern "C" int d2r_cast(int src_dtype, const void* src, int dst_dtype, void* dst
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ w16, int64_t n, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                                                    const float* __restrict__ d_hyper) {
+  if (d_hyper) {  // hipGraph-safe variant: per-step scalars live in device memory, refreshed before each replay
+    lr = d_hyper[0];
+    bc1 = d_hyper[1];
+    bc2_sqrt = d_hyper[2];
+    gscale = d_hyper[3];
+  }
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   const int64_t n4 = n / 4;
@@ -263,11 +270,26 @@ extern "C" int d2r_adamw_step(float* w, const float* g, float* m, float* v, void
   D2R_REQUIRE(d2r_aligned16(w) && d2r_aligned16(g) && d2r_aligned16(m) && d2r_aligned16(v), "d2r_adamw_step: pointers must be 16-byte aligned");
   D2R_REQUIRE(!w_bf16 || (reinterpret_cast<uintptr_t>(w_bf16) & 7u) == 0, "d2r_adamw_step: bf16 shadow must be 8-byte aligned");
   if (n == 0) return D2R_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  // double on the host, rounded once: FusedAdamW.stage_hyper (the hipGraph path) computes the very same values
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   int blocks = (int)((n / 4 + 256) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (bf16_t*)w_bf16, n, lr,
-                     beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+                     beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, (const float*)nullptr);
   return d2r_check_launch("d2r_adamw_step");
+}
+
+// hipGraph-capturable form: d_hyper = device float[4] {lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale}
+extern "C" int d2r_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w_bf16, int64_t n,
+                                  const float* d_hyper, float beta1, float beta2, float eps, float weight_decay,
+                                  void* stream) {
+  D2R_REQUIRE(w && g && m && v && d_hyper && n >= 0, "d2r_adamw_step_dev: bad arguments");
+  D2R_REQUIRE(d2r_aligned16(w) && d2r_aligned16(g) && d2r_aligned16(m) && d2r_aligned16(v), "d2r_adamw_step_dev: pointers must be 16-byte aligned");
+  if (n == 0) return D2R_OK;
+  int blocks = (int)((n / 4 + 256) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (bf16_t*)w_bf16, n, 0.f,
+                     beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.f, d_hyper);
+  return d2r_check_launch("d2r_adamw_step_dev");
 }

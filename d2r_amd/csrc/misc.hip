@@ -357,31 +357,89 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int64_t* __re
   }
 }
 
-// word/type tables: fp32 atomics (rows are hit by few tokens); position table: fixed-order sum over the batch
+// Deterministic gradients of the three tables (no float atomics: run-to-run bit-identical, so data-parallel replicas
+// and hipGraph replays agree exactly).
+// word table: the FIRST token carrying an id (its "leader") sums the dY rows of every token with that id in token
+// order and adds the result to the table row; all other tokens with that id do nothing.
 template <typename T>
-__global__ __launch_bounds__(256) void bert_embed_bwd_scatter_kernel(const T* __restrict__ dY, const int64_t* __restrict__ ids,
-                                                                     const int64_t* __restrict__ tt, int B, int L, int D,
-                                                                     int64_t pad_id, float* __restrict__ dword,
-                                                                     float* __restrict__ dtype_tab) {
+__global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const T* __restrict__ dY, const int64_t* __restrict__ ids,
+                                                                  int64_t ntok, int D, int64_t pad_id,
+                                                                  float* __restrict__ dword) {
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= (int64_t)B * L) return;
-  const int64_t id = ids[tok], ty = tt[tok];
-  for (int c = lane; c < D; c += 64) {
-    const float g = to_f<T>(dY[tok * D + c]);
-    if (id != pad_id) atomicAdd(dword + id * D + c, g);
-    atomicAdd(dtype_tab + ty * D + c, g);
+  if (tok >= ntok) return;
+  const int64_t id = ids[tok];
+  if (id == pad_id) return;
+  for (int64_t j0 = 0; j0 < tok; j0 += 64) {  // leader test (wave-uniform exit)
+    const int64_t j = j0 + lane;
+    if (__ballot(j < tok && ids[j] == id)) return;
+  }
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+  for (int64_t j0 = tok & ~(int64_t)63; j0 < ntok; j0 += 64) {
+    const int64_t j = j0 + lane;
+    uint64_t hits = __ballot(j >= tok && j < ntok && ids[j] == id);
+    while (hits) {
+      const int b = __builtin_ctzll(hits);
+      hits &= hits - 1;
+      const T* row = dY + (j0 + b) * D;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < D) {
+          const Pack<T, 4> v = ld_pack<T, 4>(row + c);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[i][k] += to_f<T>(v.v[k]);
+        }
+      }
+    }
+  }
+  float* dst = dword + id * D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < D) {
+      Pack<float, 4> o = ld_pack<float, 4>(dst + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o.v[k] += acc[i][k];
+      st_pack<float, 4>(dst + c, o);
+    }
   }
 }
+// type table: grid (cdiv(D,64), ntype); wave w of 16 sums tokens w, w+16, ... of its type in order, the 16 partials
+// are combined in wave order.
 template <typename T>
+__global__ __launch_bounds__(1024) void bert_embed_bwd_type_kernel(const T* __restrict__ dY, const int64_t* __restrict__ tt,
+                                                                   int64_t ntok, int D, float* __restrict__ dtype_tab) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t ty = blockIdx.y;
+  float s = 0.f;
+  if (c < D)
+    for (int64_t t = w; t < ntok; t += 16)
+      if (tt[t] == ty) s += to_f<T>(dY[t * D + c]);
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < D) {
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += part[i][lane];
+    dtype_tab[ty * D + c] += r;
+  }
+}
+template <typename T, bool ACC>
 __global__ __launch_bounds__(256) void batch_sum_rows_kernel(const T* __restrict__ dY, int B, int L, int D,
                                                              float* __restrict__ dst) {
-  // dst[l, c] = sum_b dY[b, l, c]
+  // dst[l, c] (+)= sum_b dY[b, l, c]
   const int l = blockIdx.x;
   for (int c = threadIdx.x; c < D; c += 256) {
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += to_f<T>(dY[((int64_t)b * L + l) * D + c]);
-    dst[(int64_t)l * D + c] = s;
+    dst[(int64_t)l * D + c] = ACC ? dst[(int64_t)l * D + c] + s : s;
   }
 }
 
@@ -399,21 +457,24 @@ extern "C" int d2r_bert_embed_fwd(int dtype, const int64_t* ids, const int64_t* 
   return d2r_check_launch("d2r_bert_embed_fwd");
 }
 
+template <typename T>
+static void launch_bert_embed_bwd(const void* dY, const int64_t* ids, const int64_t* tt, int B, int L, int D, int ntype,
+                                  int64_t pad_id, float* dword, float* dpos, float* dtype_tab, hipStream_t st) {
+  const int64_t ntok = (int64_t)B * L;
+  hipLaunchKernelGGL((bert_embed_bwd_word_kernel<T>), dim3(d2r_cdiv(ntok, 4)), dim3(256), 0, st, (const T*)dY, ids, ntok, D, pad_id, dword);
+  hipLaunchKernelGGL((bert_embed_bwd_type_kernel<T>), dim3(d2r_cdiv(D, 64), ntype), dim3(1024), 0, st, (const T*)dY, tt, ntok, D, dtype_tab);
+  hipLaunchKernelGGL((batch_sum_rows_kernel<T, true>), dim3(L), dim3(256), 0, st, (const T*)dY, B, L, D, dpos);
+}
+
 extern "C" int d2r_bert_embed_bwd(int dtype, const void* dY, const int64_t* ids, const int64_t* tt, int B, int L, int D,
-                                  int64_t pad_id, float* dword, float* dpos, float* dtype_tab, void* stream) {
+                                  int ntype, int64_t pad_id, float* dword, float* dpos, float* dtype_tab, void* stream) {
   D2R_REQUIRE(dY && ids && tt && dword && dpos && dtype_tab, "d2r_bert_embed_bwd: null pointer");
-  D2R_REQUIRE(B >= 1 && L >= 1 && D >= 1, "d2r_bert_embed_bwd: bad shape");
-  dim3 grid(d2r_cdiv((int64_t)B * L, 4)), block(256);
+  D2R_REQUIRE(B >= 1 && L >= 1 && D >= 4 && D % 4 == 0 && D <= 1024 && ntype >= 1, "d2r_bert_embed_bwd: bad shape (D % 4 == 0, D <= 1024)");
+  D2R_REQUIRE(d2r_aligned16(dword) && (reinterpret_cast<uintptr_t>(dY) & 7u) == 0, "d2r_bert_embed_bwd: dword must be 16-byte, dY 8-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == D2R_BF16) {
-    hipLaunchKernelGGL((bert_embed_bwd_scatter_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dY, ids, tt, B, L, D, pad_id, dword, dtype_tab);
-    hipLaunchKernelGGL((batch_sum_rows_kernel<bf16_t>), dim3(L), block, 0, st, (const bf16_t*)dY, B, L, D, dpos);
-  } else if (dtype == D2R_F32) {
-    hipLaunchKernelGGL((bert_embed_bwd_scatter_kernel<float>), grid, block, 0, st, (const float*)dY, ids, tt, B, L, D, pad_id, dword, dtype_tab);
-    hipLaunchKernelGGL((batch_sum_rows_kernel<float>), dim3(L), block, 0, st, (const float*)dY, B, L, D, dpos);
-  } else {
-    return d2r_fail(D2R_ERR_INVALID, "d2r_bert_embed_bwd: bad dtype %d", dtype);
-  }
+  if (dtype == D2R_BF16) launch_bert_embed_bwd<bf16_t>(dY, ids, tt, B, L, D, ntype, pad_id, dword, dpos, dtype_tab, st);
+  else if (dtype == D2R_F32) launch_bert_embed_bwd<float>(dY, ids, tt, B, L, D, ntype, pad_id, dword, dpos, dtype_tab, st);
+  else return d2r_fail(D2R_ERR_INVALID, "d2r_bert_embed_bwd: bad dtype %d", dtype);
   return d2r_check_launch("d2r_bert_embed_bwd");
 }
 
@@ -473,8 +534,8 @@ extern "C" int d2r_clip_embed_bwd(int dtype, const void* dX, int B, int ntok, in
                                   void* stream) {
   D2R_REQUIRE(dX && dcls && dpos && B >= 1 && ntok >= 1 && D >= 1, "d2r_clip_embed_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == D2R_BF16) hipLaunchKernelGGL((batch_sum_rows_kernel<bf16_t>), dim3(ntok), dim3(256), 0, st, (const bf16_t*)dX, B, ntok, D, dpos);
-  else if (dtype == D2R_F32) hipLaunchKernelGGL((batch_sum_rows_kernel<float>), dim3(ntok), dim3(256), 0, st, (const float*)dX, B, ntok, D, dpos);
+  if (dtype == D2R_BF16) hipLaunchKernelGGL((batch_sum_rows_kernel<bf16_t, false>), dim3(ntok), dim3(256), 0, st, (const bf16_t*)dX, B, ntok, D, dpos);
+  else if (dtype == D2R_F32) hipLaunchKernelGGL((batch_sum_rows_kernel<float, false>), dim3(ntok), dim3(256), 0, st, (const float*)dX, B, ntok, D, dpos);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_clip_embed_bwd: bad dtype %d", dtype);
   hipLaunchKernelGGL(copy_row_kernel, dim3(d2r_cdiv(D, 256)), dim3(256), 0, st, (const float*)dpos, dcls, D);  // dcls = dpos[0]
   return d2r_check_launch("d2r_clip_embed_bwd");

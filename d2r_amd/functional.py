@@ -137,6 +137,25 @@ class _Cast(torch.autograd.Function):
         return cast(g.contiguous(), ctx.src), None
 
 
+class _StreamJoin(torch.autograd.Function):
+    """Identity on a pair of tensors, issued on the launching stream at a fork/join point of the two-stream
+    forward.  Its only job is to give the BACKWARD the same join-then-fork shape: the gradients coming from the two
+    side streams are accumulated at this node (on the launching stream) before they flow on to the two encoders, so
+    autograd never makes the side streams wait on each other directly (that pattern breaks hipGraph capture)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return a.view_as(a), b.view_as(b)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return ga, gb
+
+
+def stream_join(a, b):
+    return _StreamJoin.apply(a, b)
+
+
 def cast_ad(x, dtype):
     return x if x.dtype == dtype else _Cast.apply(x, dtype)
 
@@ -907,7 +926,7 @@ class _BertEmbed(torch.autograd.Function):
         _lib.call("d2r_bert_embed_fwd", _dt(out), ids.data_ptr(), tt.data_ptr(), word.data_ptr(), pos.data_ptr(),
                   typ.data_ptr(), B, L, D, word.shape[0], typ.shape[0], out.data_ptr(), _stream())
         ctx.save_for_backward(ids, tt)
-        ctx.shapes = (word.shape, pos.shape, typ.shape)
+        ctx.tables = (word, pos, typ)
         return out
 
     @staticmethod
@@ -915,13 +934,21 @@ class _BertEmbed(torch.autograd.Function):
         ids, tt = ctx.saved_tensors
         g = g.contiguous()
         B, L, D = g.shape
-        ws, ps, ts = ctx.shapes
-        dword = torch.zeros(ws, dtype=torch.float32, device=g.device)
-        dpos = torch.zeros(ps, dtype=torch.float32, device=g.device)
-        dtyp = torch.zeros(ts, dtype=torch.float32, device=g.device)
-        _lib.call("d2r_bert_embed_bwd", _dt(g), g.data_ptr(), ids.data_ptr(), tt.data_ptr(), B, L, D, 0,
-                  dword.data_ptr(), dpos.data_ptr(), dtyp.data_ptr(), _stream())
-        return None, None, dword, dpos, dtyp, None
+        tables = ctx.tables
+        sinks = [getattr(t, "_d2r_grad", None) for t in tables]
+        if all(s is not None for s in sinks):  # accumulate straight into the flat gradient buffer (no 94 MB temp)
+            outs, ret = sinks, (None, None, None)
+        else:
+            outs = [torch.zeros(t.shape, dtype=torch.float32, device=g.device) for t in tables]
+            ret = tuple(outs)
+        _lib.call("d2r_bert_embed_bwd", _dt(g), g.data_ptr(), ids.data_ptr(), tt.data_ptr(), B, L, D, tables[2].shape[0],
+                  0, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
+        if ret[0] is None:
+            for t in tables:
+                cb = getattr(t, "_d2r_ready_cb", None)
+                if cb is not None:
+                    cb(t)
+        return (None, None) + ret + (None,)
 
 
 def bert_embed(ids, tt, word, pos, typ, dtype):

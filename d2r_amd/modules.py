@@ -17,7 +17,9 @@ Reference map (file:line under the reference tree):
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -622,13 +624,19 @@ class UnimoEncoder(D2RModule):
         self.vision_layers = nn.ModuleList([CLIPEncoderLayer(vision_config) for _ in range(vision_config.num_hidden_layers)])
         self.text_layer = nn.ModuleList([BertLayer(text_config) for _ in range(text_config.num_hidden_layers)])
 
-    def forward(self, vision_embeds, text_embeds, key_mask):
-        v, t = vision_embeds, text_embeds
+    def run_vision(self, v):
         for layer in self.vision_layers:
             v = layer(v)
+        return v
+
+    def run_text(self, t, key_mask):
         for layer in self.text_layer:
             t = layer(t, key_mask)
-        return t, v
+        return t
+
+    def forward(self, vision_embeds, text_embeds, key_mask):
+        """12 vision layers then 12 text layers, no cross-talk (models/modeling_unimo.py:682-712)."""
+        return self.run_text(text_embeds, key_mask), self.run_vision(vision_embeds)
 
 
 class Block(D2RModule):
@@ -682,6 +690,8 @@ class UnimoModel(D2RModule):
         self.Reversed_itr_module = Reversed_InteractionModule(args, num_layer_routing=args.DR_step, num_cells=6,
                                                               path_hid=128)
         self.text_pooler = BertPooler() if add_pooling_layer else None  # dead (ingest assert needs it)
+        self.use_streams = os.environ.get("D2R_STREAMS", "1") != "0"
+        self._streams = None
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, pixel_values=None):
         """-> (pooler_output [B,768], js_loss, aux) — models/modeling_unimo.py:786-894."""
@@ -691,23 +701,62 @@ class UnimoModel(D2RModule):
             raise ValueError("token_type_ids is None!")  # models/modeling_unimo.py:808-809
         # additive key mask (1-m)*-10000 (:58-59): tiny integer->float plumbing on [B,L]
         key_mask = ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
-        v = self.vision_pre_layrnorm(self.vision_embeddings(pixel_values))
-        t = self.text_embeddings(input_ids, token_type_ids)
-        t_enc, v_enc = self.encoder(v, t, key_mask)
-        t_out = t_enc
-        for layer in self.self_text:
-            t_out = layer(t_out, key_mask)
-        t_cls = self.text_cls_pool(t_out, fp32=True)
-        v_out = v_enc
-        for layer in self.self_vision:
-            v_out = layer(v_out)
-        v_cls = self.vision_cls_pool(v_out, fp32=True)
-        (emb_t,), sim_paths = self.itr_module(t_enc, v_enc)
-        (emb_v,), rev_sim_paths = self.Reversed_itr_module(t_enc, v_enc)
-        js1 = F.js_div(sim_paths, F.matmul_nt(t_cls, t_cls))
-        js2 = F.js_div(rev_sim_paths, F.matmul_nt(v_cls, v_cls))
+        # The vision and text halves are independent until the routing modules, and the two routing branches are
+        # independent of each other: run them on two HIP streams so their (individually small, <= 600-workgroup)
+        # kernels overlap and fill the 256 CUs.  Autograd replays each backward op on its forward stream.  With
+        # use_streams off the same ops are issued in the same order on the launching stream (bit-identical results).
+        two = self.use_streams and pixel_values.is_cuda
+        if two:
+            main = torch.cuda.current_stream()
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            sT, sV = self._streams
+            on_t, on_v = (lambda: torch.cuda.stream(sT)), (lambda: torch.cuda.stream(sV))
+            for x in (input_ids, token_type_ids, key_mask):
+                x.record_stream(sT)
+            pixel_values.record_stream(sV)
+            sT.wait_stream(main)
+            sV.wait_stream(main)
+        else:
+            on_t = on_v = contextlib.nullcontext
+        with on_v():
+            v_enc = self.encoder.run_vision(self.vision_pre_layrnorm(self.vision_embeddings(pixel_values)))
+        with on_t():
+            t_enc = self.encoder.run_text(self.text_embeddings(input_ids, token_type_ids), key_mask)
+        if two:
+            # barrier through the launching stream, then fork again (a direct sT<->sV cross wait is legal HIP but
+            # crashes hipStreamEndCapture on ROCm 7.2 when the step is being captured into a hipGraph)
+            v_enc.record_stream(sT)
+            t_enc.record_stream(sV)
+            main.wait_stream(sT)
+            main.wait_stream(sV)
+        t_enc, v_enc = F.stream_join(t_enc, v_enc)
+        if two:
+            sT.wait_stream(main)
+            sV.wait_stream(main)
+        with on_t():
+            t_out = t_enc
+            for layer in self.self_text:
+                t_out = layer(t_out, key_mask)
+            t_cls = self.text_cls_pool(t_out, fp32=True)
+            (emb_t,), sim_paths = self.itr_module(t_enc, v_enc)
+            js1 = F.js_div(sim_paths, F.matmul_nt(t_cls, t_cls))
+            tp = self.text_pool(emb_t, fp32=True)
+        with on_v():
+            v_out = v_enc
+            for layer in self.self_vision:
+                v_out = layer(v_out)
+            v_cls = self.vision_cls_pool(v_out, fp32=True)
+            (emb_v,), rev_sim_paths = self.Reversed_itr_module(t_enc, v_enc)
+            js2 = F.js_div(rev_sim_paths, F.matmul_nt(v_cls, v_cls))
+            vp_ = self.vision_pool(emb_v, fp32=True)
+        if two:
+            main.wait_stream(sT)
+            main.wait_stream(sV)
+            for x in (js1, js2, tp, vp_, emb_t, emb_v, sim_paths, rev_sim_paths, t_enc, v_enc):
+                x.record_stream(main)
         js_loss = F.lincomb([-self.args.weight_js_1, -self.args.weight_js_2], [js1, js2])
-        pooled = self.block_fusion([self.text_pool(emb_t, fp32=True), self.vision_pool(emb_v, fp32=True)])
+        pooled = self.block_fusion([tp, vp_])
         aux = dict(emb_text=emb_t, emb_image=emb_v, sim_paths=sim_paths, rev_sim_paths=rev_sim_paths,
                    text_encode_out=t_enc, vision_encode_out=v_enc)
         return pooled, js_loss, aux

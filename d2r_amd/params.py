@@ -12,6 +12,7 @@ reference stay outside the store and are never updated nor all-reduced (AdamW sk
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, List, Optional
 
 import torch
@@ -183,6 +184,8 @@ class FusedAdamW:
             base = fc_lr if g == 3 else lr
             self.param_groups.append(dict(name=names[g], range=(a, b), lr=base, initial_lr=base,
                                           weight_decay=weight_decay))
+        if store.flat_w.is_cuda:  # created eagerly, not inside a stream capture
+            self._hyper_buffers()
 
     def zero_grad(self, set_to_none: bool = False):
         self.store.zero_grad()
@@ -198,6 +201,39 @@ class FusedAdamW:
             _lib.call("d2r_adamw_step", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
                       self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, b - a, pg["lr"], self.betas[0],
                       self.betas[1], self.eps, pg["weight_decay"], self.step_count, self.grad_scale, _stream())
+
+    # -- hipGraph-capturable stepping: per-step scalars come from a device array ------------------------
+    def _hyper_buffers(self):
+        if not hasattr(self, "_hyper_dev"):
+            n = len(self.param_groups)
+            self._hyper_cpu = torch.zeros(n, 4, dtype=torch.float32)  # pageable on purpose, see stage_hyper
+            self._hyper_dev = torch.zeros(n, 4, dtype=torch.float32, device=self.store.flat_w.device)
+        return self._hyper_cpu, self._hyper_dev
+
+    def stage_hyper(self):
+        """Call BEFORE replaying a captured step: advances the step count and uploads {lr, bias corrections,
+        grad_scale} of every group (one small async H2D copy on the current stream)."""
+        self.step_count += 1
+        cpu, dev = self._hyper_buffers()
+        b1, b2 = (float(torch.tensor(b, dtype=torch.float32)) for b in self.betas)  # the f32 values the kernel sees
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2s = math.sqrt(1.0 - b2 ** self.step_count)
+        for i, pg in enumerate(self.param_groups):
+            cpu[i, 0], cpu[i, 1], cpu[i, 2], cpu[i, 3] = pg["lr"], bc1, bc2s, self.grad_scale
+        dev.copy_(cpu)  # pageable source: the runtime stages it before returning, so `cpu` may be rewritten at once
+
+    def step_captured(self):
+        """The launches recorded into a hipGraph (no host-side scalars)."""
+        st = self.store
+        _, dev = self._hyper_buffers()
+        for i, pg in enumerate(self.param_groups):
+            a, b = pg["range"]
+            if b <= a:
+                continue
+            lp = None if st.flat_lp is None else st.flat_lp.data_ptr() + 2 * a
+            _lib.call("d2r_adamw_step_dev", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
+                      self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, b - a, dev.data_ptr() + 16 * i,
+                      self.betas[0], self.betas[1], self.eps, pg["weight_decay"], _stream())
 
     def state_dict(self):
         return dict(m=self.m, v=self.v, step=self.step_count, lrs=[pg["lr"] for pg in self.param_groups])

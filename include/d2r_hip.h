@@ -221,10 +221,12 @@ int d2r_block_merge_bwd(int dtype, const void* m0, const void* m1, const float* 
 /* out[b,l,:] = word[ids[b,l]] + pos[l] + type[tt[b,l]]   (tables fp32, out dtype T; LayerNorm separately) */
 int d2r_bert_embed_fwd(int dtype, const int64_t* ids, const int64_t* tt, const float* word, const float* pos,
                        const float* type, int B, int L, int D, int vocab, int ntype, void* out, void* stream);
-/* scatter-add (fp32 atomics) of dY into dword/dtype tables (pre-zeroed by caller), dpos[l] = sum_b dY[b,l];
- * rows with ids == pad_id get no gradient (padding_idx, models/modeling_unimo.py:277). */
+/* Gradients of the three tables, ACCUMULATED (+=) into dword [vocab,D], dpos [>=L,D], dtype_tab [ntype,D] (fp32, so
+ * they may be the flat gradient buffer itself): dword[id] += sum of dY rows of the tokens carrying id, dtype_tab
+ * likewise per token type, dpos[l] += sum_b dY[b,l].  Deterministic (fixed summation order, no float atomics).
+ * Rows with ids == pad_id get no gradient (padding_idx, models/modeling_unimo.py:277).  D % 4 == 0, D <= 1024. */
 int d2r_bert_embed_bwd(int dtype, const void* dY, const int64_t* ids, const int64_t* tt, int B, int L, int D,
-                       int64_t pad_id, float* dword, float* dpos, float* dtype_tab, void* stream);
+                       int ntype, int64_t pad_id, float* dword, float* dpos, float* dtype_tab, void* stream);
 /* im2col for the stride=kernel patch conv: pixels fp32 [B,3,H,W] -> patches T [B*(H/p)*(W/p), 3*p*p] */
 int d2r_patchify(int dtype, const float* pixels, int B, int H, int W, int p, void* patches, void* stream);
 /* x[b,0,:] = cls + pos[0]; x[b,1+i,:] = patch_emb[b,i,:] + pos[1+i]  (in place on x [B,1+np,D], rows 1.. already
@@ -242,6 +244,10 @@ int d2r_clip_embed_bwd(int dtype, const void* dX, int B, int ntok, int D, float*
 int d2r_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16 /*or NULL*/, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                    void* stream);
+/* hipGraph-capturable form: the per-step scalars {lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale} are read from the
+ * device array d_hyper[4], which the host refreshes before every graph replay. */
+int d2r_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w_bf16 /*or NULL*/, int64_t n,
+                       const float* d_hyper, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

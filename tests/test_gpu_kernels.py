@@ -287,11 +287,12 @@ def test_block_merge(gpu, dtype):
 @pytest.mark.parametrize("dtype", DT)
 def test_embeddings(gpu, dtype):
     from d2r_amd import functional as F
-    B, L, D = 3, 9, 768
+    B, L, D = 5, 37, 768  # 185 tokens over 50 ids: duplicates within and across the 64-token scan chunks
     ids = torch.randint(0, 50, (B, L))
     ids[0, 5:] = 0
+    ids[:, 0] = 7
     tt = torch.randint(0, 2, (B, L))
-    word, pos, typ = keep32(rnd(50, D)), keep32(rnd(16, D, seed=1)), keep32(rnd(2, D, seed=2))
+    word, pos, typ = keep32(rnd(50, D)), keep32(rnd(40, D, seed=1)), keep32(rnd(2, D, seed=2))
 
     def ref(word, pos, typ):
         return torch.nn.functional.embedding(ids, word, padding_idx=0) + typ[tt] + pos[:L][None]

@@ -110,3 +110,66 @@ def test_cli_smoke(gpu, tmp_path):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Test Eval results" in r.stderr and os.path.exists(os.path.join(str(tmp_path), "best_model.pth"))
+
+
+def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4):
+    from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
+    model, args = _tiny(torch.bfloat16)
+    model.load_state_dict(sd, strict=True)
+    model.to(gpu).train()
+    model.model.use_streams = use_streams
+    store = ParamStore(model, torch.bfloat16)
+    opt = FusedAdamW(store, lr=1e-3)
+    sched = LinearWarmupSchedule(opt, 2, 10)
+    losses = []
+    if not use_graph:
+        for _ in range(n):
+            loss, _ = model(*batch)
+            loss.backward()
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+    else:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm caches/workspaces; no optimiser step, so the weights are untouched
+            loss, _ = model(*batch)
+            loss.backward()
+            opt.zero_grad()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, _ = model(*batch)
+            loss.backward()
+            opt.step_captured()
+            opt.zero_grad()
+        for _ in range(n):
+            opt.stage_hyper()
+            g.replay()
+            sched.step()
+            losses.append(float(loss))
+    torch.cuda.synchronize()
+    return losses, store.flat_w.clone(), opt.m.clone(), opt.v.clone(), [(n, o, k) for n, _, o, k, _ in store.entries]
+
+
+def test_streams_and_graph_replay_are_bit_identical_to_single_stream_eager(gpu):
+    """The two-stream forward/backward, and fwd+bwd+AdamW+zero_grad replayed from one hipGraph (device-side
+    hyper-parameters, d2r_adamw_step_dev), must give exactly the weights of single-stream eager launches: same kernels,
+    same operands, deterministic reductions - only the launch mechanism differs."""
+    from oracle import d2r_oracle as O
+    cfg = O.OracleConfig(text_layers=1, vision_layers=1, image_size=64, patch_size=32)
+    sd = O.seeded_state_dict(cfg, seed=5, router_bias="normal")
+    batch = tuple(t.to(gpu) for t in O.synthetic_batch(cfg, 4, 12, seed=9))
+    base = _run_steps(gpu, sd, batch, use_graph=False, use_streams=False)
+    assert base[0][-1] != base[0][0]
+    for use_graph, use_streams in ((False, False), (False, True), (True, False), (True, True)):
+        got = _run_steps(gpu, sd, batch, use_graph, use_streams)
+        tag = f"graph={use_graph} streams={use_streams}"
+        assert got[0] == base[0], (tag, got[0], base[0])
+        for what, a, b in zip(("w", "m", "v"), got[1:4], base[1:4]):
+            if not torch.equal(a, b):
+                bad = (a != b).nonzero().flatten()
+                names = sorted({n for n, o, k in got[4] if ((bad >= o) & (bad < o + k)).any()})
+                raise AssertionError(f"{tag}: {what} differs in {bad.numel()} elements of {names[:12]} ({len(names)} tensors)")
