@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -322,6 +323,9 @@ def matmul_nt(a, b):
 # ------------------------------------------------------------------------------------------------------
 # attention: O = softmax(scale * Q K^T + mask) V (+ residual), H heads; logits kept fp32
 # ------------------------------------------------------------------------------------------------------
+FUSED_MHA = os.environ.get("D2R_FUSED_MHA", "1") != "0"  # 0: three-launch path (the only one for fp32)
+
+
 def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device):
     """q, k, v: (data_ptr, row stride, batch stride) in elements of `dtype`; geo = (B, Lq, Lk, E).  Returns (o, P)."""
     B, Lq, Lk, E = geo
@@ -329,6 +333,14 @@ def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device):
     Lkp = (Lk + 7) // 8 * 8
     dt = BF16 if dtype == torch.bfloat16 else F32
     tag = "xattn_core_fwd" if H == 1 else "mha_core_fwd"
+    if FUSED_MHA and H > 1 and _lib.load().d2r_mha_supported(dt, Lq, Lk, d):
+        # one launch, scores/probabilities stay in registers; the saved state is the row log-sum-exp, not P
+        o = torch.empty(B, Lq, E, dtype=dtype, device=device)
+        lse = torch.empty(B, H, Lq, dtype=torch.float32, device=device)
+        _lib.call("d2r_mha_fwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], o.data_ptr(), E, Lq * E,
+                  _ptr(residual), E, Lq * E, _ptr(mask), lse.data_ptr(), B, H, Lq, Lk, d, scale, _stream(),
+                  meta=dict(group=tag, algo_bytes=float(B * (2 * Lq + 2 * Lk) * E * 2)))
+        return o, lse
     S = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=device)
     gemm(GEMM_NT, Lq, Lk, d, q[0], q[1], k[0], k[1], S.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B, nh=H,
          sA=(q[2], d), sB=(k[2], d), sC=(H * Lq * Lkp, Lq * Lkp), tag=tag)
@@ -344,13 +356,19 @@ def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device):
     return o, P
 
 
-def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device):
-    """g: contiguous [B,Lq,E]; q/k/v and dq/dk/dv: (ptr, row stride, batch stride)."""
+def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None):
+    """g: contiguous [B,Lq,E]; q/k/v and dq/dk/dv: (ptr, row stride, batch stride).  P: probabilities [B,H,Lq,Lkp]
+    of the unfused forward, or the fp32 log-sum-exp [B,H,Lq] of the fused one."""
     B, Lq, Lk, E = geo
     d = E // H
-    Lkp = P.shape[-1]
     dt = BF16 if dtype == torch.bfloat16 else F32
     tag = "xattn_core_bwd" if H == 1 else "mha_core_bwd"
+    if P.dim() == 3:  # fused forward ran: recompute P from q, k and the log-sum-exp
+        _lib.call("d2r_mha_bwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], g.data_ptr(), E, Lq * E,
+                  _ptr(mask), P.data_ptr(), dq[0], dq[1], dq[2], dk[0], dk[1], dk[2], dv[0], dv[1], dv[2], B, H, Lq, Lk,
+                  d, scale, _stream(), meta=dict(group=tag, algo_bytes=float(2 * B * (2 * Lq + 2 * Lk) * E * 2)))
+        return
+    Lkp = P.shape[-1]
     sP, sG = (H * Lq * Lkp, Lq * Lkp), (Lq * E, d)
     gemm(GEMM_TN, Lk, d, Lq, P.data_ptr(), Lkp, g.data_ptr(), E, dv[0], dv[1], dtype=dt, c_dtype=dt, nb=B, nh=H,
          sA=sP, sB=sG, sC=(dv[2], d), tag=tag)
@@ -383,6 +401,7 @@ class _Attention(torch.autograd.Function):
             residual = residual.contiguous()
         o, P = _attn_fwd(_desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), geo, H, scale, mask, residual, q.dtype, q.device)
         ctx.save_for_backward(q, k, v, P)
+        ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
         return o
 
@@ -394,7 +413,7 @@ class _Attention(torch.autograd.Function):
         g = g.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         _attn_bwd(g, _desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), P, _desc(dq, 0, E), _desc(dk, 0, E), _desc(dv, 0, E),
-                  geo, H, scale, q.dtype, q.device)
+                  geo, H, scale, q.dtype, q.device, ctx.mask)
         return dq, dk, dv, None, None, None, (g if has_res else None)
 
 
@@ -413,6 +432,7 @@ class _AttentionQKV(torch.autograd.Function):
         o, P = _attn_fwd(_desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), geo, H, scale, mask, residual,
                          qkv.dtype, qkv.device)
         ctx.save_for_backward(qkv, P)
+        ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
         return o
 
@@ -424,7 +444,7 @@ class _AttentionQKV(torch.autograd.Function):
         g = g.contiguous()
         d = torch.empty_like(qkv)
         _attn_bwd(g, _desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), P, _desc(d, 0, E3), _desc(d, E, E3),
-                  _desc(d, 2 * E, E3), geo, H, scale, qkv.dtype, qkv.device)
+                  _desc(d, 2 * E, E3), geo, H, scale, qkv.dtype, qkv.device, ctx.mask)
         return d, None, None, None, (g if has_res else None)
 
 
@@ -441,6 +461,7 @@ class _AttentionKV(torch.autograd.Function):
         o, P = _attn_fwd(_desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), geo, H, scale, mask, residual, q.dtype,
                          q.device)
         ctx.save_for_backward(q, kv, P)
+        ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
         return o
 
@@ -452,7 +473,7 @@ class _AttentionKV(torch.autograd.Function):
         g = g.contiguous()
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         _attn_bwd(g, _desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), P, _desc(dq, 0, E), _desc(dkv, 0, 2 * E),
-                  _desc(dkv, E, 2 * E), geo, H, scale, q.dtype, q.device)
+                  _desc(dkv, E, 2 * E), geo, H, scale, q.dtype, q.device, ctx.mask)
         return dq, dkv, None, None, None, (g if has_res else None)
 
 

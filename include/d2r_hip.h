@@ -216,6 +216,26 @@ int d2r_block_merge_bwd(int dtype, const void* m0, const void* m1, const float* 
                         int C, int R, int S, void* dm0, void* dm1, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K3 fused multi-head attention core, short sequences (bf16, head_dim 64 or 48, Lq, Lk <= 256)
+ *   O[b,:,h] = softmax(scale * Q_h K_h^T + mask[b]) V_h (+ residual)
+ * Replaces BertSelfAttention scores/softmax/context (models/modeling_unimo.py:385-424), CLIPAttention (:150-215)
+ * and the 16-head attention of models/SelfAttention.py:20-60 — scores and probabilities never reach HBM.
+ * q/k/v/o/residual/dO/dq/dk/dv: bf16 [B, L, *] views given as (pointer to column 0 of head 0, row stride,
+ * batch stride) in elements; head h occupies columns [h*head_dim, (h+1)*head_dim).  mask: fp32 additive [B,Lk] or
+ * NULL.  lse: fp32 [B,H,Lq] row log-sum-exp written by fwd and read by bwd.  Pointers 16-byte aligned, strides
+ * multiples of 8 elements.  Deterministic.
+ * ------------------------------------------------------------------------------------------------ */
+int d2r_mha_supported(int dtype, int Lq, int Lk, int head_dim);
+int d2r_mha_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
+                const void* v, int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual,
+                int64_t ldr, int64_t srb, const float* mask, float* lse, int B, int H, int Lq, int Lk, int head_dim,
+                float scale, void* stream);
+int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
+                const void* v, int64_t ldv, int64_t svb, const void* dO, int64_t ldg, int64_t sgb, const float* mask,
+                const float* lse, void* dq, int64_t lddq, int64_t sdqb, void* dk, int64_t lddk, int64_t sdkb, void* dv,
+                int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk, int head_dim, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K12 embeddings (models/modeling_unimo.py:87-118, 272-331)
  * ------------------------------------------------------------------------------------------------ */
 /* out[b,l,:] = word[ids[b,l]] + pos[l] + type[tt[b,l]]   (tables fp32, out dtype T; LayerNorm separately) */

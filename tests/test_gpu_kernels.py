@@ -114,7 +114,9 @@ def test_linear_fp32_out(gpu, dtype):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cfg", [(2, 8, 8, 4, 0.3, False, False), (3, 16, 5, 1, 100 / math.sqrt(768), False, True),
-                                 (2, 197, 197, 12, 0.125, True, False), (2, 40, 40, 16, 1 / math.sqrt(48), False, True)])
+                                 (2, 197, 197, 12, 0.125, True, False), (2, 40, 40, 16, 1 / math.sqrt(48), False, True),
+                                 (2, 128, 128, 12, 0.125, True, False), (2, 70, 250, 12, 0.125, True, True),
+                                 (2, 197, 197, 16, 1 / math.sqrt(48), False, True)])
 def test_attention(gpu, dtype, cfg):
     from d2r_amd import functional as F
     B, Lq, Lk, H, scale, use_mask, use_res = cfg
@@ -139,6 +141,34 @@ def test_attention(gpu, dtype, cfg):
         return o + res if use_res else o + 0 * res
 
     run_both(f, r, [q, k, v, res], dtype, gpu, wrt=[0, 1, 2] + ([3] if use_res else []), name=f"attention{cfg}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", [(2, 128, 12, True), (2, 197, 12, False), (2, 37, 16, False)])
+def test_attention_packed_qkv_and_kv(gpu, dtype, cfg):
+    """The packed layouts the fused projections produce: qkv [B,L,3E] (self-attention) and q + kv [B,Lk,2E]; gradients
+    land in one packed tensor."""
+    from d2r_amd import functional as F
+    B, L, H, use_mask = cfg
+    E, d = 768, 768 // H
+    scale = 1 / math.sqrt(d)
+    qkv = rnd(B, L, 3 * E, scale=0.5)
+    mask = torch.zeros(B, L)
+    if use_mask:
+        mask[0, L // 3:] = -10000.0
+
+    def ref_core(q, k, v):
+        qh, kh, vh = (t.reshape(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+        s = scale * qh @ kh.transpose(-1, -2)
+        if use_mask:
+            s = s + mask.double()[:, None, None, :]
+        return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, -1, E)
+
+    run_both(lambda x: F.attention_qkv(x, H, scale, mask=mask.to(gpu) if use_mask else None),
+             lambda x: ref_core(x[..., :E], x[..., E:2 * E], x[..., 2 * E:]), [qkv], dtype, gpu, name=f"attention_qkv{cfg}")
+    q, kv = rnd(B, L + 5, E, scale=0.5, seed=4), rnd(B, L, 2 * E, scale=0.5, seed=5)
+    run_both(lambda q, kv: F.attention_kv(q, kv, H, scale, mask=mask.to(gpu) if use_mask else None),
+             lambda q, kv: ref_core(q, kv[..., :E], kv[..., E:]), [q, kv], dtype, gpu, name=f"attention_kv{cfg}")
 
 
 @pytest.mark.parametrize("dtype", DT)
