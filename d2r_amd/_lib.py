@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("preact", vp),
         ("workspace", vp), ("workspace_bytes", sz),
         ("s_bias_b", i64),
+        ("dbias", vp),
     ]
 
 

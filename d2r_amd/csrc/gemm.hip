@@ -144,6 +144,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient of a linear layer inside its weight-gradient GEMM (TN): the workgroups of the first tile column
+  // also multiply their A fragments with an all-ones B fragment -> acc_b[i][r] = sum_k A[k, row] in every column
+  const bool do_bias = (LAYOUT == D2R_GEMM_TN) && g.dbias != nullptr && tile_n == 0;
+  f32x4 acc_b[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) acc_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   const int fr = lane & 15, fq = lane >> 4;
   const int tq = (lane & 15) >> 2, tp = lane & 3;  // transpose-read address roles inside a 16-lane group
   const int nk_all = (g.K + BK - 1) / BK;
@@ -203,6 +210,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if constexpr (LAYOUT == D2R_GEMM_TN) {
+          if (do_bias) {
+            const bf16_t one = (bf16_t)1.f;
+            const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc_b[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_b[i], 0, 0, 0);
+          }
+        }
       }
     } else {
 #pragma unroll
@@ -218,6 +233,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if constexpr (LAYOUT == D2R_GEMM_TN) {
+          if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc_b[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], 1.f, acc_b[i], 0, 0, 0);
+          }
+        }
       }
     }
     if constexpr (NBUF == 2) {
@@ -232,6 +253,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 
   // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg -------------
+  if constexpr (LAYOUT == D2R_GEMM_TN) {
+    if (do_bias && (wave % WAVES_N) == 0 && fr == 0) {  // one wave per row band, one lane per 4 rows
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm0 + i * 16 + fq * 4 + r;
+          if (row >= g.M) continue;
+          if (g.splits > 1) g.ws[(int64_t)g.splits * g.M * g.N + (int64_t)split * g.M + row] = acc_b[i][r];
+          else g.dbias[row] += acc_b[i][r];  // this workgroup is the only writer of the row
+        }
+    }
+  }
   if (g.splits > 1) {  // raw fp32 partial slab; the reduce kernel applies alpha/beta
     float* slab = g.ws + (int64_t)split * g.M * g.N;
 #pragma unroll
@@ -332,6 +366,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // C[m,n] = epilogue(alpha * sum_s ws[s][m][n])   (fixed order over s; same epilogue as the main kernel)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   const int64_t total = (int64_t)g.M * g.N;
+  if (g.dbias) {
+    const float* wb = g.ws + (int64_t)g.splits * total;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < g.M; m += (int64_t)gridDim.x * 256) {
+      float s = 0.f;
+      for (int k = 0; k < g.splits; ++k) s += wb[(int64_t)k * g.M + m];
+      g.dbias[m] += s;
+    }
+  }
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     float s = 0.f;
     for (int k = 0; k < g.splits; ++k) s += g.ws[(int64_t)k * total + idx];
@@ -381,7 +423,8 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     int bn = 0;
     if (g_tile == 4) bn = 128;
     else if (g_tile == 5) bn = 64;
-    else if (g_tile < 0 && g_glds && a.K >= 2048) bn = t64 >= 256 ? 64 : 0;  // measured: only the K=3072 shapes win
+    else if (g_tile < 0 && g_glds && a.K >= 2048 && !a.dbias) bn = t64 >= 256 ? 64 : 0;  // measured: only the K=3072 shapes win
+    if (a.dbias) bn = 0;  // the bias-gradient side product lives in the generic kernel
     if (bn) {
       GemmArgs b = a;
       b.ws = nullptr; b.splits = 1; b.tiles_per_split = 0;
@@ -413,7 +456,7 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
       int want = (int)((512 + tiles - 1) / tiles);
       if (want > 16) want = 16;
       if (want > nk / 2) want = nk / 2;
-      while (want > 1 && (size_t)want * a.M * a.N * sizeof(float) > ws_bytes) --want;
+      while (want > 1 && (size_t)want * ((size_t)a.M * a.N + (a.dbias ? a.M : 0)) * sizeof(float) > ws_bytes) --want;
       if (want > 1) {
         a.tiles_per_split = d2r_cdiv(nk, want);
         a.splits = d2r_cdiv(nk, a.tiles_per_split);
@@ -471,6 +514,8 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh; a.sBiasB = d->s_bias_b;
   a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype;
   a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd;
+  D2R_REQUIRE(!d->dbias || (d->layout == D2R_GEMM_TN && d->nb * d->nh == 1), "d2r_gemm: dbias needs the TN layout and batch 1");
+  a.dbias = d->dbias;
   const int64_t es = (int64_t)d2r_esize(d->dtype);
   auto vec_ok = [&](const void* p, int64_t ld, int64_t sb, int64_t sh) {
     return d2r_aligned16(p) && (ld * es) % 16 == 0 && (sb * es) % 16 == 0 && (sh * es) % 16 == 0;

@@ -14,7 +14,8 @@ struct GemmArgs {
   const float* bias;
   const void* R;
   void* P;
-  float* ws;  // split-K partial slabs [splits][M][N] (fp32) or null
+  float* ws;  // split-K partial slabs [splits][M][N] (fp32), then [splits][M] bias-gradient partials; or null
+  float* dbias;  // TN only: dbias[m] += sum_k A[k,m]
   int M, N, K, nh, splits, tiles_per_split;
   int64_t lda, ldb, ldc, ldr;
   int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh, sBiasB;

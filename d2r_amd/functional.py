@@ -99,11 +99,12 @@ def _as_rows(x: torch.Tensor):
 # ------------------------------------------------------------------------------------------------------
 def gemm(layout, M, N, K, A, lda, B, ldb, Cc, ldc, *, dtype, c_dtype, nb=1, nh=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
          alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, residual=None, ldr=0, sR=(0, 0), preact=None, tag=None,
-         splitk_ws=None, s_bias=0):
+         splitk_ws=None, s_bias=0, dbias=None):
     d = GemmDesc(dtype=dtype, c_dtype=c_dtype, layout=layout, act=act, M=M, N=N, K=K, nb=nb, nh=nh, alpha=alpha,
                  beta=beta, A=A, lda=lda, sAb=sA[0], sAh=sA[1], B=B, ldb=ldb, sBb=sB[0], sBh=sB[1], C=Cc, ldc=ldc,
                  sCb=sC[0], sCh=sC[1], bias=bias, residual=residual, ldr=ldr, sRb=sR[0], sRh=sR[1], preact=preact)
     d.s_bias_b = s_bias
+    d.dbias = dbias
     if splitk_ws is not None:  # deterministic split-K scratch (dW GEMMs): fp32 partial slabs
         d.workspace, d.workspace_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
     meta = None
@@ -191,6 +192,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, w_compute, pre if pre is not None else (y if act in _ACT_FROM_OUTPUT else None))
         ctx.w_needs = w_master.requires_grad
         ctx.w_master = w_master
+        ctx.bias = bias
         return y
 
     @staticmethod
@@ -211,20 +213,33 @@ class _Linear(torch.autograd.Function):
             gemm(GEMM_NN, M, K, N, g.data_ptr(), N, w.data_ptr(), K, dxc.data_ptr(), K, dtype=_dt(x), c_dtype=_dt(x),
                  splitk_ws=_workspace(64 << 20, x.device) if M <= 64 else None)
             dx = dxc.view(*x.shape[:-1], K) if x.dim() != 2 else dxc
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        db_ptr = None
+        if want_db and ctx.w_needs:  # bias gradient = column sums of g: a side product of the dW GEMM below
+            bsink = getattr(ctx.bias, "_d2r_grad", None)
+            if bsink is None:
+                db = torch.zeros(N, dtype=torch.float32, device=x.device)
+                db_ptr = db.data_ptr()
+            else:
+                db_ptr = bsink.data_ptr()
         if ctx.w_needs:
             sink = getattr(ctx.w_master, "_d2r_grad", None)  # flat fp32 gradient buffer (d2r_amd.params.ParamStore)
             if sink is not None:
                 # dW accumulates straight into the zero-initialised flat buffer: no temp, no autograd add kernel
                 gemm(GEMM_TN, N, K, M, g.data_ptr(), N, x.data_ptr(), lda, sink.data_ptr(), K, dtype=_dt(x),
-                     c_dtype=F32, beta=1.0, splitk_ws=_workspace(64 << 20, x.device))
+                     c_dtype=F32, beta=1.0, splitk_ws=_workspace(64 << 20, x.device), dbias=db_ptr)
                 cb = getattr(ctx.w_master, "_d2r_ready_cb", None)  # data-parallel bucket readiness (d2r_amd.dp)
                 if cb is not None:
                     cb(ctx.w_master)
             else:
                 dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
                 gemm(GEMM_TN, N, K, M, g.data_ptr(), N, x.data_ptr(), lda, dw.data_ptr(), K, dtype=_dt(x), c_dtype=F32,
-                     splitk_ws=_workspace(64 << 20, x.device))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                     splitk_ws=_workspace(64 << 20, x.device), dbias=db_ptr)
+            if want_db and db is None:
+                cb = getattr(ctx.bias, "_d2r_ready_cb", None)
+                if cb is not None:
+                    cb(ctx.bias)
+        elif want_db:
             db = colsum(g, M, N, N)
         return dx, dw, db, None, None, gres, None
 

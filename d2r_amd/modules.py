@@ -330,10 +330,6 @@ class ContextRichCrossModalCell(D2RModule):
 # ------------------------------------------------------------------------------------------------------
 # routing layers
 # ------------------------------------------------------------------------------------------------------
-CELL_STREAMS = int(os.environ.get("D2R_CELL_STREAMS", "0"))  # extra streams per routing branch for its cells
-_CELL_STREAM_POOL = {}
-
-
 class _RoutingLayer(D2RModule):
     """One DynamicInteraction layer; ``swap`` selects the reversed (image-branch) variant."""
 
@@ -377,43 +373,12 @@ class _RoutingLayer(D2RModule):
                 pooled = F.mean_pool(refs)  # [6,B,768] in one launch
                 gates = [c.router.gate_from_pooled(pooled[j]) for j, c in enumerate(cells)]
             G = torch.stack(gates, dim=0)  # fp32 [6,B,P]
-        embs = self._run_cells(cells, refs, other)
+        embs = [c(refs[j], other) for j, c in enumerate(cells)]
         if self.num_out_path == 1:
             probs, outs = F.route_aggregate(G, *embs, refs=refs[1:])
         else:
             probs, outs = F.route_aggregate(G, *embs)
         return outs, probs
-
-
-    @staticmethod
-    def _run_cells(cells, refs, other):
-        """The six cells of a layer read the same inputs and are independent: spread them over CELL_STREAMS extra HIP
-        streams forked from / joined to the launching stream (same ops, same order, bit-identical results; each
-        cell's kernels are far too small to fill 256 CUs alone)."""
-        n_extra = CELL_STREAMS if other.is_cuda else 0
-        if n_extra <= 0:
-            return [c(refs[j], other) for j, c in enumerate(cells)]
-        cur = torch.cuda.current_stream()
-        pool = _CELL_STREAM_POOL.setdefault(cur.cuda_stream, [])
-        while len(pool) < n_extra:
-            pool.append(torch.cuda.Stream())
-        for st in pool[:n_extra]:
-            st.wait_stream(cur)
-        embs, k = [], 0
-        for j, c in enumerate(cells):
-            if isinstance(c, RectifiedIdentityCell):  # a single relu: stays on the launching stream
-                embs.append(c(refs[j], other))
-                continue
-            slot = k % (n_extra + 1)
-            k += 1
-            if slot == n_extra:
-                embs.append(c(refs[j], other))
-            else:
-                with torch.cuda.stream(pool[slot]):
-                    embs.append(c(refs[j], other))
-        for st in pool[:n_extra]:
-            cur.wait_stream(st)
-        return embs
 
 
 class DynamicInteraction_Layer0(_RoutingLayer):

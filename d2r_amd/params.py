@@ -138,6 +138,7 @@ class ParamStore:
             fw._d2r_grad = self.flat_g[ow:ow + nrows * K].view(nrows, K)
             fw.grad = fw._d2r_grad
             fb.grad = self.flat_g[ob:ob + nrows]
+            fb._d2r_grad = fb.grad
             fw._d2r_lp = None if self.flat_lp is None else self.flat_lp[ow:ow + nrows * K].view(nrows, K)
             if not isinstance(getattr(owner, "_fused", None), dict):
                 owner._fused = {}

@@ -87,6 +87,10 @@ typedef struct {
    * gradients, M<=32 router/pooler products); used only when batch == 1.  NULL disables split-K. */
   void* workspace; size_t workspace_bytes;
   int64_t s_bias_b;  /* bias stride per outer batch index b (grouped linears: one bias row per group); 0 = shared */
+  /* TN layout, batch == 1 only: dbias[m] += sum_k A[k,m] (fp32 [M], ACCUMULATED) — the bias gradient of a linear
+   * layer computed inside its weight-gradient GEMM (dW = dY^T X reads dY anyway), replacing a separate column-sum
+   * launch.  NULL disables. */
+  float* dbias;
 } d2r_gemm_desc;
 
 int d2r_gemm(const d2r_gemm_desc* d, void* stream);

@@ -113,13 +113,11 @@ def test_cli_smoke(gpu, tmp_path):
 
 
 def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4):
-    from d2r_amd import modules as M
     from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
     model, args = _tiny(torch.bfloat16)
     model.load_state_dict(sd, strict=True)
     model.to(gpu).train()
     model.model.use_streams = use_streams
-    saved_cell_streams, M.CELL_STREAMS = M.CELL_STREAMS, (2 if use_streams else 0)
     store = ParamStore(model, torch.bfloat16)
     opt = FusedAdamW(store, lr=1e-3)
     sched = LinearWarmupSchedule(opt, 2, 10)
@@ -153,7 +151,6 @@ def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4):
             sched.step()
             losses.append(float(loss))
     torch.cuda.synchronize()
-    M.CELL_STREAMS = saved_cell_streams
     return losses, store.flat_w.clone(), opt.m.clone(), opt.v.clone(), [(n, o, k) for n, _, o, k, _ in store.entries]
 
 
