@@ -35,6 +35,16 @@ class GemmDesc(C.Structure):
     ]
 
 
+class EncoderLayerDesc(C.Structure):
+    _fields_ = ([("dtype", i32), ("pre_ln", i32), ("act", i32), ("B", i32), ("L", i32), ("E", i32), ("H", i32), ("F", i32),
+                 ("eps", f32), ("scale", f32), ("mask", vp)]
+                + [(n, vp) for n in ("w_qkv", "w_o", "w_1", "w_2", "b_qkv", "b_o", "b_1", "b_2", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                                     "gw_qkv", "gw_o", "gw_1", "gw_2", "gb_qkv", "gb_o", "gb_1", "gb_2", "gln1_g", "gln1_b",
+                                     "gln2_g", "gln2_b", "x", "y", "qkv", "ctx", "h1", "n1", "f_pre", "f", "h2", "lse",
+                                     "mean1", "rstd1", "mean2", "rstd2", "dy", "dx", "scratch")]
+                + [("scratch_bytes", sz), ("splitk_ws", vp), ("splitk_bytes", sz)])
+
+
 # name -> (restype, argtypes); every symbol include/d2r_hip.h declares
 SIGNATURES = {
     "d2r_version": (C.c_char_p, []),
@@ -51,6 +61,10 @@ SIGNATURES = {
     "d2r_layernorm_fwd": (i32, [i32, vp, vp, vp, f32, i64, i32, vp, vp, vp, vp]),
     "d2r_layernorm_bwd_workspace": (sz, [i64, i32]),
     "d2r_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "d2r_layernorm_bwd_ex": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "d2r_encoder_layer_bwd_scratch": (sz, [i32, i32, i32, i32]),
+    "d2r_encoder_layer_fwd": (i32, [C.POINTER(EncoderLayerDesc), vp]),
+    "d2r_encoder_layer_bwd": (i32, [C.POINTER(EncoderLayerDesc), vp]),
     "d2r_l2norm_fwd": (i32, [i32, vp, vp, vp, i64, i32, vp]),
     "d2r_l2norm_bwd": (i32, [i32, vp, vp, vp, vp, i64, i32, vp]),
     "d2r_act_bwd": (i32, [i32, i32, vp, vp, vp, i64, vp]),

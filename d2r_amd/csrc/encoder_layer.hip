@@ -1,0 +1,143 @@
+// encoder_layer.hip — one transformer encoder layer (forward, or backward) per C call.
+//
+// Replaces (reference file:line): BertLayer.forward (models/modeling_unimo.py:473-512, post-LayerNorm, GELU) and
+// CLIPEncoderLayer.forward (:222-268, pre-LayerNorm, quick_gelu) and their autograd backward.  The kernels are the
+// ones the single-op entry points launch (d2r_gemm, d2r_mha_*, d2r_layernorm_*, d2r_act_bwd), in the same order;
+// what this file removes is the host work between them: the 7 forward / ~16 backward launches of a layer are
+// issued from C++ in one call instead of one Python autograd node and one ctypes call each, skip-connection
+// gradients ride in GEMM / LayerNorm epilogues instead of separate add kernels, and every parameter gradient is
+// accumulated straight into the caller's fp32 sinks.
+#include "common.h"
+
+namespace {
+
+struct Gemm {
+  d2r_gemm_desc d;
+  Gemm(int dtype, int layout, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+       int64_t ldc, int c_dtype) {
+    memset(&d, 0, sizeof(d));
+    d.dtype = dtype, d.c_dtype = c_dtype, d.layout = layout, d.act = D2R_ACT_NONE;
+    d.M = M, d.N = N, d.K = K, d.nb = 1, d.nh = 1, d.alpha = 1.f, d.beta = 0.f;
+    d.A = A, d.lda = lda, d.B = B, d.ldb = ldb, d.C = C, d.ldc = ldc;
+  }
+};
+
+// y = act(x W^T + b) (+ residual); W [N,K]
+int linear_fwd(const d2r_encoder_layer_desc* L, int T, int N, int K, const void* x, const void* w, const float* b,
+               void* y, int act, const void* residual, void* preact, void* stream) {
+  Gemm g(L->dtype, D2R_GEMM_NT, T, N, K, x, K, w, K, y, N, L->dtype);
+  g.d.bias = b, g.d.act = act, g.d.residual = residual, g.d.ldr = N, g.d.preact = preact;
+  return d2r_gemm(&g.d, stream);
+}
+// dx = dy W (+ residual);  gW += dy^T x, gb += colsum(dy)
+int linear_bwd(const d2r_encoder_layer_desc* L, int T, int N, int K, const void* dy, const void* x, const void* w,
+               void* dx, const void* dx_residual, float* gw, float* gb, void* stream) {
+  Gemm gx(L->dtype, D2R_GEMM_NN, T, K, N, dy, N, w, K, dx, K, L->dtype);
+  gx.d.residual = dx_residual, gx.d.ldr = K;
+  if (int rc = d2r_gemm(&gx.d, stream)) return rc;
+  Gemm gw_(L->dtype, D2R_GEMM_TN, N, K, T, dy, N, x, K, gw, K, D2R_F32);
+  gw_.d.beta = 1.f, gw_.d.dbias = gb, gw_.d.workspace = L->splitk_ws, gw_.d.workspace_bytes = L->splitk_bytes;
+  return d2r_gemm(&gw_.d, stream);
+}
+
+size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+
+}  // namespace
+
+#define D2R_TRY(expr)            \
+  do {                           \
+    if (int rc_ = (expr)) return rc_; \
+  } while (0)
+
+extern "C" size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F) {
+  const size_t T = (size_t)B * L, es = 2;
+  const size_t wide = (size_t)(F > 3 * E ? F : 3 * E);
+  return 2 * align256(T * E * es) + align256(T * wide * es) + align256(d2r_layernorm_bwd_workspace((int64_t)T, E));
+}
+
+static int check_desc(const d2r_encoder_layer_desc* L, const char* fn) {
+  D2R_REQUIRE(L != nullptr, "%s: null descriptor", fn);
+  D2R_REQUIRE(L->dtype == D2R_BF16, "%s: bf16 only (the fp32 path runs op by op)", fn);
+  D2R_REQUIRE(L->B >= 1 && L->L >= 1 && L->E >= 8 && L->H >= 1 && L->F >= 8 && L->E % L->H == 0, "%s: bad shape", fn);
+  D2R_REQUIRE(d2r_mha_supported(L->dtype, L->L, L->L, L->E / L->H), "%s: attention shape unsupported by the fused core", fn);
+  D2R_REQUIRE(L->act == D2R_ACT_GELU || L->act == D2R_ACT_QUICK_GELU, "%s: activation must be gelu or quick_gelu", fn);
+  D2R_REQUIRE(L->w_qkv && L->w_o && L->w_1 && L->w_2 && L->b_qkv && L->b_o && L->b_1 && L->b_2 && L->ln1_g && L->ln1_b &&
+                  L->ln2_g && L->ln2_b, "%s: null parameter", fn);
+  D2R_REQUIRE(L->x && L->y && L->qkv && L->ctx && L->h1 && L->n1 && L->f_pre && L->f && L->h2 && L->lse && L->mean1 &&
+                  L->rstd1 && L->mean2 && L->rstd2, "%s: null activation buffer", fn);
+  return D2R_OK;
+}
+
+extern "C" int d2r_encoder_layer_fwd(const d2r_encoder_layer_desc* L, void* stream) {
+  D2R_TRY(check_desc(L, "d2r_encoder_layer_fwd"));
+  const int T = L->B * L->L, E = L->E, F = L->F, dh = E / L->H;
+  const int64_t E3 = 3 * (int64_t)E;
+  const char* qkv = (const char*)L->qkv;
+  const void* attn_in = L->x;
+  if (L->pre_ln) {
+    D2R_TRY(d2r_layernorm_fwd(L->dtype, L->x, L->ln1_g, L->ln1_b, L->eps, T, E, L->n1, L->mean1, L->rstd1, stream));
+    attn_in = L->n1;
+  }
+  D2R_TRY(linear_fwd(L, T, 3 * E, E, attn_in, L->w_qkv, L->b_qkv, L->qkv, D2R_ACT_NONE, nullptr, nullptr, stream));
+  D2R_TRY(d2r_mha_fwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, L->ctx, E,
+                      (int64_t)L->L * E, nullptr, 0, 0, L->mask, L->lse, L->B, L->H, L->L, L->L, dh, L->scale, stream));
+  D2R_TRY(linear_fwd(L, T, E, E, L->ctx, L->w_o, L->b_o, L->h1, D2R_ACT_NONE, L->x, nullptr, stream));
+  if (L->pre_ln) {
+    D2R_TRY(d2r_layernorm_fwd(L->dtype, L->h1, L->ln2_g, L->ln2_b, L->eps, T, E, L->h2, L->mean2, L->rstd2, stream));
+    D2R_TRY(linear_fwd(L, T, F, E, L->h2, L->w_1, L->b_1, L->f, L->act, nullptr, L->f_pre, stream));
+    D2R_TRY(linear_fwd(L, T, E, F, L->f, L->w_2, L->b_2, L->y, D2R_ACT_NONE, L->h1, nullptr, stream));
+  } else {
+    D2R_TRY(d2r_layernorm_fwd(L->dtype, L->h1, L->ln1_g, L->ln1_b, L->eps, T, E, L->n1, L->mean1, L->rstd1, stream));
+    D2R_TRY(linear_fwd(L, T, F, E, L->n1, L->w_1, L->b_1, L->f, L->act, nullptr, L->f_pre, stream));
+    D2R_TRY(linear_fwd(L, T, E, F, L->f, L->w_2, L->b_2, L->h2, D2R_ACT_NONE, L->n1, nullptr, stream));
+    D2R_TRY(d2r_layernorm_fwd(L->dtype, L->h2, L->ln2_g, L->ln2_b, L->eps, T, E, L->y, L->mean2, L->rstd2, stream));
+  }
+  return D2R_OK;
+}
+
+extern "C" int d2r_encoder_layer_bwd(const d2r_encoder_layer_desc* L, void* stream) {
+  D2R_TRY(check_desc(L, "d2r_encoder_layer_bwd"));
+  D2R_REQUIRE(L->dy && L->dx && L->gw_qkv && L->gw_o && L->gw_1 && L->gw_2 && L->gb_qkv && L->gb_o && L->gb_1 && L->gb_2 &&
+                  L->gln1_g && L->gln1_b && L->gln2_g && L->gln2_b, "d2r_encoder_layer_bwd: null gradient pointer");
+  D2R_REQUIRE(L->scratch && L->scratch_bytes >= d2r_encoder_layer_bwd_scratch(L->B, L->L, L->E, L->F) && d2r_aligned16(L->scratch),
+              "d2r_encoder_layer_bwd: scratch too small (need d2r_encoder_layer_bwd_scratch bytes, 16-byte aligned)");
+  const int T = L->B * L->L, E = L->E, F = L->F, dh = E / L->H;
+  const int64_t E3 = 3 * (int64_t)E;
+  const size_t es = 2, wide = (size_t)(F > 3 * E ? F : 3 * E);
+  char* p = (char*)L->scratch;
+  void* s0 = p;                      p += align256((size_t)T * E * es);
+  void* s2 = p;                      p += align256((size_t)T * E * es);
+  void* s1 = p;                      p += align256((size_t)T * wide * es);
+  void* lnws = p;
+  const size_t lnws_bytes = d2r_layernorm_bwd_workspace(T, E);
+  const char* qkv = (const char*)L->qkv;
+  const int64_t n_f = (int64_t)T * F;
+  if (!L->pre_ln) {
+    // y = LN2(h2), h2 = n1 + ffn(n1), n1 = LN1(h1), h1 = x + attn(x)
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, L->dy, L->h2, L->ln2_g, L->mean2, L->rstd2, T, E, s0, nullptr, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // s0 = d h2
+    D2R_TRY(linear_bwd(L, T, E, F, s0, L->f, L->w_2, s1, nullptr, L->gw_2, L->gb_2, stream));                       // s1 = d f
+    D2R_TRY(d2r_act_bwd(L->dtype, L->act, s1, L->f_pre, s1, n_f, stream));                                           // s1 = d f_pre
+    D2R_TRY(linear_bwd(L, T, F, E, s1, L->n1, L->w_1, s2, s0, L->gw_1, L->gb_1, stream));                            // s2 = d n1 (ffn + skip)
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, s2, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, s0, nullptr, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // s0 = d h1
+    D2R_TRY(linear_bwd(L, T, E, E, s0, L->ctx, L->w_o, s2, nullptr, L->gw_o, L->gb_o, stream));                      // s2 = d ctx
+    char* dqkv = (char*)s1;
+    D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, s2, E, (int64_t)L->L * E,
+                        L->mask, L->lse, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
+                        L->L, L->L, dh, L->scale, stream));
+    D2R_TRY(linear_bwd(L, T, 3 * E, E, dqkv, L->x, L->w_qkv, L->dx, s0, L->gw_qkv, L->gb_qkv, stream));              // dx = d(attn in) + d h1
+  } else {
+    // y = h1 + ffn(h2), h2 = LN2(h1), h1 = x + attn(n1), n1 = LN1(x)
+    D2R_TRY(linear_bwd(L, T, E, F, L->dy, L->f, L->w_2, s1, nullptr, L->gw_2, L->gb_2, stream));                     // s1 = d f
+    D2R_TRY(d2r_act_bwd(L->dtype, L->act, s1, L->f_pre, s1, n_f, stream));
+    D2R_TRY(linear_bwd(L, T, F, E, s1, L->h2, L->w_1, s0, nullptr, L->gw_1, L->gb_1, stream));                       // s0 = d h2
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, s0, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, s2, L->dy, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // s2 = d h1 (+ skip)
+    D2R_TRY(linear_bwd(L, T, E, E, s2, L->ctx, L->w_o, s0, nullptr, L->gw_o, L->gb_o, stream));                      // s0 = d ctx
+    char* dqkv = (char*)s1;
+    D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, s0, E, (int64_t)L->L * E,
+                        L->mask, L->lse, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
+                        L->L, L->L, dh, L->scale, stream));
+    D2R_TRY(linear_bwd(L, T, 3 * E, E, dqkv, L->n1, L->w_qkv, s0, nullptr, L->gw_qkv, L->gb_qkv, stream));           // s0 = d n1
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, s0, L->x, L->ln1_g, L->mean1, L->rstd1, T, E, L->dx, s2, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // dx = LN1'(d n1) + d h1
+  }
+  return D2R_OK;
+}

@@ -361,18 +361,26 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int64_t* __re
 // and hipGraph replays agree exactly).
 // word table: the FIRST token carrying an id (its "leader") sums the dY rows of every token with that id in token
 // order and adds the result to the table row; all other tokens with that id do nothing.
-template <typename T>
+template <typename T, bool IDS_IN_LDS>
 __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const T* __restrict__ dY, const int64_t* __restrict__ ids,
                                                                   int64_t ntok, int D, int64_t pad_id,
                                                                   float* __restrict__ dword) {
+  // the scans below touch every id: keep them in LDS (as int32) when they fit, one coalesced pass per workgroup
+  constexpr int LDS_IDS = IDS_IN_LDS ? 8192 : 1;
+  __shared__ int sid[LDS_IDS];
+  if constexpr (IDS_IN_LDS) {
+    for (int64_t j = threadIdx.x; j < ntok; j += 256) sid[j] = (int)ids[j];
+    __syncthreads();
+  }
+  auto id_at = [&](int64_t j) -> int64_t { return IDS_IN_LDS ? (int64_t)sid[j] : ids[j]; };
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= ntok) return;
-  const int64_t id = ids[tok];
+  const int64_t id = id_at(tok);
   if (id == pad_id) return;
   for (int64_t j0 = 0; j0 < tok; j0 += 64) {  // leader test (wave-uniform exit)
     const int64_t j = j0 + lane;
-    if (__ballot(j < tok && ids[j] == id)) return;
+    if (__ballot(j < tok && id_at(j) == id)) return;
   }
   float acc[4][4];
 #pragma unroll
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const T* __res
     for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
   for (int64_t j0 = tok & ~(int64_t)63; j0 < ntok; j0 += 64) {
     const int64_t j = j0 + lane;
-    uint64_t hits = __ballot(j >= tok && j < ntok && ids[j] == id);
+    uint64_t hits = __ballot(j >= tok && j < ntok && id_at(j) == id);
     while (hits) {
       const int b = __builtin_ctzll(hits);
       hits &= hits - 1;
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const T* __res
   }
 }
 // type table: grid (cdiv(D,64), ntype); wave w of 16 sums tokens w, w+16, ... of its type in order, the 16 partials
-// are combined in wave order.
+// are combined in wave order.  Loads are unconditional (masked after the fact) so that 8 of them are in flight.
 template <typename T>
 __global__ __launch_bounds__(1024) void bert_embed_bwd_type_kernel(const T* __restrict__ dY, const int64_t* __restrict__ tt,
                                                                    int64_t ntok, int D, float* __restrict__ dtype_tab) {
@@ -419,9 +427,22 @@ __global__ __launch_bounds__(1024) void bert_embed_bwd_type_kernel(const T* __re
   const int c = blockIdx.x * 64 + lane;
   const int64_t ty = blockIdx.y;
   float s = 0.f;
-  if (c < D)
-    for (int64_t t = w; t < ntok; t += 16)
+  if (c < D) {
+    int64_t t = w;
+    for (; t + 16 * 7 < ntok; t += 16 * 8) {
+      float v[8];
+      bool m[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = to_f<T>(dY[(t + 16 * u) * D + c]);
+        m[u] = tt[t + 16 * u] == ty;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += m[u] ? v[u] : 0.f;
+    }
+    for (; t < ntok; t += 16)
       if (tt[t] == ty) s += to_f<T>(dY[t * D + c]);
+  }
   part[w][lane] = s;
   __syncthreads();
   if (w == 0 && c < D) {
@@ -461,7 +482,8 @@ template <typename T>
 static void launch_bert_embed_bwd(const void* dY, const int64_t* ids, const int64_t* tt, int B, int L, int D, int ntype,
                                   int64_t pad_id, float* dword, float* dpos, float* dtype_tab, hipStream_t st) {
   const int64_t ntok = (int64_t)B * L;
-  hipLaunchKernelGGL((bert_embed_bwd_word_kernel<T>), dim3(d2r_cdiv(ntok, 4)), dim3(256), 0, st, (const T*)dY, ids, ntok, D, pad_id, dword);
+  if (ntok <= 8192) hipLaunchKernelGGL((bert_embed_bwd_word_kernel<T, true>), dim3(d2r_cdiv(ntok, 4)), dim3(256), 0, st, (const T*)dY, ids, ntok, D, pad_id, dword);
+  else hipLaunchKernelGGL((bert_embed_bwd_word_kernel<T, false>), dim3(d2r_cdiv(ntok, 4)), dim3(256), 0, st, (const T*)dY, ids, ntok, D, pad_id, dword);
   hipLaunchKernelGGL((bert_embed_bwd_type_kernel<T>), dim3(d2r_cdiv(D, 64), ntype), dim3(1024), 0, st, (const T*)dY, tt, ntok, D, dtype_tab);
   hipLaunchKernelGGL((batch_sum_rows_kernel<T, true>), dim3(L), dim3(256), 0, st, (const T*)dY, B, L, D, dpos);
 }

@@ -159,6 +159,33 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   if (grp == 0 && c < ncols) out[c] = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
 }
 
+// stage 2 of LayerNorm backward: column c < D -> dgamma, else dbeta; ws rows are [2*D]; optional accumulation
+__global__ __launch_bounds__(256) void ln_sum_partials_kernel(const float* __restrict__ ws, int nparts, int D,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int accumulate) {
+  __shared__ float sh[4][64];
+  const int l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l, stride = 2 * D;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < stride) {
+    int p = grp;
+    for (; p + 12 < nparts; p += 16) {
+      a0 += ws[(int64_t)p * stride + c];
+      a1 += ws[(int64_t)(p + 4) * stride + c];
+      a2 += ws[(int64_t)(p + 8) * stride + c];
+      a3 += ws[(int64_t)(p + 12) * stride + c];
+    }
+    for (; p < nparts; p += 4) a0 += ws[(int64_t)p * stride + c];
+  }
+  sh[grp][l] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && c < stride) {
+    const float t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+    float* dst = c < D ? dgamma + c : dbeta + (c - D);
+    *dst = accumulate ? *dst + t : t;
+  }
+}
+
 // =====================================================================================================
 // LayerNorm: wave per row, row kept in registers as 16-byte packs (D % VEC == 0, D <= 64*VEC*MAXP)
 // =====================================================================================================
@@ -228,7 +255,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int64_t rows, int D,
-                                                            T* __restrict__ dX, float* __restrict__ ws) {
+                                                            T* __restrict__ dX, float* __restrict__ ws,
+                                                            const T* __restrict__ dres) {
   constexpr int VEC = PackOf<T>::N;
   extern __shared__ float sh[];  // [4][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -276,8 +304,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       const int pk = lane + i * 64;
       if (pk < npk) {
         Pack<T, VEC> o;
+        if (dres) {  // gradient arriving through the skip connection around this LayerNorm's block
+          const Pack<T, VEC> r = ld_pack<T, VEC>(dres + row * D + pk * VEC);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(rs * (g[i][j] - s1 - xh[i][j] * s2));
+          for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(rs * (g[i][j] - s1 - xh[i][j] * s2) + to_f<T>(r.v[j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(rs * (g[i][j] - s1 - xh[i][j] * s2));
+        }
         st_pack<T, VEC>(dx + pk * VEC, o);
       }
     }
@@ -336,11 +370,12 @@ extern "C" int d2r_layernorm_fwd(int dtype, const void* X, const float* gamma, c
   return d2r_check_launch("d2r_layernorm_fwd");
 }
 
-extern "C" int d2r_layernorm_bwd(int dtype, const void* dY, const void* X, const float* gamma, const float* mean,
-                                 const float* rstd, int64_t rows, int D, void* dX, float* dgamma, float* dbeta,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+// dX = LN'(dY) (+ dres); dgamma/dbeta overwritten, or accumulated when `accumulate`
+extern "C" int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, const float* gamma, const float* mean,
+                                    const float* rstd, int64_t rows, int D, void* dX, const void* dres, float* dgamma,
+                                    float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   D2R_REQUIRE(dY && X && gamma && mean && rstd && dX && dgamma && dbeta, "d2r_layernorm_bwd: null pointer");
-  D2R_REQUIRE(d2r_aligned16(X) && d2r_aligned16(dY) && d2r_aligned16(dX), "d2r_layernorm_bwd: tensors must be 16-byte aligned");
+  D2R_REQUIRE(d2r_aligned16(X) && d2r_aligned16(dY) && d2r_aligned16(dX) && d2r_aligned16(dres), "d2r_layernorm_bwd: tensors must be 16-byte aligned");
   if (workspace_bytes < d2r_layernorm_bwd_workspace(rows, D) || !workspace)
     return d2r_fail(D2R_ERR_WORKSPACE, "d2r_layernorm_bwd: workspace %zu < %zu", workspace_bytes, d2r_layernorm_bwd_workspace(rows, D));
   hipStream_t st = (hipStream_t)stream;
@@ -350,19 +385,25 @@ extern "C" int d2r_layernorm_bwd(int dtype, const void* dY, const void* X, const
   if (dtype == D2R_BF16) {
     if (int rc = ln_check<bf16_t>("d2r_layernorm_bwd", D)) return rc;
     // register arrays are sized by MAXP = ceil(D / (64 lanes * 8)): D=768 needs 2, not 4 (occupancy)
-    if (D <= 64 * 8 * 2) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 2>), dim3(nb), dim3(256), shmem, st, (const bf16_t*)dY, (const bf16_t*)X, gamma, mean, rstd, rows, D, (bf16_t*)dX, ws);
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 4>), dim3(nb), dim3(256), shmem, st, (const bf16_t*)dY, (const bf16_t*)X, gamma, mean, rstd, rows, D, (bf16_t*)dX, ws);
+    if (D <= 64 * 8 * 2) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 2>), dim3(nb), dim3(256), shmem, st, (const bf16_t*)dY, (const bf16_t*)X, gamma, mean, rstd, rows, D, (bf16_t*)dX, ws, (const bf16_t*)dres);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 4>), dim3(nb), dim3(256), shmem, st, (const bf16_t*)dY, (const bf16_t*)X, gamma, mean, rstd, rows, D, (bf16_t*)dX, ws, (const bf16_t*)dres);
   } else if (dtype == D2R_F32) {
     if (int rc = ln_check<float>("d2r_layernorm_bwd", D)) return rc;
-    if (D <= 64 * 4 * 3) hipLaunchKernelGGL((layernorm_bwd_kernel<float, 3>), dim3(nb), dim3(256), shmem, st, (const float*)dY, (const float*)X, gamma, mean, rstd, rows, D, (float*)dX, ws);
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<float, 4>), dim3(nb), dim3(256), shmem, st, (const float*)dY, (const float*)X, gamma, mean, rstd, rows, D, (float*)dX, ws);
+    if (D <= 64 * 4 * 3) hipLaunchKernelGGL((layernorm_bwd_kernel<float, 3>), dim3(nb), dim3(256), shmem, st, (const float*)dY, (const float*)X, gamma, mean, rstd, rows, D, (float*)dX, ws, (const float*)dres);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<float, 4>), dim3(nb), dim3(256), shmem, st, (const float*)dY, (const float*)X, gamma, mean, rstd, rows, D, (float*)dX, ws, (const float*)dres);
   } else {
     return d2r_fail(D2R_ERR_INVALID, "d2r_layernorm_bwd: bad dtype %d", dtype);
   }
   if (int rc = d2r_check_launch("d2r_layernorm_bwd")) return rc;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(d2r_cdiv(D, 64)), dim3(256), 0, st, ws, nb, 2 * D, D, dgamma);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(d2r_cdiv(D, 64)), dim3(256), 0, st, ws + D, nb, 2 * D, D, dbeta);
+  hipLaunchKernelGGL(ln_sum_partials_kernel, dim3(d2r_cdiv(2 * D, 64)), dim3(256), 0, st, ws, nb, D, dgamma, dbeta, accumulate);
   return d2r_check_launch("d2r_layernorm_bwd(sum)");
+}
+
+extern "C" int d2r_layernorm_bwd(int dtype, const void* dY, const void* X, const float* gamma, const float* mean,
+                                 const float* rstd, int64_t rows, int D, void* dX, float* dgamma, float* dbeta,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  return d2r_layernorm_bwd_ex(dtype, dY, X, gamma, mean, rstd, rows, D, dX, nullptr, dgamma, dbeta, 0, workspace,
+                              workspace_bytes, stream);
 }
 
 // =====================================================================================================

@@ -506,6 +506,105 @@ def attention_kv(q, kv, num_heads, scale, mask=None, residual=None):
 
 
 # ------------------------------------------------------------------------------------------------------
+# K15 whole encoder layer (bf16): one C call forward, one backward
+# ------------------------------------------------------------------------------------------------------
+class LayerBundle:
+    """Pointers of one encoder layer's parameters and fp32 gradient sinks (stable across steps: they live in the flat
+    buffers of d2r_amd.params.ParamStore), pre-packed into a descriptor template."""
+
+    def __init__(self, *, pre_ln, act, H, eps, qkv, o, fc1, fc2, ln1, ln2):
+        """qkv/o/fc1/fc2: (weight leaf, bias leaf) with ._d2r_lp / ._d2r_grad; ln1/ln2: (gamma, beta) fp32 leaves."""
+        self.params = [t for pair in (qkv, o, fc1, fc2, ln1, ln2) for t in pair]
+        if any(getattr(t, "_d2r_grad", None) is None for t in self.params) or any(
+                getattr(w, "_d2r_lp", None) is None for w in (qkv[0], o[0], fc1[0], fc2[0])):
+            raise _lib.D2RError("LayerBundle needs a model prepared by ParamStore with a bf16 shadow")
+        E, Fi = o[0].shape[0], fc1[0].shape[0]
+        assert qkv[0].shape == (3 * E, E) and fc2[0].shape == (E, Fi)
+        self.E, self.F, self.H = E, Fi, H
+        t = _lib.EncoderLayerDesc()
+        t.dtype, t.pre_ln, t.act, t.E, t.H, t.F, t.eps, t.scale = BF16, int(pre_ln), act, E, H, Fi, eps, float((E // H) ** -0.5)
+        for name, (w, b) in (("qkv", qkv), ("o", o), ("1", fc1), ("2", fc2)):
+            setattr(t, "w_" + name, w._d2r_lp.data_ptr())
+            setattr(t, "b_" + name, b.data_ptr())
+            setattr(t, "gw_" + name, w._d2r_grad.data_ptr())
+            setattr(t, "gb_" + name, b._d2r_grad.data_ptr())
+        for name, (g, b) in (("ln1", ln1), ("ln2", ln2)):
+            setattr(t, name + "_g", g.data_ptr())
+            setattr(t, name + "_b", b.data_ptr())
+            setattr(t, "g" + name + "_g", g._d2r_grad.data_ptr())
+            setattr(t, "g" + name + "_b", b._d2r_grad.data_ptr())
+        self.template = t
+        self.key = (qkv[0]._d2r_lp.data_ptr(), qkv[0]._d2r_grad.data_ptr())
+
+    def supports(self, x) -> bool:
+        return (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.shape[-1] == self.E
+                and bool(_lib.load().d2r_mha_supported(BF16, x.shape[1], x.shape[1], self.E // self.H)))
+
+
+_SCRATCH = {}
+
+
+def _layer_scratch(nbytes: int, device) -> torch.Tensor:
+    key = (device.index, _stream())
+    ws = _SCRATCH.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _SCRATCH[key] = ws
+    return ws
+
+
+class _EncoderLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, bundle, mask):
+        x = x.contiguous()
+        B, L, E = x.shape
+        T, Fi, H = B * L, bundle.F, bundle.H
+        d = _lib.EncoderLayerDesc()
+        C.memmove(C.byref(d), C.byref(bundle.template), C.sizeof(d))
+        d.B, d.L = B, L
+        d.mask = _ptr(mask)
+        acts = torch.empty(T * (7 * E + 2 * Fi), dtype=torch.bfloat16, device=x.device)  # qkv ctx h1 n1 h2 | f_pre f
+        stats = torch.empty(B * H * L + 4 * T, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        a0, s0 = acts.data_ptr(), stats.data_ptr()
+        d.x, d.y = x.data_ptr(), y.data_ptr()
+        d.qkv, d.ctx, d.h1, d.n1, d.h2 = a0, a0 + 6 * T * E, a0 + 8 * T * E, a0 + 10 * T * E, a0 + 12 * T * E
+        d.f_pre, d.f = a0 + 14 * T * E, a0 + 14 * T * E + 2 * T * Fi
+        d.lse = s0
+        s0 += 4 * B * H * L
+        d.mean1, d.rstd1, d.mean2, d.rstd2 = s0, s0 + 4 * T, s0 + 8 * T, s0 + 12 * T
+        _lib.call("d2r_encoder_layer_fwd", C.byref(d), _stream(), meta=dict(group="encoder_layer_fwd"))
+        ctx.save_for_backward(x)
+        ctx.d, ctx.keep, ctx.bundle = d, (acts, stats, mask), bundle
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        d, bundle = ctx.d, ctx.bundle
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        need = _lib.load().d2r_encoder_layer_bwd_scratch(d.B, d.L, d.E, d.F)
+        scratch = _layer_scratch(need, g.device)
+        ws = _workspace(64 << 20, g.device)
+        d.dy, d.dx = g.data_ptr(), dx.data_ptr()
+        d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
+        d.splitk_ws, d.splitk_bytes = ws.data_ptr(), ws.numel()
+        _lib.call("d2r_encoder_layer_bwd", C.byref(d), _stream(), meta=dict(group="encoder_layer_bwd"))
+        ctx.keep = None
+        for p in bundle.params:  # data-parallel bucket readiness (d2r_amd.dp)
+            cb = getattr(p, "_d2r_ready_cb", None)
+            if cb is not None:
+                cb(p)
+        return dx, None, None, None
+
+
+def encoder_layer(x, bundle: LayerBundle, mask=None):
+    """One whole BertLayer / CLIPEncoderLayer (bf16) as a single autograd node and a single C call each way."""
+    return _EncoderLayer.apply(x, bundle.params[0], bundle, mask)
+
+
+# ------------------------------------------------------------------------------------------------------
 # row kernels
 # ------------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):

@@ -451,6 +451,25 @@ def _check_dropout(p: float, training: bool, what: str):
             "(BASELINE.md section 3) or call model.eval()")
 
 
+COMPOSITE_LAYERS = os.environ.get("D2R_COMPOSITE", "1") != "0"  # whole encoder layers as one C call (bf16 only)
+
+
+def _layer_bundle(layer, x):
+    """The cached LayerBundle of a BertLayer / CLIPEncoderLayer when the one-call path applies (bf16 model prepared by
+    ParamStore, fused q|k|v, attention shape supported by the fused core), else None -> the op-by-op path."""
+    if not COMPOSITE_LAYERS or layer.cdtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not x.is_cuda:
+        return None
+    att = layer.attention.self if hasattr(layer, "attention") else layer.self_attn
+    fz = att._fused_linear()
+    if fz is None or getattr(fz.weight, "_d2r_lp", None) is None:
+        return None
+    b = getattr(layer, "_bundle_cache", None)
+    if b is None or b.key != (fz.weight._d2r_lp.data_ptr(), fz.weight._d2r_grad.data_ptr()):
+        b = layer._bundle()
+        layer._bundle_cache = b
+    return b if b.supports(x) else None
+
+
 class BertSelfAttention(D2RModule):
     def __init__(self, config):
         super().__init__()
@@ -502,10 +521,23 @@ class BertLayer(D2RModule):
         self.output = BertOutput(config)
         self.p_hidden = config.hidden_dropout_prob
 
+    def _bundle(self):
+        sa, so = self.attention.self, self.attention.output
+        fz = sa._fused_linear()
+        return F.LayerBundle(pre_ln=False, act=ACT_GELU, H=sa.num_attention_heads, eps=so.LayerNorm.eps,
+                             qkv=(fz.weight, fz.bias), o=(so.dense.weight, so.dense.bias),
+                             fc1=(self.intermediate.dense.weight, self.intermediate.dense.bias),
+                             fc2=(self.output.dense.weight, self.output.dense.bias),
+                             ln1=(so.LayerNorm.weight, so.LayerNorm.bias),
+                             ln2=(self.output.LayerNorm.weight, self.output.LayerNorm.bias))
+
     def forward(self, x, key_mask=None):
         sa = self.attention.self
         _check_dropout(sa.p_drop, self.training, "attention_probs_dropout_prob")
         _check_dropout(self.p_hidden, self.training, "hidden_dropout_prob")
+        bundle = _layer_bundle(self, x)
+        if bundle is not None:
+            return F.encoder_layer(x, bundle, key_mask)
         H = sa.num_attention_heads
         fz = sa._fused_linear()
         if fz is not None:
@@ -548,9 +580,21 @@ class CLIPEncoderLayer(D2RModule):
         self.mlp = CLIPMLP(config)
         self.layer_norm2 = LayerNorm(config.hidden_size, eps=1e-5)
 
+    def _bundle(self):
+        at = self.self_attn
+        fz = at._fused_linear()
+        return F.LayerBundle(pre_ln=True, act=ACT_QUICK_GELU, H=at.num_heads, eps=self.layer_norm1.eps,
+                             qkv=(fz.weight, fz.bias), o=(at.out_proj.weight, at.out_proj.bias),
+                             fc1=(self.mlp.fc1.weight, self.mlp.fc1.bias), fc2=(self.mlp.fc2.weight, self.mlp.fc2.bias),
+                             ln1=(self.layer_norm1.weight, self.layer_norm1.bias),
+                             ln2=(self.layer_norm2.weight, self.layer_norm2.bias))
+
     def forward(self, x):
         at = self.self_attn
         _check_dropout(at.p_drop, self.training, "attention_dropout")
+        bundle = _layer_bundle(self, x)
+        if bundle is not None:
+            return F.encoder_layer(x, bundle)
         h = self.layer_norm1(x)
         d = x.shape[-1] // at.num_heads
         fz = at._fused_linear()

@@ -219,6 +219,12 @@ int d2r_block_merge_fwd(int dtype, const void* m0, const void* m1, int B, int C,
 int d2r_block_merge_bwd(int dtype, const void* m0, const void* m1, const float* zraw, const void* dout, int B,
                         int C, int R, int S, void* dm0, void* dm1, void* stream);
 
+/* As d2r_layernorm_bwd, plus: dX += dres when dres != NULL (the gradient arriving through the skip connection
+ * around the block this LayerNorm belongs to), and dgamma/dbeta ACCUMULATED when accumulate != 0. */
+int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, const float* gamma, const float* mean,
+                         const float* rstd, int64_t rows, int D, void* dX, const void* dres, float* dgamma,
+                         float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K3 fused multi-head attention core, short sequences (bf16, head_dim 64 or 48, Lq, Lk <= 256)
  *   O[b,:,h] = softmax(scale * Q_h K_h^T + mask[b]) V_h (+ residual)
@@ -238,6 +244,39 @@ int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* 
                 const void* v, int64_t ldv, int64_t svb, const void* dO, int64_t ldg, int64_t sgb, const float* mask,
                 const float* lse, void* dq, int64_t lddq, int64_t sdqb, void* dk, int64_t lddk, int64_t sdkb, void* dv,
                 int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk, int head_dim, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K15 one transformer encoder layer per call (bf16): BertLayer.forward (models/modeling_unimo.py:473-512,
+ * post-LayerNorm, GELU) and CLIPEncoderLayer.forward (:222-268, pre-LayerNorm, quick_gelu), forward or backward.
+ * Same kernels, same order as the single-op entry points; the 7 forward / ~16 backward launches are issued from
+ * C++ in one call, skip-connection gradients ride in GEMM / LayerNorm epilogues, parameter gradients accumulate
+ * into the caller's fp32 sinks.  All activation buffers are [B*L, *] row-major in `dtype`.
+ *   post-LN: h1 = x + attn(x) ; n1 = LN1(h1) ; h2 = n1 + ffn(n1) ; y = LN2(h2)
+ *   pre-LN : n1 = LN1(x) ; h1 = x + attn(n1) ; h2 = LN2(h1) ; y = h1 + ffn(h2)
+ *   attn(a) = mha(a Wqkv^T + bqkv) Wo^T + bo ;  ffn(a) = act(a W1^T + b1) W2^T + b2
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int dtype;                  /* D2R_BF16 */
+  int pre_ln;                 /* 0 post-LN (BERT), 1 pre-LN (CLIP ViT) */
+  int act;                    /* D2R_ACT_GELU | D2R_ACT_QUICK_GELU */
+  int B, L, E, H, F;          /* batch, tokens, hidden, heads, intermediate */
+  float eps, scale;           /* LayerNorm eps; attention logit scale (head_dim^-0.5) */
+  const float* mask;          /* additive key mask fp32 [B,L] or NULL */
+  const void *w_qkv, *w_o, *w_1, *w_2;           /* [3E,E] (q|k|v rows), [E,E], [F,E], [E,F] in dtype */
+  const float *b_qkv, *b_o, *b_1, *b_2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  float *gw_qkv, *gw_o, *gw_1, *gw_2, *gb_qkv, *gb_o, *gb_1, *gb_2, *gln1_g, *gln1_b, *gln2_g, *gln2_b; /* bwd: += */
+  const void* x;              /* in  [B*L,E] */
+  void* y;                    /* out [B*L,E] */
+  void *qkv, *ctx, *h1, *n1, *f_pre, *f, *h2;    /* saved by fwd, read by bwd: [T,3E] [T,E] [T,E] [T,E] [T,F] [T,F] [T,E] */
+  float *lse, *mean1, *rstd1, *mean2, *rstd2;    /* [B,H,L], [T] x4 */
+  const void* dy;             /* bwd in  [B*L,E] */
+  void* dx;                   /* bwd out [B*L,E] */
+  void* scratch; size_t scratch_bytes;           /* bwd: >= d2r_encoder_layer_bwd_scratch() */
+  void* splitk_ws; size_t splitk_bytes;          /* bwd: split-K scratch of the weight-gradient GEMMs (may be NULL) */
+} d2r_encoder_layer_desc;
+size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F);
+int d2r_encoder_layer_fwd(const d2r_encoder_layer_desc* d, void* stream);
+int d2r_encoder_layer_bwd(const d2r_encoder_layer_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K12 embeddings (models/modeling_unimo.py:87-118, 272-331)

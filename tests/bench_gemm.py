@@ -13,15 +13,20 @@ from d2r_amd import functional as F
 from d2r_amd._lib import BF16, F32, GEMM_NN, GEMM_NT, GEMM_TN
 
 dev = torch.device("cuda:0")
+NAMES_EARLY = {GEMM_NT: "NT", GEMM_NN: "NN", GEMM_TN: "TN"}
 lib = _lib.load()
 ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+dbias = torch.zeros(4096, dtype=torch.float32, device=dev)
 
 # (layout, M, N, K): forward linears, dX, dW of the C2 workload (B=32, L=128 / 197 tokens)
 SHAPES = [
     (GEMM_NT, 4096, 768, 768), (GEMM_NT, 6304, 768, 768), (GEMM_NT, 6304, 3072, 768), (GEMM_NT, 6304, 768, 3072),
     (GEMM_NN, 4096, 768, 768), (GEMM_NN, 6304, 768, 3072), (GEMM_NN, 6304, 3072, 768),
-    (GEMM_TN, 768, 768, 4096), (GEMM_TN, 768, 768, 6304), (GEMM_TN, 3072, 768, 6304), (GEMM_TN, 768, 3072, 6304),
+    (GEMM_TN, 768, 768, 4096), (GEMM_TN, 768, 768, 6304), (GEMM_TN, 2304, 768, 4096), (GEMM_TN, 2304, 768, 6304),
+    (GEMM_TN, 3072, 768, 6304), (GEMM_TN, 768, 3072, 6304), (GEMM_TN, 3072, 768, 4096), (GEMM_TN, 768, 3072, 4096),
 ]
+if os.environ.get("BENCH_GEMM_ONLY"):
+    SHAPES = [s for s in SHAPES if NAMES_EARLY[s[0]] == os.environ["BENCH_GEMM_ONLY"]]
 NAMES = {GEMM_NT: "NT", GEMM_NN: "NN", GEMM_TN: "TN"}
 
 
@@ -35,7 +40,8 @@ def operands(layout, M, N, K, dtype):
 def run(layout, M, N, K, a, b, c, use_ws):
     F.gemm(layout, M, N, K, a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], c.data_ptr(), N,
            dtype=BF16 if a.dtype == torch.bfloat16 else F32, c_dtype=F32 if c.dtype == torch.float32 else BF16,
-           beta=1.0 if layout == GEMM_TN else 0.0, splitk_ws=ws if use_ws else None)
+           beta=1.0 if layout == GEMM_TN else 0.0, splitk_ws=ws if use_ws else None,
+           dbias=dbias.data_ptr() if layout == GEMM_TN else None)  # weight-gradient GEMMs carry the bias gradient
 
 
 def timeit(fn, iters=20):

@@ -43,4 +43,5 @@ for _ in range(5):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(35)
+st.sort_stats("tottime").print_stats(30)
+st.sort_stats("cumulative").print_stats("functional.py|modules.py", 45)
