@@ -7,6 +7,9 @@
 // issued from C++ in one call instead of one Python autograd node and one ctypes call each, skip-connection
 // gradients ride in GEMM / LayerNorm epilogues instead of separate add kernels, and every parameter gradient is
 // accumulated straight into the caller's fp32 sinks.
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -29,15 +32,40 @@ int linear_fwd(const d2r_encoder_layer_desc* L, int T, int N, int K, const void*
   g.d.bias = b, g.d.act = act, g.d.residual = residual, g.d.ldr = N, g.d.preact = preact;
   return d2r_gemm(&g.d, stream);
 }
-// dx = dy W (+ residual);  gW += dy^T x, gb += colsum(dy)
+// Fork: `side` waits for everything enqueued on `stream` so far.  Events come from a small ring; a wait captures
+// the event's state at the time of the call, so re-recording an event later does not disturb earlier waits.
+int fork_stream(void* stream, void* side) {
+  constexpr int RING = 64;
+  static hipEvent_t ring[RING];
+  static std::atomic<unsigned> next{0};
+  static std::once_flag once;
+  static hipError_t init_err = hipSuccess;
+  std::call_once(once, [] {
+    for (int i = 0; i < RING && init_err == hipSuccess; ++i) init_err = hipEventCreateWithFlags(&ring[i], hipEventDisableTiming);
+  });
+  if (init_err != hipSuccess) return d2r_fail(D2R_ERR_LAUNCH, "encoder layer: hipEventCreate failed: %s", hipGetErrorString(init_err));
+  hipEvent_t ev = ring[next.fetch_add(1) % RING];
+  hipError_t e = hipEventRecord(ev, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)side, ev, 0);
+  if (e != hipSuccess) return d2r_fail(D2R_ERR_LAUNCH, "encoder layer: stream fork failed: %s", hipGetErrorString(e));
+  return D2R_OK;
+}
+
+// dx = dy W (+ residual);  gW += dy^T x, gb += colsum(dy).  The weight-gradient GEMM feeds nothing downstream in
+// the backward pass: with a side stream it is forked off BEFORE the dX GEMM and overlaps the rest of the chain.
 int linear_bwd(const d2r_encoder_layer_desc* L, int T, int N, int K, const void* dy, const void* x, const void* w,
                void* dx, const void* dx_residual, float* gw, float* gb, void* stream) {
-  Gemm gx(L->dtype, D2R_GEMM_NN, T, K, N, dy, N, w, K, dx, K, L->dtype);
-  gx.d.residual = dx_residual, gx.d.ldr = K;
-  if (int rc = d2r_gemm(&gx.d, stream)) return rc;
+  void* wstream = stream;
+  if (L->wgrad_stream && L->wgrad_stream != stream) {
+    if (int rc = fork_stream(stream, L->wgrad_stream)) return rc;
+    wstream = L->wgrad_stream;
+  }
   Gemm gw_(L->dtype, D2R_GEMM_TN, N, K, T, dy, N, x, K, gw, K, D2R_F32);
   gw_.d.beta = 1.f, gw_.d.dbias = gb, gw_.d.workspace = L->splitk_ws, gw_.d.workspace_bytes = L->splitk_bytes;
-  return d2r_gemm(&gw_.d, stream);
+  if (int rc = d2r_gemm(&gw_.d, wstream)) return rc;
+  Gemm gx(L->dtype, D2R_GEMM_NN, T, K, N, dy, N, w, K, dx, K, L->dtype);
+  gx.d.residual = dx_residual, gx.d.ldr = K;
+  return d2r_gemm(&gx.d, stream);
 }
 
 size_t align256(size_t n) { return (n + 255) / 256 * 256; }
@@ -50,9 +78,10 @@ size_t align256(size_t n) { return (n + 255) / 256 * 256; }
   } while (0)
 
 extern "C" size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F) {
+  // every intermediate gradient has its own buffer (none is reused inside the layer): the weight-gradient GEMMs
+  // that read them may still be running on the side stream when the main chain has moved on
   const size_t T = (size_t)B * L, es = 2;
-  const size_t wide = (size_t)(F > 3 * E ? F : 3 * E);
-  return 2 * align256(T * E * es) + align256(T * wide * es) + align256(d2r_layernorm_bwd_workspace((int64_t)T, E));
+  return 5 * align256(T * E * es) + align256(T * F * es) + align256(T * 3 * E * es) + align256(d2r_layernorm_bwd_workspace((int64_t)T, E));
 }
 
 static int check_desc(const d2r_encoder_layer_desc* L, const char* fn) {
@@ -103,41 +132,48 @@ extern "C" int d2r_encoder_layer_bwd(const d2r_encoder_layer_desc* L, void* stre
               "d2r_encoder_layer_bwd: scratch too small (need d2r_encoder_layer_bwd_scratch bytes, 16-byte aligned)");
   const int T = L->B * L->L, E = L->E, F = L->F, dh = E / L->H;
   const int64_t E3 = 3 * (int64_t)E;
-  const size_t es = 2, wide = (size_t)(F > 3 * E ? F : 3 * E);
+  const size_t es = 2;
   char* p = (char*)L->scratch;
-  void* s0 = p;                      p += align256((size_t)T * E * es);
-  void* s2 = p;                      p += align256((size_t)T * E * es);
-  void* s1 = p;                      p += align256((size_t)T * wide * es);
+  auto take = [&](size_t elems) { void* r = p; p += align256(elems * es); return r; };
+  void* a0 = take((size_t)T * E);  // five [T,E] gradients
+  void* a1 = take((size_t)T * E);
+  void* a2 = take((size_t)T * E);
+  void* a3 = take((size_t)T * E);
+  void* a4 = take((size_t)T * E);
+  void* df = take((size_t)T * F);  // d f / d f_pre (in place)
+  char* dqkv = (char*)take((size_t)T * 3 * E);
   void* lnws = p;
   const size_t lnws_bytes = d2r_layernorm_bwd_workspace(T, E);
   const char* qkv = (const char*)L->qkv;
   const int64_t n_f = (int64_t)T * F;
   if (!L->pre_ln) {
     // y = LN2(h2), h2 = n1 + ffn(n1), n1 = LN1(h1), h1 = x + attn(x)
-    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, L->dy, L->h2, L->ln2_g, L->mean2, L->rstd2, T, E, s0, nullptr, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // s0 = d h2
-    D2R_TRY(linear_bwd(L, T, E, F, s0, L->f, L->w_2, s1, nullptr, L->gw_2, L->gb_2, stream));                       // s1 = d f
-    D2R_TRY(d2r_act_bwd(L->dtype, L->act, s1, L->f_pre, s1, n_f, stream));                                           // s1 = d f_pre
-    D2R_TRY(linear_bwd(L, T, F, E, s1, L->n1, L->w_1, s2, s0, L->gw_1, L->gb_1, stream));                            // s2 = d n1 (ffn + skip)
-    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, s2, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, s0, nullptr, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // s0 = d h1
-    D2R_TRY(linear_bwd(L, T, E, E, s0, L->ctx, L->w_o, s2, nullptr, L->gw_o, L->gb_o, stream));                      // s2 = d ctx
-    char* dqkv = (char*)s1;
-    D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, s2, E, (int64_t)L->L * E,
+    void *d_h2 = a0, *d_n1 = a1, *d_h1 = a2, *d_ctx = a3;
+    (void)a4;
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, L->dy, L->h2, L->ln2_g, L->mean2, L->rstd2, T, E, d_h2, nullptr, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));
+    D2R_TRY(linear_bwd(L, T, E, F, d_h2, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream));
+    D2R_TRY(d2r_act_bwd(L->dtype, L->act, df, L->f_pre, df, n_f, stream));
+    D2R_TRY(linear_bwd(L, T, F, E, df, L->n1, L->w_1, d_n1, d_h2, L->gw_1, L->gb_1, stream));  // ffn path + skip
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, d_h1, nullptr, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));
+    D2R_TRY(linear_bwd(L, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
+    D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
                         L->mask, L->lse, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
                         L->L, L->L, dh, L->scale, stream));
-    D2R_TRY(linear_bwd(L, T, 3 * E, E, dqkv, L->x, L->w_qkv, L->dx, s0, L->gw_qkv, L->gb_qkv, stream));              // dx = d(attn in) + d h1
+    D2R_TRY(linear_bwd(L, T, 3 * E, E, dqkv, L->x, L->w_qkv, L->dx, d_h1, L->gw_qkv, L->gb_qkv, stream));  // + skip
   } else {
     // y = h1 + ffn(h2), h2 = LN2(h1), h1 = x + attn(n1), n1 = LN1(x)
-    D2R_TRY(linear_bwd(L, T, E, F, L->dy, L->f, L->w_2, s1, nullptr, L->gw_2, L->gb_2, stream));                     // s1 = d f
-    D2R_TRY(d2r_act_bwd(L->dtype, L->act, s1, L->f_pre, s1, n_f, stream));
-    D2R_TRY(linear_bwd(L, T, F, E, s1, L->h2, L->w_1, s0, nullptr, L->gw_1, L->gb_1, stream));                       // s0 = d h2
-    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, s0, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, s2, L->dy, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // s2 = d h1 (+ skip)
-    D2R_TRY(linear_bwd(L, T, E, E, s2, L->ctx, L->w_o, s0, nullptr, L->gw_o, L->gb_o, stream));                      // s0 = d ctx
-    char* dqkv = (char*)s1;
-    D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, s0, E, (int64_t)L->L * E,
+    void *d_h2 = a0, *d_h1 = a1, *d_ctx = a2, *d_n1 = a3;
+    (void)a4;
+    D2R_TRY(linear_bwd(L, T, E, F, L->dy, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream));
+    D2R_TRY(d2r_act_bwd(L->dtype, L->act, df, L->f_pre, df, n_f, stream));
+    D2R_TRY(linear_bwd(L, T, F, E, df, L->h2, L->w_1, d_h2, nullptr, L->gw_1, L->gb_1, stream));
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_h2, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, d_h1, L->dy, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // + skip
+    D2R_TRY(linear_bwd(L, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
+    D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
                         L->mask, L->lse, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
                         L->L, L->L, dh, L->scale, stream));
-    D2R_TRY(linear_bwd(L, T, 3 * E, E, dqkv, L->n1, L->w_qkv, s0, nullptr, L->gw_qkv, L->gb_qkv, stream));           // s0 = d n1
-    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, s0, L->x, L->ln1_g, L->mean1, L->rstd1, T, E, L->dx, s2, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // dx = LN1'(d n1) + d h1
+    D2R_TRY(linear_bwd(L, T, 3 * E, E, dqkv, L->n1, L->w_qkv, d_n1, nullptr, L->gw_qkv, L->gb_qkv, stream));
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->x, L->ln1_g, L->mean1, L->rstd1, T, E, L->dx, d_h1, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // + skip
   }
   return D2R_OK;
 }

@@ -441,7 +441,7 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
   // 128x128 when the output is large and 128x64 + split-K when it is 768x768.
   int tile;  // 0: 32x64, 1: 64x64, 2: 128x64, 3: 128x128
   if (a.M <= 32) tile = 0;
-  else if (LAYOUT == D2R_GEMM_TN && batch == 1) tile = ((int64_t)a.M * a.N >= 2000000) ? 3 : 2;
+  else if (LAYOUT == D2R_GEMM_TN && batch == 1) tile = ((int64_t)a.M * a.N >= 1500000) ? 3 : 1;  // gemm_ab_r01_c.log
   else tile = 1;
   if (g_tile >= 0 && g_tile <= 3 && a.M > 32) tile = g_tile;
   if (tile > 1) a.vecC = 0;  // the LDS-staged epilogue only pays on the small tiles (register pressure on the large ones)

@@ -67,6 +67,9 @@ class FlatGradReducer:
         view = self.flat_g[a:b]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            from .functional import wgrad_streams
+            for side in wgrad_streams():  # weight-gradient GEMMs accumulate into flat_g on their own streams
+                self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

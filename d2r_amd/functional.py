@@ -60,10 +60,84 @@ def _parr(ts: Sequence[Optional[torch.Tensor]]):
 
 _WS = {}
 
+# Weight-gradient GEMMs (dW = dY^T X) feed nothing but the optimiser: they are issued on a side stream per compute
+# stream so that they fill the CUs the (small, latency-bound) dX chain leaves idle.  Whoever consumes the flat
+# gradient buffer (optimiser step, all-reduce, zero_grad, a test reading .grad) calls wgrad_join() first.
+WGRAD_STREAMS = os.environ.get("D2R_WGRAD_STREAMS", "0") != "0"  # measured slower on MI355X (35.4 vs 33.7 ms/step): off
+_WGRAD = {}
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (all kernels run stream-ordered on the current stream)."""
-    key = (device.index, _stream())
+
+def wgrad_stream(*tensors) -> Optional[int]:
+    """Side stream of the current stream (raw handle), already waiting on the work enqueued so far; `tensors` are the
+    operands the side stream will read (kept alive for it).  None when the feature is off."""
+    if not WGRAD_STREAMS:
+        return None
+    cur = torch.cuda.current_stream()
+    side = _WGRAD.get(cur.cuda_stream)
+    if side is None:
+        side = _WGRAD[cur.cuda_stream] = torch.cuda.Stream()
+    side.wait_stream(cur)
+    for t in tensors:
+        t.record_stream(side)
+    return side.cuda_stream
+
+
+def wgrad_side_stream_handle() -> Optional[int]:
+    """Raw handle of the current stream's side stream WITHOUT synchronising (the C composite orders itself)."""
+    if not WGRAD_STREAMS:
+        return None
+    cur = torch.cuda.current_stream()
+    side = _WGRAD.get(cur.cuda_stream)
+    if side is None:
+        side = _WGRAD[cur.cuda_stream] = torch.cuda.Stream()
+    return side
+
+
+def wgrad_streams():
+    return list(_WGRAD.values())
+
+
+_COMPUTE_STREAMS = []  # extra streams the forward forks onto (d2r_amd.modules registers its text / vision streams)
+_join_queued = False
+
+
+def register_compute_stream(s):
+    if s not in _COMPUTE_STREAMS:
+        _COMPUTE_STREAMS.append(s)
+
+
+def _backward_join_cb():
+    """Final callback of a backward pass; autograd runs it on the stream that was current around .backward(): that
+    stream now waits for every compute and weight-gradient stream, so whatever follows (optimiser step, all-reduce,
+    a host read of .grad) is ordered after ALL gradient writes — independent of which autograd leaves happened to run."""
+    global _join_queued
+    _join_queued = False
+    cur = torch.cuda.current_stream()
+    for st in _COMPUTE_STREAMS:
+        cur.wait_stream(st)
+    for st in _WGRAD.values():
+        cur.wait_stream(st)
+
+
+def _ensure_backward_join():
+    """Called from backward functions: queues _backward_join_cb once per backward pass."""
+    global _join_queued
+    if not _join_queued:
+        _join_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(_backward_join_cb)
+
+
+def wgrad_join():
+    """Makes the current stream wait for every weight-gradient side stream."""
+    if _WGRAD:
+        cur = torch.cuda.current_stream()
+        for side in _WGRAD.values():
+            cur.wait_stream(side)
+
+
+def _workspace(nbytes: int, device, stream: Optional[int] = None) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream): kernels that share it run stream-ordered."""
+    key = (device.index, _stream() if stream is None else stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -99,7 +173,7 @@ def _as_rows(x: torch.Tensor):
 # ------------------------------------------------------------------------------------------------------
 def gemm(layout, M, N, K, A, lda, B, ldb, Cc, ldc, *, dtype, c_dtype, nb=1, nh=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
          alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, residual=None, ldr=0, sR=(0, 0), preact=None, tag=None,
-         splitk_ws=None, s_bias=0, dbias=None):
+         splitk_ws=None, s_bias=0, dbias=None, stream=None):
     d = GemmDesc(dtype=dtype, c_dtype=c_dtype, layout=layout, act=act, M=M, N=N, K=K, nb=nb, nh=nh, alpha=alpha,
                  beta=beta, A=A, lda=lda, sAb=sA[0], sAh=sA[1], B=B, ldb=ldb, sBb=sB[0], sBh=sB[1], C=Cc, ldc=ldc,
                  sCb=sC[0], sCh=sC[1], bias=bias, residual=residual, ldr=ldr, sRb=sR[0], sRh=sR[1], preact=preact)
@@ -113,7 +187,7 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cc, ldc, *, dtype, c_dtype, nb=1, nh=1
         meta = dict(group=tag or f"gemm_{'bf16' if dtype == BF16 else 'f32'}_{('NT', 'NN', 'TN')[layout]}",
                     flops=2.0 * M * N * K * z,
                     bytes=float(z) * ((M * K + N * K) * es + M * N * cs * (2 if (beta != 0.0 or residual) else 1)))
-    _lib.call("d2r_gemm", C.byref(d), _stream(), meta=meta)
+    _lib.call("d2r_gemm", C.byref(d), _stream() if stream is None else stream, meta=meta)
 
 
 def colsum(g: torch.Tensor, M: int, N: int, ld: int) -> torch.Tensor:
@@ -197,6 +271,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        _ensure_backward_join()
         x, w, ref = ctx.saved_tensors
         M, N, K, lda = ctx.dims
         g = g.contiguous()
@@ -225,9 +300,13 @@ class _Linear(torch.autograd.Function):
         if ctx.w_needs:
             sink = getattr(ctx.w_master, "_d2r_grad", None)  # flat fp32 gradient buffer (d2r_amd.params.ParamStore)
             if sink is not None:
-                # dW accumulates straight into the zero-initialised flat buffer: no temp, no autograd add kernel
+                # dW accumulates straight into the zero-initialised flat buffer: no temp, no autograd add kernel;
+                # nothing downstream in backward reads it, so it runs on the weight-gradient side stream
+                # (not when g is also handed on as the skip-connection gradient: autograd may then accumulate into
+                # that very tensor in place on the main stream while the side stream still reads it)
+                side = wgrad_stream(g, x) if (db is None and not ctx.has_res) else None
                 gemm(GEMM_TN, N, K, M, g.data_ptr(), N, x.data_ptr(), lda, sink.data_ptr(), K, dtype=_dt(x),
-                     c_dtype=F32, beta=1.0, splitk_ws=_workspace(64 << 20, x.device), dbias=db_ptr)
+                     c_dtype=F32, beta=1.0, splitk_ws=_workspace(64 << 20, x.device, side), dbias=db_ptr, stream=side)
                 cb = getattr(ctx.w_master, "_d2r_ready_cb", None)  # data-parallel bucket readiness (d2r_amd.dp)
                 if cb is not None:
                     cb(ctx.w_master)
@@ -580,13 +659,23 @@ class _EncoderLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        _ensure_backward_join()
         (x,) = ctx.saved_tensors
         d, bundle = ctx.d, ctx.bundle
         g = g.contiguous()
         dx = torch.empty_like(g)
         need = _lib.load().d2r_encoder_layer_bwd_scratch(d.B, d.L, d.E, d.F)
-        scratch = _layer_scratch(need, g.device)
-        ws = _workspace(64 << 20, g.device)
+        side = wgrad_side_stream_handle()
+        if side is None:
+            scratch = _layer_scratch(need, g.device)
+            ws = _workspace(64 << 20, g.device)
+            d.wgrad_stream = None
+        else:  # the weight-gradient GEMMs outlive this call on the side stream: fresh scratch, operands kept alive
+            scratch = torch.empty(need, dtype=torch.uint8, device=g.device)
+            for t in (scratch, g, x, ctx.keep[0]):
+                t.record_stream(side)
+            ws = _workspace(64 << 20, g.device, side.cuda_stream)
+            d.wgrad_stream = side.cuda_stream
         d.dy, d.dx = g.data_ptr(), dx.data_ptr()
         d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
         d.splitk_ws, d.splitk_bytes = ws.data_ptr(), ws.numel()
@@ -1011,6 +1100,7 @@ class _CrossEntropy(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        _ensure_backward_join()
         logits, labels = ctx.saved_tensors
         g = g.contiguous()
         B, Cn = logits.shape

@@ -754,6 +754,8 @@ class UnimoModel(D2RModule):
             main = torch.cuda.current_stream()
             if self._streams is None:
                 self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                for st in self._streams:
+                    F.register_compute_stream(st)  # joined at the end of every backward pass
             sT, sV = self._streams
             on_t, on_v = (lambda: torch.cuda.stream(sT)), (lambda: torch.cuda.stream(sV))
             for x in (input_ids, token_type_ids, key_mask):

@@ -161,6 +161,8 @@ class ParamStore:
             _lib.call("d2r_cast", _lib.F32, self.flat_w.data_ptr(), _lib.BF16, self.flat_lp.data_ptr(), self.n, _stream())
 
     def zero_grad(self):
+        from .functional import wgrad_join
+        wgrad_join()  # weight-gradient GEMMs of the step may still be accumulating on their side streams
         self.flat_g.zero_()  # one memset node
 
     def live_numel(self) -> int:
@@ -192,6 +194,8 @@ class FusedAdamW:
         self.store.zero_grad()
 
     def step(self):
+        from .functional import wgrad_join
+        wgrad_join()
         self.step_count += 1
         st = self.store
         for pg in self.param_groups:
@@ -225,6 +229,8 @@ class FusedAdamW:
 
     def step_captured(self):
         """The launches recorded into a hipGraph (no host-side scalars)."""
+        from .functional import wgrad_join
+        wgrad_join()
         st = self.store
         _, dev = self._hyper_buffers()
         for i, pg in enumerate(self.param_groups):

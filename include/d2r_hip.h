@@ -273,6 +273,10 @@ typedef struct {
   void* dx;                   /* bwd out [B*L,E] */
   void* scratch; size_t scratch_bytes;           /* bwd: >= d2r_encoder_layer_bwd_scratch() */
   void* splitk_ws; size_t splitk_bytes;          /* bwd: split-K scratch of the weight-gradient GEMMs (may be NULL) */
+  /* bwd: optional second stream (hipStream_t) for the four weight-gradient GEMMs, forked from `stream` inside the
+   * call; the caller joins it before anything reads the gradient sinks, and keeps x, the saved activations, dy and
+   * scratch alive until it has drained.  NULL: everything on `stream`. */
+  void* wgrad_stream;
 } d2r_encoder_layer_desc;
 size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F);
 int d2r_encoder_layer_fwd(const d2r_encoder_layer_desc* d, void* stream);
