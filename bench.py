@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--dr-step", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=8)
+    ap.add_argument("--cpu-samples", type=int, default=48)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="overlap bucketed grad all-reduce with backward")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("D2R_BENCH_GRAPH", "0")),
@@ -226,10 +226,20 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        with KernelTimer() as kt:
-            for _ in range(2):
-                eager_step()  # per-launch events need eager launches; the kernels are the ones the graph replays
-        summ = kt.summary()
+        # Per-kernel durations: the same step, but launched op by op on ONE stream (whole-layer C calls and the
+        # two-stream overlap switched off), so that every launch is bracketed by its own pair of HIP events and runs
+        # alone on the GPU — the durations rocprofv3 --kernel-trace reports (it serialises dispatches too).
+        saved = (M.COMPOSITE_LAYERS, model.model.use_streams)
+        M.COMPOSITE_LAYERS, model.model.use_streams = False, False
+        try:
+            eager_step()
+            torch.cuda.synchronize()
+            with KernelTimer() as kt:
+                for _ in range(2):
+                    eager_step()
+            summ = kt.summary()
+        finally:
+            M.COMPOSITE_LAYERS, model.model.use_streams = saved
         kernels = []
         for name, r in summ.items():
             calls, t_s = r["calls"], r["ms"] * 1e-3
@@ -241,7 +251,7 @@ def main():
                 key = "bf16" if "bf16" in name else "f32"
                 ach = r["flops"] / t_s / 1e12
                 ent.update(bound="mfma", achieved=round(ach, 2), peak=MFMA_PEAK_TF[key], unit="TFLOP/s",
-                           frac=round(ach / MFMA_PEAK_TF[key], 4))
+                           frac=round(ach / MFMA_PEAK_TF[key], 4), algo_bytes_per_launch=round(r["bytes"] / calls))
             else:
                 nbytes = r["algo_bytes"] if r["algo_bytes"] > 0 else r["bytes"]
                 if nbytes > 0:
@@ -255,8 +265,16 @@ def main():
         total_ms = sum(e["ms_per_step"] for e in kernels)
         dom = next((e for e in kernels if "bound" in e), None)
         if dom is not None:
+            traffic = None  # HBM bytes per launch of that kernel family from the committed rocprofv3 --pmc passes
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")) as f:
+                    traffic = json.load(f).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+            except OSError:
+                pass
             out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
-                               "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": None,
+                               "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic,
+                               "traffic_source": "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950)" if traffic else None,
+                               "algorithmic_bytes_per_launch": dom.get("algo_bytes_per_launch"),
                                "avg_launch_us": dom["avg_us"], "share_of_kernel_time": round(dom["ms_per_step"] / max(total_ms, 1e-9), 3)}
         log("instrumented (per-kernel HIP event) pass done")
         out["roofline_kernels"] = kernels[:24]

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Aggregates the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as the counters do not fit one
+pass on gfx950) of `bench.py --steps 2 --warmup 1` into per-kernel-family HBM traffic per d2r_gemm launch.
+
+  python profiles/make_pmc_summary.py gpurun_out/pmc/fetch/f_counter_collection.csv \
+         gpurun_out/pmc/write/w_counter_collection.csv profiles/pmc_traffic_r01.json
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE
+counts 64 B per 128-B request of a wide coalesced read, i.e. HALF the bytes -> doubled here; WRITE_SIZE is exact for
+16-B-per-lane stores.  A d2r_gemm launch of the TN (weight-gradient) family is the GEMM kernel plus, when split-K is
+used, its splitk_reduce_kernel: both are attributed to the family and divided by the number of GEMM kernels."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def family(name: str):
+    if "splitk_reduce" in name:
+        return "gemm_bf16_TN", False
+    m = re.search(r"gemm_kernelIDF16bLi(\d)E", name)
+    if m:
+        return "gemm_bf16_" + ("NT", "NN", "TN")[int(m.group(1))], True
+    if "gemm_kernel<bool _Accum" in name:  # llvm-cxxfilt's rendering of gemm_kernel<__bf16, 1 (NN), ...>
+        return "gemm_bf16_NN", True
+    m = re.search(r"gemm_glds_kernel<(\d)", name)
+    if m:
+        return "gemm_bf16_" + ("NT", "NN", "TN")[int(m.group(1))], True
+    m = re.search(r"gemm_kernel<float, (\d)", name)
+    if m:
+        return "gemm_f32_" + ("NT", "NN", "TN")[int(m.group(1))], True
+    for key, fam in (("mha_fwd", "mha_core_fwd"), ("mha_bwd", "mha_core_bwd"), ("adamw", "d2r_adamw_step"),
+                     ("agg_fwd", "route_aggregate_fwd"), ("agg_bwd", "route_aggregate_bwd"), ("meanpool_fwd", "d2r_meanpool_fwd"),
+                     ("layernorm_bwd", "d2r_layernorm_bwd"), ("layernorm_fwd", "d2r_layernorm_fwd")):
+        if key in name:
+            return fam, True
+    return None, False
+
+
+def load(path, counter):
+    tot, launches = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            fam, counts = family(row["Kernel_Name"])
+            if fam is None:
+                continue
+            tot[fam] += float(row["Counter_Value"]) * 1024.0
+            launches[fam] += 1 if counts else 0
+    return tot, launches
+
+
+fetch, n_f = load(sys.argv[1], "FETCH_SIZE")
+write, n_w = load(sys.argv[2], "WRITE_SIZE")
+out = {"_doc": "HBM bytes per launch from rocprofv3 --pmc (FETCH_SIZE x2 on gfx950, WRITE_SIZE exact); bench.py --steps 2 --warmup 1, bf16 C2 workload"}
+for fam in sorted(fetch):
+    n = max(n_f[fam], 1)
+    rd, wr = 2.0 * fetch[fam] / n, write.get(fam, 0.0) / max(n_w.get(fam, 0), 1)
+    out[fam] = {"launches_profiled": n_f[fam], "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                "hbm_bytes_per_launch": round(rd + wr)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
