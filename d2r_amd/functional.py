@@ -418,6 +418,7 @@ def matmul_nt(a, b):
 # attention: O = softmax(scale * Q K^T + mask) V (+ residual), H heads; logits kept fp32
 # ------------------------------------------------------------------------------------------------------
 FUSED_MHA = os.environ.get("D2R_FUSED_MHA", "1") != "0"  # 0: three-launch path (the only one for fp32)
+FUSED_XATTN = os.environ.get("D2R_FUSED_XATTN", "1") != "0"
 
 
 def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device):
@@ -433,6 +434,13 @@ def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device):
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=device)
         _lib.call("d2r_mha_fwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], o.data_ptr(), E, Lq * E,
                   _ptr(residual), E, Lq * E, _ptr(mask), lse.data_ptr(), B, H, Lq, Lk, d, scale, _stream(),
+                  meta=dict(group=tag, algo_bytes=float(B * (2 * Lq + 2 * Lk) * E * 2)))
+        return o, lse
+    if FUSED_XATTN and H == 1 and _lib.load().d2r_xattn_supported(dt, Lq, Lk, E):
+        o = torch.empty(B, Lq, E, dtype=dtype, device=device)
+        lse = torch.empty(B, 1, Lq, dtype=torch.float32, device=device)
+        _lib.call("d2r_xattn_fwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], o.data_ptr(), E, Lq * E,
+                  _ptr(residual), E, Lq * E, _ptr(mask), lse.data_ptr(), B, Lq, Lk, E, scale, _stream(),
                   meta=dict(group=tag, algo_bytes=float(B * (2 * Lq + 2 * Lk) * E * 2)))
         return o, lse
     S = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=device)
@@ -457,6 +465,19 @@ def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None
     d = E // H
     dt = BF16 if dtype == torch.bfloat16 else F32
     tag = "xattn_core_bwd" if H == 1 else "mha_core_bwd"
+    if P.dim() == 3 and H == 1:  # fused single-head forward: dS, P and dQ in one launch, then the two key-side GEMMs
+        Lkp = (Lk + 7) // 8 * 8
+        Pb = torch.empty(B, Lq, Lkp, dtype=dtype, device=device)
+        dS = torch.empty(B, Lq, Lkp, dtype=dtype, device=device)
+        _lib.call("d2r_xattn_bwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], g.data_ptr(), E, Lq * E,
+                  _ptr(mask), P.data_ptr(), dq[0], dq[1], dq[2], Pb.data_ptr(), dS.data_ptr(), Lkp, B, Lq, Lk, E, scale,
+                  _stream(), meta=dict(group=tag, algo_bytes=float(2 * B * (2 * Lq + 2 * Lk) * E * 2)))
+        sP = (Lq * Lkp, 0)
+        gemm(GEMM_TN, Lk, E, Lq, Pb.data_ptr(), Lkp, g.data_ptr(), E, dv[0], dv[1], dtype=dt, c_dtype=dt, nb=B,
+             sA=sP, sB=(Lq * E, 0), sC=(dv[2], 0), tag=tag)
+        gemm(GEMM_TN, Lk, E, Lq, dS.data_ptr(), Lkp, q[0], q[1], dk[0], dk[1], dtype=dt, c_dtype=dt, nb=B,
+             sA=sP, sB=(q[2], 0), sC=(dk[2], 0), tag=tag)
+        return
     if P.dim() == 3:  # fused forward ran: recompute P from q, k and the log-sum-exp
         _lib.call("d2r_mha_bwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], g.data_ptr(), E, Lq * E,
                   _ptr(mask), P.data_ptr(), dq[0], dq[1], dq[2], dk[0], dk[1], dk[2], dv[0], dv[1], dv[2], B, H, Lq, Lk,

@@ -246,6 +246,26 @@ int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* 
                 int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk, int head_dim, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K2 / K4 fused single-head attention over the full 768-wide feature (bf16, D = 768, Lk <= 256)
+ *   O[b] = softmax(scale * Q K^T + mask[b]) V (+ residual)
+ * Replaces the CrossModalAlignment core (models/XModules.py:300-310 = models/Refinement.py:105-115, scale
+ * 100/sqrt(768)) and the ContextRichCrossModalCell core (models/Cells.py:244-246, scale 1, residual Qs): three
+ * launches (QK^T GEMM, softmax, PV GEMM) and an fp32 [B,Lq,Lk] round trip become one launch.
+ * q/k/v/o/residual/dO/dq: bf16 [B, L, 768] views as (pointer, row stride, batch stride) in elements.
+ * lse: fp32 [B, Lq].  d2r_xattn_bwd writes dq plus P and dS (bf16 [B, Lq, lkp], lkp = Lk rounded up to 8) for
+ * the key-side products dV = P^T dO and dK = dS^T Q, which the caller runs as batched d2r_gemm (TN) launches.
+ * ------------------------------------------------------------------------------------------------ */
+int d2r_xattn_supported(int dtype, int Lq, int Lk, int D);
+int d2r_xattn_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
+                  const void* v, int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual,
+                  int64_t ldr, int64_t srb, const float* mask, float* lse, int B, int Lq, int Lk, int D, float scale,
+                  void* stream);
+int d2r_xattn_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
+                  const void* v, int64_t ldv, int64_t svb, const void* dO, int64_t ldg, int64_t sgb, const float* mask,
+                  const float* lse, void* dq, int64_t lddq, int64_t sdqb, void* P, void* dS, int lkp, int B, int Lq,
+                  int Lk, int D, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K15 one transformer encoder layer per call (bf16): BertLayer.forward (models/modeling_unimo.py:473-512,
  * post-LayerNorm, GELU) and CLIPEncoderLayer.forward (:222-268, pre-LayerNorm, quick_gelu), forward or backward.
  * Same kernels, same order as the single-op entry points; the 7 forward / ~16 backward launches are issued from

@@ -116,12 +116,17 @@ def test_linear_fp32_out(gpu, dtype):
 @pytest.mark.parametrize("cfg", [(2, 8, 8, 4, 0.3, False, False), (3, 16, 5, 1, 100 / math.sqrt(768), False, True),
                                  (2, 197, 197, 12, 0.125, True, False), (2, 40, 40, 16, 1 / math.sqrt(48), False, True),
                                  (2, 128, 128, 12, 0.125, True, False), (2, 70, 250, 12, 0.125, True, True),
-                                 (2, 197, 197, 16, 1 / math.sqrt(48), False, True)])
+                                 (2, 197, 197, 16, 1 / math.sqrt(48), False, True),
+                                 (2, 128, 197, 1, 100 / math.sqrt(768), False, False), (2, 197, 128, 1, 100 / math.sqrt(768), False, False),
+                                 (2, 197, 197, 1, 1.0, False, True), (2, 40, 250, 1, 0.3, True, False), (2, 33, 256, 1, 0.3, True, True)])
 def test_attention(gpu, dtype, cfg):
     from d2r_amd import functional as F
     B, Lq, Lk, H, scale, use_mask, use_res = cfg
     E = 768
-    q, k, v = rnd(B, Lq, E, scale=0.5), rnd(B, Lk, E, scale=0.5, seed=1), rnd(B, Lk, E, seed=2)
+    # single-head cases contract over all 768 features: keep the logits O(1) so that the comparison measures the
+    # kernel and not the conditioning of a near-one-hot softmax
+    qk = 0.15 if (H == 1 and Lq >= 33) else 0.5
+    q, k, v = rnd(B, Lq, E, scale=qk), rnd(B, Lk, E, scale=qk, seed=1), rnd(B, Lk, E, seed=2)
     mask = torch.zeros(B, Lk)
     if use_mask:
         mask[0, Lk // 2:] = -10000.0
