@@ -161,6 +161,60 @@ extern "C" int d2r_add(int dtype, const void* a, const void* b, void* out, int64
   return ew_launch("d2r_add", dtype, p, n, AddF{}, stream);
 }
 
+// ---- dropout ------------------------------------------------------------------------------------------------
+// nn.Dropout of the BERT path (models/modeling_unimo.py:330,388,413,468): y = keep(i) ? x / (1 - p) : 0 (+ add).
+// keep(i) comes from a counter-based generator (splitmix64 finaliser of seed and element index), so the backward
+// pass regenerates the mask from (seed, index) instead of storing it: dx = d2r_dropout(dy) with the same seed.
+__device__ __forceinline__ uint32_t d2r_rand24(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 40);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ y,
+                                                      int64_t n, uint32_t thresh, float scale, uint64_t seed, int vec_ok) {
+  constexpr int VEC = PackOf<T>::N;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t npk = vec_ok ? n / VEC : 0;
+  for (int64_t k = tid; k < npk; k += nthreads) {
+    const Pack<T, VEC> px = ld_pack<T, VEC>(x + k * VEC);
+    Pack<T, VEC> pa, po;
+    if (add) pa = ld_pack<T, VEC>(add + k * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float v = d2r_rand24(seed, (uint64_t)(k * VEC + j)) >= thresh ? to_f<T>(px.v[j]) * scale : 0.f;
+      if (add) v += to_f<T>(pa.v[j]);
+      po.v[j] = from_f<T>(v);
+    }
+    st_pack<T, VEC>(y + k * VEC, po);
+  }
+  for (int64_t e = npk * VEC + tid; e < n; e += nthreads) {
+    float v = d2r_rand24(seed, (uint64_t)e) >= thresh ? to_f<T>(x[e]) * scale : 0.f;
+    if (add) v += to_f<T>(add[e]);
+    y[e] = from_f<T>(v);
+  }
+}
+
+extern "C" int d2r_dropout(int dtype, const void* x, const void* add, void* y, int64_t n, float p, uint64_t seed,
+                           void* stream) {
+  D2R_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f, "d2r_dropout: bad arguments (0 <= p < 1)");
+  if (n == 0) return D2R_OK;
+  const uint32_t thresh = (uint32_t)((double)p * 16777216.0);  // drop when the 24-bit uniform is below p * 2^24
+  const float scale = 1.f / (1.f - p);
+  const int vec_ok = d2r_aligned16(x) && d2r_aligned16(y) && d2r_aligned16(add);
+  const int64_t work = n / (dtype == D2R_BF16 ? 8 : 4) + 1;
+  int blocks = (int)((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == D2R_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)add, (bf16_t*)y, n, thresh, scale, seed, vec_ok);
+  else if (dtype == D2R_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)add, (float*)y, n, thresh, scale, seed, vec_ok);
+  else return d2r_fail(D2R_ERR_INVALID, "d2r_dropout: bad dtype %d", dtype);
+  return d2r_check_launch("d2r_dropout");
+}
+
 // out[0] = sum_k coef[k] * x_k[0]  (scalar loss combination: CE + js terms, models/unimo_model.py:160,
 // models/modeling_unimo.py:849)
 struct LinCombArgs {

@@ -421,28 +421,30 @@ FUSED_MHA = os.environ.get("D2R_FUSED_MHA", "1") != "0"  # 0: three-launch path 
 FUSED_XATTN = os.environ.get("D2R_FUSED_XATTN", "1") != "0"
 
 
-def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device):
-    """q, k, v: (data_ptr, row stride, batch stride) in elements of `dtype`; geo = (B, Lq, Lk, E).  Returns (o, P)."""
+def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device, p_drop=0.0):
+    """q, k, v: (data_ptr, row stride, batch stride) in elements of `dtype`; geo = (B, Lq, Lk, E).  Returns (o, P, seed).
+    p_drop > 0 (training-time attention-probability dropout, models/modeling_unimo.py:204,388) takes the three-launch
+    path: P is saved BEFORE dropout, the mask is regenerated from the seed."""
     B, Lq, Lk, E = geo
     d = E // H
     Lkp = (Lk + 7) // 8 * 8
     dt = BF16 if dtype == torch.bfloat16 else F32
     tag = "xattn_core_fwd" if H == 1 else "mha_core_fwd"
-    if FUSED_MHA and H > 1 and _lib.load().d2r_mha_supported(dt, Lq, Lk, d):
+    if p_drop <= 0.0 and FUSED_MHA and H > 1 and _lib.load().d2r_mha_supported(dt, Lq, Lk, d):
         # one launch, scores/probabilities stay in registers; the saved state is the row log-sum-exp, not P
         o = torch.empty(B, Lq, E, dtype=dtype, device=device)
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=device)
         _lib.call("d2r_mha_fwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], o.data_ptr(), E, Lq * E,
                   _ptr(residual), E, Lq * E, _ptr(mask), lse.data_ptr(), B, H, Lq, Lk, d, scale, _stream(),
                   meta=dict(group=tag, algo_bytes=float(B * (2 * Lq + 2 * Lk) * E * 2)))
-        return o, lse
-    if FUSED_XATTN and H == 1 and _lib.load().d2r_xattn_supported(dt, Lq, Lk, E):
+        return o, lse, 0
+    if p_drop <= 0.0 and FUSED_XATTN and H == 1 and _lib.load().d2r_xattn_supported(dt, Lq, Lk, E):
         o = torch.empty(B, Lq, E, dtype=dtype, device=device)
         lse = torch.empty(B, 1, Lq, dtype=torch.float32, device=device)
         _lib.call("d2r_xattn_fwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], o.data_ptr(), E, Lq * E,
                   _ptr(residual), E, Lq * E, _ptr(mask), lse.data_ptr(), B, Lq, Lk, E, scale, _stream(),
                   meta=dict(group=tag, algo_bytes=float(B * (2 * Lq + 2 * Lk) * E * 2)))
-        return o, lse
+        return o, lse, 0
     S = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=device)
     gemm(GEMM_NT, Lq, Lk, d, q[0], q[1], k[0], k[1], S.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B, nh=H,
          sA=(q[2], d), sB=(k[2], d), sC=(H * Lq * Lkp, Lq * Lkp), tag=tag)
@@ -451,14 +453,19 @@ def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device):
     P = S if dtype == torch.float32 else torch.empty(B, H, Lq, Lkp, dtype=dtype, device=device)
     _lib.call("d2r_softmax_fwd", F32, dt, S.data_ptr(), P.data_ptr(), Lkp, B * H * Lq, Lk, scale, _ptr(mask), H * Lq,
               _stream(), meta=dict(group=tag))  # padding columns of P are never read (K = Lk below)
+    seed, Pd = 0, P
+    if p_drop > 0.0:  # dropout on the probabilities: P itself is what the softmax backward needs
+        seed = _next_dropout_seed()
+        Pd = torch.empty_like(P)
+        _lib.call("d2r_dropout", _dt(P), P.data_ptr(), None, Pd.data_ptr(), P.numel(), p_drop, seed, _stream())
     o = torch.empty(B, Lq, E, dtype=dtype, device=device)
-    gemm(GEMM_NN, Lq, d, Lk, P.data_ptr(), Lkp, v[0], v[1], o.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
+    gemm(GEMM_NN, Lq, d, Lk, Pd.data_ptr(), Lkp, v[0], v[1], o.data_ptr(), E, dtype=dt, c_dtype=dt, nb=B, nh=H,
          sA=(H * Lq * Lkp, Lq * Lkp), sB=(v[2], d), sC=(Lq * E, d), residual=_ptr(residual), ldr=E, sR=(Lq * E, d),
          tag=tag)
-    return o, P
+    return o, P, seed
 
 
-def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None):
+def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None, p_drop=0.0, seed=0):
     """g: contiguous [B,Lq,E]; q/k/v and dq/dk/dv: (ptr, row stride, batch stride).  P: probabilities [B,H,Lq,Lkp]
     of the unfused forward, or the fp32 log-sum-exp [B,H,Lq] of the fused one."""
     B, Lq, Lk, E = geo
@@ -485,11 +492,17 @@ def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None
         return
     Lkp = P.shape[-1]
     sP, sG = (H * Lq * Lkp, Lq * Lkp), (Lq * E, d)
-    gemm(GEMM_TN, Lk, d, Lq, P.data_ptr(), Lkp, g.data_ptr(), E, dv[0], dv[1], dtype=dt, c_dtype=dt, nb=B, nh=H,
+    Pd = P
+    if p_drop > 0.0:  # regenerate the dropped probabilities from the seed (same element indexing as the forward)
+        Pd = torch.empty_like(P)
+        _lib.call("d2r_dropout", _dt(P), P.data_ptr(), None, Pd.data_ptr(), P.numel(), p_drop, seed, _stream())
+    gemm(GEMM_TN, Lk, d, Lq, Pd.data_ptr(), Lkp, g.data_ptr(), E, dv[0], dv[1], dtype=dt, c_dtype=dt, nb=B, nh=H,
          sA=sP, sB=sG, sC=(dv[2], d), tag=tag)
     dP = torch.empty(B, H, Lq, Lkp, dtype=torch.float32, device=device)
     gemm(GEMM_NT, Lq, Lk, d, g.data_ptr(), E, v[0], v[1], dP.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B, nh=H,
          sA=sG, sB=(v[2], d), sC=sP, tag=tag)
+    if p_drop > 0.0:  # gradient through the dropout: same mask, same 1/(1-p)
+        _lib.call("d2r_dropout", F32, dP.data_ptr(), None, dP.data_ptr(), dP.numel(), p_drop, seed, _stream())
     dS = dP if dtype == torch.float32 else torch.empty(B, H, Lq, Lkp, dtype=dtype, device=device)
     _lib.call("d2r_softmax_bwd", dt, F32, P.data_ptr(), dP.data_ptr(), dS.data_ptr(), Lkp, B * H * Lq, Lk, scale,
               _stream(), meta=dict(group=tag))
@@ -508,13 +521,15 @@ class _Attention(torch.autograd.Function):
     """separate q [B,Lq,E], k, v [B,Lk,E]"""
 
     @staticmethod
-    def forward(ctx, q, k, v, H, scale, mask, residual):
+    def forward(ctx, q, k, v, H, scale, mask, residual, p_drop=0.0):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, Lq, E = q.shape
         geo = (B, Lq, k.shape[1], E)
         if residual is not None:
             residual = residual.contiguous()
-        o, P = _attn_fwd(_desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), geo, H, scale, mask, residual, q.dtype, q.device)
+        o, P, seed = _attn_fwd(_desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), geo, H, scale, mask, residual, q.dtype,
+                               q.device, p_drop)
+        ctx.drop = (p_drop, seed)
         ctx.save_for_backward(q, k, v, P)
         ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
@@ -528,8 +543,8 @@ class _Attention(torch.autograd.Function):
         g = g.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         _attn_bwd(g, _desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), P, _desc(dq, 0, E), _desc(dk, 0, E), _desc(dv, 0, E),
-                  geo, H, scale, q.dtype, q.device, ctx.mask)
-        return dq, dk, dv, None, None, None, (g if has_res else None)
+                  geo, H, scale, q.dtype, q.device, ctx.mask, *ctx.drop)
+        return dq, dk, dv, None, None, None, (g if has_res else None), None
 
 
 class _AttentionQKV(torch.autograd.Function):
@@ -537,15 +552,16 @@ class _AttentionQKV(torch.autograd.Function):
     backward writes dq/dk/dv straight into ONE [B,L,3E] gradient (no slice-backward copies, no adds)."""
 
     @staticmethod
-    def forward(ctx, qkv, H, scale, mask, residual):
+    def forward(ctx, qkv, H, scale, mask, residual, p_drop=0.0):
         qkv = qkv.contiguous()
         B, L, E3 = qkv.shape
         E = E3 // 3
         geo = (B, L, L, E)
         if residual is not None:
             residual = residual.contiguous()
-        o, P = _attn_fwd(_desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), geo, H, scale, mask, residual,
-                         qkv.dtype, qkv.device)
+        o, P, seed = _attn_fwd(_desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), geo, H, scale, mask, residual,
+                               qkv.dtype, qkv.device, p_drop)
+        ctx.drop = (p_drop, seed)
         ctx.save_for_backward(qkv, P)
         ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
@@ -559,22 +575,23 @@ class _AttentionQKV(torch.autograd.Function):
         g = g.contiguous()
         d = torch.empty_like(qkv)
         _attn_bwd(g, _desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), P, _desc(d, 0, E3), _desc(d, E, E3),
-                  _desc(d, 2 * E, E3), geo, H, scale, qkv.dtype, qkv.device, ctx.mask)
-        return d, None, None, None, (g if has_res else None)
+                  _desc(d, 2 * E, E3), geo, H, scale, qkv.dtype, qkv.device, ctx.mask, *ctx.drop)
+        return d, None, None, None, (g if has_res else None), None
 
 
 class _AttentionKV(torch.autograd.Function):
     """cross-attention: q [B,Lq,E] and packed kv [B,Lk,2E] (k | v from one fused projection of the other modality)."""
 
     @staticmethod
-    def forward(ctx, q, kv, H, scale, mask, residual):
+    def forward(ctx, q, kv, H, scale, mask, residual, p_drop=0.0):
         q, kv = q.contiguous(), kv.contiguous()
         B, Lq, E = q.shape
         geo = (B, Lq, kv.shape[1], E)
         if residual is not None:
             residual = residual.contiguous()
-        o, P = _attn_fwd(_desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), geo, H, scale, mask, residual, q.dtype,
-                         q.device)
+        o, P, seed = _attn_fwd(_desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), geo, H, scale, mask, residual,
+                               q.dtype, q.device, p_drop)
+        ctx.drop = (p_drop, seed)
         ctx.save_for_backward(q, kv, P)
         ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
@@ -588,21 +605,21 @@ class _AttentionKV(torch.autograd.Function):
         g = g.contiguous()
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         _attn_bwd(g, _desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), P, _desc(dq, 0, E), _desc(dkv, 0, 2 * E),
-                  _desc(dkv, E, 2 * E), geo, H, scale, q.dtype, q.device, ctx.mask)
-        return dq, dkv, None, None, None, (g if has_res else None)
+                  _desc(dkv, E, 2 * E), geo, H, scale, q.dtype, q.device, ctx.mask, *ctx.drop)
+        return dq, dkv, None, None, None, (g if has_res else None), None
 
 
-def attention(q, k, v, num_heads, scale, mask=None, residual=None):
+def attention(q, k, v, num_heads, scale, mask=None, residual=None, p_drop=0.0):
     """q [B,Lq,E], k/v [B,Lk,E]; mask: fp32 additive [B,Lk] or None; residual [B,Lq,E] added to the output."""
-    return _Attention.apply(q, k, v, num_heads, float(scale), mask, residual)
+    return _Attention.apply(q, k, v, num_heads, float(scale), mask, residual, float(p_drop))
 
 
-def attention_qkv(qkv, num_heads, scale, mask=None, residual=None):
-    return _AttentionQKV.apply(qkv, num_heads, float(scale), mask, residual)
+def attention_qkv(qkv, num_heads, scale, mask=None, residual=None, p_drop=0.0):
+    return _AttentionQKV.apply(qkv, num_heads, float(scale), mask, residual, float(p_drop))
 
 
-def attention_kv(q, kv, num_heads, scale, mask=None, residual=None):
-    return _AttentionKV.apply(q, kv, num_heads, float(scale), mask, residual)
+def attention_kv(q, kv, num_heads, scale, mask=None, residual=None, p_drop=0.0):
+    return _AttentionKV.apply(q, kv, num_heads, float(scale), mask, residual, float(p_drop))
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -896,6 +913,43 @@ class _Add(torch.autograd.Function):
 
 def add(a, b):
     return _Add.apply(a, b)
+
+
+# nn.Dropout of the BERT path.  The mask is a pure function of (seed, element index): each call draws a fresh 63-bit
+# seed from torch's CPU generator (so torch.manual_seed makes training runs reproducible; no device sync), and the
+# backward pass regenerates the mask from it.
+def _next_dropout_seed() -> int:
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, p, seed):
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+            assert residual.shape == x.shape and residual.dtype == x.dtype
+        y = torch.empty_like(x)
+        _lib.call("d2r_dropout", _dt(x), x.data_ptr(), _ptr(residual), y.data_ptr(), x.numel(), p, seed, _stream())
+        ctx.cfg = (p, seed, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, has_res = ctx.cfg
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        _lib.call("d2r_dropout", _dt(g), g.data_ptr(), None, dx.data_ptr(), g.numel(), p, seed, _stream())
+        return dx, (g if has_res else None), None, None
+
+
+def dropout(x, p: float, training: bool, residual=None):
+    """nn.Dropout(p)(x) (+ residual).  Identity (plus the add) when not training or p == 0."""
+    if not training or p <= 0.0:
+        return x if residual is None else add(x, residual)
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f"dropout probability {p} outside [0, 1)")
+    return _Dropout.apply(x, residual, float(p), _next_dropout_seed())
 
 
 class _LinComb(torch.autograd.Function):

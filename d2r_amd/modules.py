@@ -444,13 +444,6 @@ class Reversed_InteractionModule(_InteractionBase):
 # ------------------------------------------------------------------------------------------------------
 # encoders
 # ------------------------------------------------------------------------------------------------------
-def _check_dropout(p: float, training: bool, what: str):
-    if training and p > 0.0:
-        raise NotImplementedError(
-            f"{what}={p}: dropout is not implemented in the HIP path yet; build the config with dropout 0 "
-            "(BASELINE.md section 3) or call model.eval()")
-
-
 COMPOSITE_LAYERS = os.environ.get("D2R_COMPOSITE", "1") != "0"  # whole encoder layers as one C call (bf16 only)
 
 
@@ -533,17 +526,24 @@ class BertLayer(D2RModule):
 
     def forward(self, x, key_mask=None):
         sa = self.attention.self
-        _check_dropout(sa.p_drop, self.training, "attention_probs_dropout_prob")
-        _check_dropout(self.p_hidden, self.training, "hidden_dropout_prob")
-        bundle = _layer_bundle(self, x)
+        # training-time dropout (models/modeling_unimo.py:388,413,468) runs op by op; without it the whole layer
+        # is one C call
+        p_att = sa.p_drop if self.training else 0.0
+        p_hid = self.p_hidden if self.training else 0.0
+        bundle = _layer_bundle(self, x) if (p_att == 0.0 and p_hid == 0.0) else None
         if bundle is not None:
             return F.encoder_layer(x, bundle, key_mask)
         H = sa.num_attention_heads
+        scale = 1.0 / math.sqrt(x.shape[-1] // H)
         fz = sa._fused_linear()
         if fz is not None:
-            ctx = F.attention_qkv(fz(x, self.cdtype), H, 1.0 / math.sqrt(x.shape[-1] // H), mask=key_mask)
+            ctx = F.attention_qkv(fz(x, self.cdtype), H, scale, mask=key_mask, p_drop=p_att)
         else:
-            ctx = F.attention(sa.query(x), sa.key(x), sa.value(x), H, 1.0 / math.sqrt(x.shape[-1] // H), mask=key_mask)
+            ctx = F.attention(sa.query(x), sa.key(x), sa.value(x), H, scale, mask=key_mask, p_drop=p_att)
+        if p_hid > 0.0:
+            a = self.attention.output.LayerNorm(F.dropout(self.attention.output.dense(ctx), p_hid, True, residual=x))
+            h = self.intermediate.dense(a, act=ACT_GELU)
+            return self.output.LayerNorm(F.dropout(self.output.dense(h), p_hid, True, residual=a))
         a = self.attention.output.LayerNorm(self.attention.output.dense(ctx, residual=x))
         h = self.intermediate.dense(a, act=ACT_GELU)
         return self.output.LayerNorm(self.output.dense(h, residual=a))
@@ -591,17 +591,17 @@ class CLIPEncoderLayer(D2RModule):
 
     def forward(self, x):
         at = self.self_attn
-        _check_dropout(at.p_drop, self.training, "attention_dropout")
-        bundle = _layer_bundle(self, x)
+        p_att = at.p_drop if self.training else 0.0  # attention_dropout (models/modeling_unimo.py:204), 0 by default
+        bundle = _layer_bundle(self, x) if p_att == 0.0 else None
         if bundle is not None:
             return F.encoder_layer(x, bundle)
         h = self.layer_norm1(x)
         d = x.shape[-1] // at.num_heads
         fz = at._fused_linear()
         if fz is not None:
-            ctx = F.attention_qkv(fz(h, self.cdtype), at.num_heads, d ** -0.5)
+            ctx = F.attention_qkv(fz(h, self.cdtype), at.num_heads, d ** -0.5, p_drop=p_att)
         else:
-            ctx = F.attention(at.q_proj(h), at.k_proj(h), at.v_proj(h), at.num_heads, d ** -0.5)
+            ctx = F.attention(at.q_proj(h), at.k_proj(h), at.v_proj(h), at.num_heads, d ** -0.5, p_drop=p_att)
         x = at.out_proj(ctx, residual=x)
         h = self.mlp.fc1(self.layer_norm2(x), act=ACT_QUICK_GELU)
         return self.mlp.fc2(h, residual=x)
@@ -655,10 +655,9 @@ class BertEmbeddings(D2RModule):
         self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
 
     def forward(self, input_ids, token_type_ids):
-        _check_dropout(self.p_drop, self.training, "hidden_dropout_prob")
         x = F.bert_embed(input_ids, token_type_ids, self.word_embeddings.weight, self.position_embeddings.weight,
                          self.token_type_embeddings.weight, self.cdtype)
-        return self.LayerNorm(x)
+        return F.dropout(self.LayerNorm(x), self.p_drop, self.training)  # models/modeling_unimo.py:329-330
 
 
 class UnimoEncoder(D2RModule):

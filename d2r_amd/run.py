@@ -70,6 +70,8 @@ def build_parser():
     p.add_argument("--image_size", default=224, type=int)
     p.add_argument("--patch_size", default=32, type=int)
     p.add_argument("--encoder_layers", default=12, type=int)
+    p.add_argument("--bert_dropout", default=0.1, type=float,
+                   help="hidden_dropout_prob = attention_probs_dropout_prob of the BERT config (bert-base default 0.1)")
     p.add_argument("--train_samples", default=512, type=int)
     p.add_argument("--eval_samples", default=128, type=int)
     p.add_argument("--num_workers", default=4, type=int)
@@ -108,8 +110,8 @@ def main(argv=None):
         return make_loader(ds, per_rank, shuffle, args.num_workers, drop_last=shuffle, sampler=sampler)
 
     train_dl, dev_dl, test_dl = loader(args.train_samples, 1, True), loader(args.eval_samples, 2, False), loader(args.eval_samples, 3, False)
-    # dropout 0: the HIP path has no dropout kernel yet
-    text_config = TextConfig(num_hidden_layers=args.encoder_layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    text_config = TextConfig(num_hidden_layers=args.encoder_layers, hidden_dropout_prob=args.bert_dropout,
+                             attention_probs_dropout_prob=args.bert_dropout)
     vision_config = VisionConfig(num_hidden_layers=args.encoder_layers, image_size=args.image_size, patch_size=args.patch_size)
     model = UnimoModelF(args=args, vision_config=vision_config, text_config=text_config, num_classes=args.num_classes)
     trainer = MSDTrainer(train_data=train_dl, dev_data=dev_dl, test_data=test_dl, model=model, args=args, logger=logger,

@@ -143,6 +143,10 @@ int d2r_muladd_bwd(int dtype, const void* a, const void* s, const void* dout, vo
 int d2r_lerp_fwd(int dtype, const void* g, const void* a, const void* b, void* out, int64_t n, void* stream);
 int d2r_lerp_bwd(int dtype, const void* g, const void* a, const void* b, const void* dout, void* dg, void* da,
                  void* db, int64_t n, void* stream);
+/* nn.Dropout (models/modeling_unimo.py:330,388,413,468): y[i] = keep(i) ? x[i] / (1-p) : 0, plus add[i] when add != NULL
+ * (the skip connection that follows the dropout in BertSelfOutput / BertOutput).  keep(i) is a pure function of
+ * (seed, i): the backward pass calls the same entry point on dy with the same seed — no mask is stored. */
+int d2r_dropout(int dtype, const void* x, const void* add, void* y, int64_t n, float p, uint64_t seed, void* stream);
 int d2r_add(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
 /* out[0] = sum_k h_coef[k] * x_k[0]  (n <= 8 fp32 device scalars): loss = CE - w1*JS1 - w2*JS2 */
 int d2r_lincomb(const float* const* h_x, const float* h_coef, int n, float* out, void* stream);

@@ -425,3 +425,72 @@ def test_encoder_layer_one_call_matches_op_by_op(gpu, kind):
     for n, p, o, k, _ in store.entries:
         r = float((g1[o:o + k] - g0[o:o + k]).norm() / (g0[o:o + k].norm() + 1e-3 * g0.norm()))  # floor: a key bias has a mathematically zero gradient
         assert r < 2e-2, (n, r)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dropout_kernel(gpu, dtype):
+    """nn.Dropout semantics: keep fraction 1-p, survivors scaled by 1/(1-p), residual add fused, mask = pure function
+    of (seed, index) so the backward regenerates it; new seed -> new mask; eval / p=0 -> identity."""
+    from d2r_amd import functional as F
+    torch.manual_seed(11)
+    x = (1.0 + torch.rand(7, 333, 77)).to(dtype).to(gpu).requires_grad_(True)  # odd sizes: scalar tail, all > 0
+    r = torch.randn(7, 333, 77).to(dtype).to(gpu).requires_grad_(True)
+    p = 0.1
+    y = F.dropout(x, p, True)
+    keep = y != 0
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p)) < 3e-3, frac
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
+    assert torch.allclose(y[keep].float(), x.detach()[keep].float() / (1 - p), rtol=tol)
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(x.grad != 0, keep & (g != 0))  # same mask in the backward
+    assert torch.allclose(x.grad[keep].float(), g[keep].float() / (1 - p), rtol=tol)
+    y2 = F.dropout(x, p, True)
+    assert not torch.equal(y2 != 0, keep), "every call must draw a fresh mask"
+    x.grad = None
+    z = F.dropout(x, p, True, residual=r)
+    z.backward(g)
+    assert torch.equal(r.grad, g)
+    assert float(((z - r).abs() > 1e-3).float().mean()) == pytest.approx(1 - p, abs=3e-3)
+    assert F.dropout(x, p, False) is x and F.dropout(x, 0.0, True) is x
+    torch.manual_seed(11)
+    a = F.dropout(x, p, True)
+    torch.manual_seed(11)
+    b = F.dropout(x, p, True)
+    assert torch.equal(a, b), "torch.manual_seed must restart the dropout stream"
+
+
+def test_bert_layer_with_dropout_backward_is_consistent(gpu, monkeypatch):
+    """BertLayer in train mode with hidden and attention-probability dropout 0.1 (the bert-base default): with the seed
+    stream frozen the layer is a deterministic function, so the analytic gradient must match a central finite
+    difference along a random direction (fp32 path)."""
+    from d2r_amd import functional as F
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig
+    torch.manual_seed(5)
+    layer = M.BertLayer(TextConfig(num_hidden_layers=1, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)).to(gpu)
+    layer.set_compute_dtype(torch.float32).train()
+    B, L = 2, 19
+    x0 = torch.randn(B, L, 768, device=gpu)
+    w = torch.randn(B, L, 768, device=gpu)
+    d = torch.randn(B, L, 768, device=gpu)
+    mask = torch.zeros(B, L, device=gpu)
+    mask[1, 12:] = -10000.0
+
+    def f(x):
+        seeds = iter(range(1000, 1100))
+        monkeypatch.setattr(F, "_next_dropout_seed", lambda: next(seeds))
+        return (layer(x, mask) * w).sum()
+
+    x = x0.clone().requires_grad_(True)
+    y = f(x)
+    y.backward()
+    analytic = float((x.grad * d).sum())
+    eps = 1e-2
+    with torch.no_grad():
+        numeric = float((f(x0 + eps * d) - f(x0 - eps * d)) / (2 * eps))
+    assert abs(analytic - numeric) <= 2e-2 * max(abs(analytic), abs(numeric), 1.0), (analytic, numeric)
+    layer.eval()
+    with torch.no_grad():
+        assert torch.equal(layer(x0, mask), layer(x0, mask)), "eval mode must not drop anything"
