@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=48)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="overlap bucketed grad all-reduce with backward")
+    ap.add_argument("--bert-dropout", type=float, default=0.0,
+                    help="hidden / attention-probability dropout of the BERT config (BASELINE.md section 3 benchmarks 0)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("D2R_BENCH_GRAPH", "0")),
                     help="1: replay the step from a captured hipGraph (fwd+bwd[+AdamW at N=1]); 0 (default): eager launches — measured faster on ROCm 7.2, see DESIGN.md")
     return ap.parse_args()
@@ -129,7 +131,8 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     torch.manual_seed(2023)  # reference default seed (run.py:49); identical replicas, then broadcast anyway
-    tc = TextConfig(num_hidden_layers=args.layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    tc = TextConfig(num_hidden_layers=args.layers, hidden_dropout_prob=args.bert_dropout,
+                    attention_probs_dropout_prob=args.bert_dropout)
     vc = VisionConfig(num_hidden_layers=args.layers, image_size=args.image_size, patch_size=args.patch)
     model = M.UnimoModelF(default_args(DR_step=args.dr_step), vc, tc)
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
@@ -235,8 +238,9 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: synthetic MVSA-Single shape, per-GPU batch %d, seq_len %d, %d image tokens, "
-                               "DR_step %d, %d+%d encoder layers, random-init weights, dropout 0; step = fwd+bwd+grad-allreduce+AdamW"
-                               % (args.batch, args.seq, (args.image_size // args.patch) ** 2 + 1, args.dr_step, args.layers, args.layers),
+                               "DR_step %d, %d+%d encoder layers, random-init weights, dropout %g; step = fwd+bwd+grad-allreduce+AdamW"
+                               % (args.batch, args.seq, (args.image_size // args.patch) ** 2 + 1, args.dr_step, args.layers, args.layers,
+                                  args.bert_dropout),
                    "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}"},
         "final_loss": round(loss_val, 5), "launch": "hipGraph replay" if args.graph else "eager",
         "host_enqueue_ms_per_step": round(host_ms, 3),
