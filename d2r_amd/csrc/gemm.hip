@@ -452,8 +452,15 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
   const int nk = d2r_cdiv(a.K, BK);
   if (batch == 1 && ws && nk >= 8) {
     const int64_t tiles = tile == 3 ? t128 : (tile == 2 ? t12864 : (tile == 1 ? t64 : (int64_t)d2r_cdiv(a.M, 32) * d2r_cdiv(a.N, 64)));
-    if (tiles < 256) {
-      int want = (int)((512 + tiles - 1) / tiles);
+    // Split so that ALL workgroups of the launch are resident at once: a partial second round of workgroups doubles
+    // the time of these short kernels.  128-row tiles run 2 workgroups per CU (VGPR-limited) -> 512 slots: 3072x768
+    // outputs (144 tiles) split 3 ways, not 4 (324 -> 385 TFLOP/s), 2304x768 (108 tiles) 4 ways, not 5 (249 -> 306).
+    // 64x64 tiles: the best measured split of the 768x768 weight gradients is 6 (864 workgroups); more splits only
+    // add slab traffic.  profiles/gemm_ab_r01_d.log.
+    static const int cap_small = env_int("D2R_SPLITK_CAP1", 896), cap_large = env_int("D2R_SPLITK_CAP3", 512);
+    const int64_t capacity = tile <= 1 ? cap_small : cap_large;
+    if (tiles < capacity) {
+      int want = (int)(capacity / tiles);
       if (want > 16) want = 16;
       if (want > nk / 2) want = nk / 2;
       while (want > 1 && (size_t)want * ((size_t)a.M * a.N + (a.dbias ? a.M : 0)) * sizeof(float) > ws_bytes) --want;
