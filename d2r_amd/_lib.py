@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("workspace", vp), ("workspace_bytes", sz),
         ("s_bias_b", i64),
         ("dbias", vp),
+        ("grad_ref", vp), ("grad_act", i32),
     ]
 
 

@@ -54,7 +54,8 @@ int fork_stream(void* stream, void* side) {
 // dx = dy W (+ residual);  gW += dy^T x, gb += colsum(dy).  The weight-gradient GEMM feeds nothing downstream in
 // the backward pass: with a side stream it is forked off BEFORE the dX GEMM and overlaps the rest of the chain.
 int linear_bwd(const d2r_encoder_layer_desc* L, int T, int N, int K, const void* dy, const void* x, const void* w,
-               void* dx, const void* dx_residual, float* gw, float* gb, void* stream) {
+               void* dx, const void* dx_residual, float* gw, float* gb, void* stream, const void* grad_ref = nullptr,
+               int grad_act = D2R_ACT_NONE) {
   void* wstream = stream;
   if (L->wgrad_stream && L->wgrad_stream != stream) {
     if (int rc = fork_stream(stream, L->wgrad_stream)) return rc;
@@ -65,6 +66,7 @@ int linear_bwd(const d2r_encoder_layer_desc* L, int T, int N, int K, const void*
   if (int rc = d2r_gemm(&gw_.d, wstream)) return rc;
   Gemm gx(L->dtype, D2R_GEMM_NN, T, K, N, dy, N, w, K, dx, K, L->dtype);
   gx.d.residual = dx_residual, gx.d.ldr = K;
+  gx.d.grad_ref = grad_ref, gx.d.grad_act = grad_act;  // dx = (dy W) * act'(grad_ref): the previous layer's act backward
   return d2r_gemm(&gx.d, stream);
 }
 
@@ -145,14 +147,12 @@ extern "C" int d2r_encoder_layer_bwd(const d2r_encoder_layer_desc* L, void* stre
   void* lnws = p;
   const size_t lnws_bytes = d2r_layernorm_bwd_workspace(T, E);
   const char* qkv = (const char*)L->qkv;
-  const int64_t n_f = (int64_t)T * F;
   if (!L->pre_ln) {
     // y = LN2(h2), h2 = n1 + ffn(n1), n1 = LN1(h1), h1 = x + attn(x)
     void *d_h2 = a0, *d_n1 = a1, *d_h1 = a2, *d_ctx = a3;
     (void)a4;
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, L->dy, L->h2, L->ln2_g, L->mean2, L->rstd2, T, E, d_h2, nullptr, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));
-    D2R_TRY(linear_bwd(L, T, E, F, d_h2, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream));
-    D2R_TRY(d2r_act_bwd(L->dtype, L->act, df, L->f_pre, df, n_f, stream));
+    D2R_TRY(linear_bwd(L, T, E, F, d_h2, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
     D2R_TRY(linear_bwd(L, T, F, E, df, L->n1, L->w_1, d_n1, d_h2, L->gw_1, L->gb_1, stream));  // ffn path + skip
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, d_h1, nullptr, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));
     D2R_TRY(linear_bwd(L, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
@@ -164,8 +164,7 @@ extern "C" int d2r_encoder_layer_bwd(const d2r_encoder_layer_desc* L, void* stre
     // y = h1 + ffn(h2), h2 = LN2(h1), h1 = x + attn(n1), n1 = LN1(x)
     void *d_h2 = a0, *d_h1 = a1, *d_ctx = a2, *d_n1 = a3;
     (void)a4;
-    D2R_TRY(linear_bwd(L, T, E, F, L->dy, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream));
-    D2R_TRY(d2r_act_bwd(L->dtype, L->act, df, L->f_pre, df, n_f, stream));
+    D2R_TRY(linear_bwd(L, T, E, F, L->dy, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
     D2R_TRY(linear_bwd(L, T, F, E, df, L->h2, L->w_1, d_h2, nullptr, L->gw_1, L->gb_1, stream));
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_h2, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, d_h1, L->dy, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // + skip
     D2R_TRY(linear_bwd(L, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));

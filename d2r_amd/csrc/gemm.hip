@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C);
     bf16_t* Pg = reinterpret_cast<bf16_t*>(g.P);
     const bf16_t* Rg = reinterpret_cast<const bf16_t*>(g.R);
+    const bf16_t* Gg = reinterpret_cast<const bf16_t*>(g.G);
 #pragma unroll
     for (int it = 0; it < WM * CPR / 64; ++it) {
       const int e = it * 64 + lane;
@@ -317,21 +318,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const int64_t ri = rz + (int64_t)row * g.ldr + col;
       if (col + 8 <= g.N) {
         if (Pg) st_pack<bf16_t, 8>(Pg + ci, pv);
-        Pack<bf16_t, 8> rv, cv, ov;
+        Pack<bf16_t, 8> rv, cv, ov, gv;
         if (Rg) rv = ld_pack<bf16_t, 8>(Rg + ri);
         if (g.beta != 0.f) cv = ld_pack<bf16_t, 8>(Cg + ci);
+        if (Gg) gv = ld_pack<bf16_t, 8>(Gg + ci);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           float v = act_apply(g.act, (float)pv.v[u]);
+          if (Gg) v *= act_grad(g.gact, (float)gv.v[u]);
           if (Rg) v += (float)rv.v[u];
           if (g.beta != 0.f) v += g.beta * (float)cv.v[u];
           ov.v[u] = (bf16_t)v;
         }
         st_pack<bf16_t, 8>(Cg + ci, ov);
       } else {
-        for (int u = 0; u < 8 && col + u < g.N; ++u) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // (fully unrolled: a runtime bound would index the packs dynamically -> scratch)
+          if (col + u >= g.N) break;
           if (Pg) Pg[ci + u] = pv.v[u];
           float v = act_apply(g.act, (float)pv.v[u]);
+          if (Gg) v *= act_grad(g.gact, (float)Gg[ci + u]);
           if (Rg) v += (float)Rg[ri + u];
           if (g.beta != 0.f) v += g.beta * (float)Cg[ci + u];
           Cg[ci + u] = (bf16_t)v;
@@ -382,6 +388,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
     float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f);
     if (g.P) store_c(g.P, g.c_dtype, ci, v);
     v = act_apply(g.act, v);
+    if (g.G) v *= act_grad(g.gact, load_c(g.G, g.c_dtype, ci));
     if (g.R) v += load_c(g.R, g.c_dtype, (int64_t)m * g.ldr + n);
     if (g.beta != 0.f) v += g.beta * load_c(g.C, g.c_dtype, ci);
     store_c(g.C, g.c_dtype, ci, v);
@@ -418,13 +425,14 @@ template <typename T, int LAYOUT>
 static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t ws_bytes) {
   if constexpr (sizeof(T) == 2) {
     // large bf16 shapes: LDS-DMA pipelined 128xBN kernel (forced with tile 4 = 128x128, 5 = 128x64 for A/B runs)
-    const int64_t t128 = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 128);
-    const int64_t t64 = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 64);
     int bn = 0;
     if (g_tile == 4) bn = 128;
     else if (g_tile == 5) bn = 64;
-    else if (g_tile < 0 && g_glds && a.K >= 2048 && !a.dbias) bn = t64 >= 256 ? 64 : 0;  // measured: only the K=3072 shapes win
-    if (a.dbias) bn = 0;  // the bias-gradient side product lives in the generic kernel
+    // measured (profiles/gemm_ab_r01_e.log): the 128x64 LDS-DMA kernel beats the register-staged 64x64 tiles on every
+    // NT / NN shape of the workload (351 vs 275, 548 vs 422, 616 vs 343 TFLOP/s ...); weight-gradient GEMMs that carry
+    // the bias-gradient side product stay on the generic kernel
+    else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN) bn = 64;
+    if (a.dbias) bn = 0;
     if (bn) {
       GemmArgs b = a;
       b.ws = nullptr; b.splits = 1; b.tiles_per_split = 0;
@@ -444,6 +452,10 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
   else if (LAYOUT == D2R_GEMM_TN && batch == 1) tile = ((int64_t)a.M * a.N >= 1500000) ? 3 : 1;  // gemm_ab_r01_c.log
   else tile = 1;
   if (g_tile >= 0 && g_tile <= 3 && a.M > 32) tile = g_tile;
+  if (a.G) {  // the activation-gradient epilogue exists in the LDS-staged (vectorised, bf16) epilogue of the small tiles only
+    if (!a.vecC || a.c_dtype != D2R_BF16) return d2r_fail(D2R_ERR_INVALID, "d2r_gemm: grad_ref needs a bf16 output with 16-byte aligned rows");
+    if (tile > 1) tile = 1;
+  }
   if (tile > 1) a.vecC = 0;  // the LDS-staged epilogue only pays on the small tiles (register pressure on the large ones)
   // deterministic split-K for reduction-heavy GEMMs with few output tiles (weight gradients)
   a.splits = 1;
@@ -523,6 +535,9 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd;
   D2R_REQUIRE(!d->dbias || (d->layout == D2R_GEMM_TN && d->nb * d->nh == 1), "d2r_gemm: dbias needs the TN layout and batch 1");
   a.dbias = d->dbias;
+  D2R_REQUIRE(!d->grad_ref || d->nb * d->nh == 1, "d2r_gemm: grad_ref needs batch 1");
+  a.G = d->grad_ref;
+  a.gact = d->grad_act;
   const int64_t es = (int64_t)d2r_esize(d->dtype);
   auto vec_ok = [&](const void* p, int64_t ld, int64_t sb, int64_t sh) {
     return d2r_aligned16(p) && (ld * es) % 16 == 0 && (sb * es) % 16 == 0 && (sh * es) % 16 == 0;
@@ -535,6 +550,7 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
       return !p || (d2r_aligned16(p) && (ld * cs) % 16 == 0 && (sb * cs) % 16 == 0 && (sh * cs) % 16 == 0);
     };
     a.vecC = (g_vepi && cvec(d->C, d->ldc, d->sCb, d->sCh) && cvec(d->preact, d->ldc, d->sCb, d->sCh) &&
+              cvec(d->grad_ref, d->ldc, d->sCb, d->sCh) &&
               cvec(d->residual, d->ldr, d->sRb, d->sRh)) ? 1 : 0;
   }
   const int batch = d->nb * d->nh;

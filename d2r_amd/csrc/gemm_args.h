@@ -16,6 +16,8 @@ struct GemmArgs {
   void* P;
   float* ws;  // split-K partial slabs [splits][M][N] (fp32), then [splits][M] bias-gradient partials; or null
   float* dbias;  // TN only: dbias[m] += sum_k A[k,m]
+  const void* G;  // optional [M,N] (layout of C): the result is multiplied by act_grad(gact, G[m,n])
+  int gact;
   int M, N, K, nh, splits, tiles_per_split;
   int64_t lda, ldb, ldc, ldr;
   int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh, sBiasB;

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C);
     bf16_t* Pg = reinterpret_cast<bf16_t*>(g.P);
     const bf16_t* Rg = reinterpret_cast<const bf16_t*>(g.R);
+    const bf16_t* Gg = reinterpret_cast<const bf16_t*>(g.G);
 #pragma unroll
     for (int it = 0; it < WM * CPR / 64; ++it) {
       const int e = it * 64 + lane;
@@ -179,21 +180,26 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
       const int64_t ri = (int64_t)row * g.ldr + col;
       if (col + 8 <= g.N) {
         if (Pg) st_pack<bf16_t, 8>(Pg + ci, pv);
-        Pack<bf16_t, 8> rv, cv, ov;
+        Pack<bf16_t, 8> rv, cv, ov, gv;
         if (Rg) rv = ld_pack<bf16_t, 8>(Rg + ri);
         if (g.beta != 0.f) cv = ld_pack<bf16_t, 8>(Cg + ci);
+        if (Gg) gv = ld_pack<bf16_t, 8>(Gg + ci);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           float v = act_apply(g.act, (float)pv.v[u]);
+          if (Gg) v *= act_grad(g.gact, (float)gv.v[u]);
           if (Rg) v += (float)rv.v[u];
           if (g.beta != 0.f) v += g.beta * (float)cv.v[u];
           ov.v[u] = (bf16_t)v;
         }
         st_pack<bf16_t, 8>(Cg + ci, ov);
       } else {
-        for (int u = 0; u < 8 && col + u < g.N; ++u) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // (fully unrolled: a runtime bound would index the packs dynamically -> scratch)
+          if (col + u >= g.N) break;
           if (Pg) Pg[ci + u] = pv.v[u];
           float v = act_apply(g.act, (float)pv.v[u]);
+          if (Gg) v *= act_grad(g.gact, (float)Gg[ci + u]);
           if (Rg) v += (float)Rg[ri + u];
           if (g.beta != 0.f) v += g.beta * (float)Cg[ci + u];
           Cg[ci + u] = (bf16_t)v;
@@ -240,6 +246,7 @@ static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st) {
   if (batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
   if (!a.vecA || !a.vecB) return 0;
+  if (a.G && !(a.vecC && a.c_dtype == D2R_BF16)) return 0;  // the activation-gradient epilogue is in the vectorised path only
   const bool a_strided = layout == D2R_GEMM_TN, b_strided = layout != D2R_GEMM_NT;
   if ((a_strided && a.M % 8 != 0) || (b_strided && a.N % 8 != 0)) return 0;
   switch (layout) {

@@ -91,6 +91,11 @@ typedef struct {
    * layer computed inside its weight-gradient GEMM (dW = dY^T X reads dY anyway), replacing a separate column-sum
    * launch.  NULL disables. */
   float* dbias;
+  /* optional, batch == 1: the result (after bias / act) is multiplied elementwise by d act(grad_act) evaluated at
+   * grad_ref[m,n] (dtype and leading dimension of C; the pre-activation for gelu / quick_gelu, the activation
+   * output for relu / tanh / sigmoid) — the activation backward of the PREVIOUS linear fused into this dX GEMM. */
+  const void* grad_ref;
+  int grad_act;
 } d2r_gemm_desc;
 
 int d2r_gemm(const d2r_gemm_desc* d, void* stream);
