@@ -117,6 +117,7 @@ class D2RError(RuntimeError):
 
 
 _lib = None
+_FN = {}  # name -> bound foreign function (filled by load(); one dict lookup per launch instead of two getattr)
 
 
 def load():
@@ -133,6 +134,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch; let it propagate
         fn.restype = res
         fn.argtypes = args
+        _FN[name] = fn
     _lib = lib
     return lib
 
@@ -178,7 +180,11 @@ _timer = None
 
 def call(name: str, *args, meta=None):
     if _timer is None:
-        rc = getattr(load(), name)(*args)
+        fn = _FN.get(name)
+        if fn is None:
+            load()
+            fn = _FN[name]
+        rc = fn(*args)
     else:
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
