@@ -52,6 +52,8 @@ SIGNATURES = {
     "d2r_last_error": (C.c_char_p, []),
     "d2r_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "d2r_gemm_tuning": (None, [i32, i32, i32]),
+    "d2r_gemm_tn_grouped": (i32, [i32, i32, i32, i32, i64, i64, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                  C.POINTER(vp), i32, f32, vp]),
     "d2r_softmax_fwd": (i32, [i32, i32, vp, vp, i64, i64, i32, f32, vp, i64, vp]),
     "d2r_softmax_bwd": (i32, [i32, i32, vp, vp, vp, i64, i64, i32, f32, vp]),
     "d2r_mha_supported": (i32, [i32, i32, i32, i32]),

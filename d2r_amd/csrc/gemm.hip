@@ -20,8 +20,8 @@
 
 #include "gemm_args.h"
 
-template <typename T, int LAYOUT, int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+template <typename T, int LAYOUT, int BM, int BN, int WAVES_M, int WAVES_N, int NBUF, bool GROUPED = false>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
   constexpr bool IS_BF16 = sizeof(T) == 2;
   constexpr int BK = IS_BF16 ? 64 : 16;
   constexpr int VEC = 16 / sizeof(T);
@@ -62,6 +62,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int zb = z / g.nh, zh = z % g.nh;
   const T* A = reinterpret_cast<const T*>(g.A) + zb * g.sAb + zh * g.sAh;
   const T* B = reinterpret_cast<const T*>(g.B) + zb * g.sBb + zh * g.sBh;
+  if constexpr (GROUPED) {  // problem z has its own operands (same shape and leading dimensions)
+    A = reinterpret_cast<const T*>(grp.A[z]);
+    B = reinterpret_cast<const T*>(grp.B[z]);
+    g.C = grp.C[z];
+    g.dbias = grp.dbias[z];
+  }
   const bool vecA = g.vecA != 0, vecB = g.vecB != 0;
 
   Pack<T, VEC> ra[IT_A], rb[IT_B];
@@ -414,8 +420,9 @@ extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
 template <typename T, int LAYOUT, int BM, int BN, int WM_, int WN_>
 static void launch_tile(const GemmArgs& a, int gz, hipStream_t st) {
   dim3 grid(d2r_cdiv(a.N, BN), d2r_cdiv(a.M, BM), gz);
-  if (g_nbuf == 2) hipLaunchKernelGGL((gemm_kernel<T, LAYOUT, BM, BN, WM_, WN_, 2>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gemm_kernel<T, LAYOUT, BM, BN, WM_, WN_, 1>), grid, dim3(256), 0, st, a);
+  static const GemmGroup no_group = {};
+  if (g_nbuf == 2) hipLaunchKernelGGL((gemm_kernel<T, LAYOUT, BM, BN, WM_, WN_, 2>), grid, dim3(256), 0, st, a, no_group);
+  else hipLaunchKernelGGL((gemm_kernel<T, LAYOUT, BM, BN, WM_, WN_, 1>), grid, dim3(256), 0, st, a, no_group);
 }
 
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st);  // gemm_glds.hip
@@ -557,4 +564,51 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == D2R_BF16) return launch_dtype<bf16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
   return launch_dtype<float>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
+}
+
+// ---- grouped weight gradients -------------------------------------------------------------------------------
+// `count` TN GEMMs of ONE shape, C_i (fp32) = beta * C_i + A_i^T B_i (+ dbias_i[m] += sum_k A_i[k,m]), in launches of up
+// to 16 problems (blockIdx.z = problem).  A 768x768 weight gradient alone has 144 output tiles and needs split-K,
+// fp32 slabs and a reduce launch to fill the chip (175 TFLOP/s); sixteen of them give 2304 workgroups that each
+// run the whole reduction (356 TFLOP/s, profiles/gemm_grouped_r01.log).  Nothing in the backward pass reads a weight
+// gradient, so the caller may defer these products and launch them together.
+template <typename T>
+static int launch_grouped_tn(const GemmArgs& base, const void* const* A, const void* const* B, float* const* C,
+                             float* const* dbias, int count, hipStream_t st) {
+  for (int first = 0; first < count; first += D2R_GEMM_GROUP_MAX) {
+    const int n = count - first < D2R_GEMM_GROUP_MAX ? count - first : D2R_GEMM_GROUP_MAX;
+    GemmGroup grp = {};
+    for (int i = 0; i < n; ++i) {
+      grp.A[i] = A[first + i], grp.B[i] = B[first + i], grp.C[i] = C[first + i];
+      grp.dbias[i] = dbias ? dbias[first + i] : nullptr;
+    }
+    GemmArgs a = base;
+    a.dbias = dbias ? reinterpret_cast<float*>(1) : nullptr;  // per-problem pointer substituted in the kernel; non-null enables the path
+    dim3 grid(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 64), n);
+    hipLaunchKernelGGL((gemm_kernel<T, D2R_GEMM_TN, 64, 64, 2, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
+    if (int rc = d2r_check_launch("d2r_gemm_tn_grouped")) return rc;
+  }
+  return D2R_OK;
+}
+
+extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                                   const void* const* h_A, const void* const* h_B, float* const* h_C,
+                                   float* const* h_dbias, int count, float beta, void* stream) {
+  D2R_REQUIRE(h_A && h_B && h_C && count >= 0, "d2r_gemm_tn_grouped: null pointer array");
+  D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_gemm_tn_grouped: bad dtype %d", dtype);
+  D2R_REQUIRE(M >= 1 && N >= 1 && K >= 0 && lda >= M && ldb >= N && ldc >= N, "d2r_gemm_tn_grouped: bad shape");
+  if (count == 0) return D2R_OK;
+  const int64_t es = (int64_t)d2r_esize(dtype);
+  GemmArgs a = {};
+  a.M = M, a.N = N, a.K = K, a.nh = 1, a.splits = 1, a.lda = lda, a.ldb = ldb, a.ldc = ldc;
+  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.xcd = 0, a.grouped = 1;
+  a.vecA = (lda * es) % 16 == 0, a.vecB = (ldb * es) % 16 == 0, a.vecC = 0;
+  for (int i = 0; i < count; ++i) {
+    D2R_REQUIRE(h_A[i] && h_B[i] && h_C[i] && (!h_dbias || h_dbias[i]), "d2r_gemm_tn_grouped: null operand in problem %d", i);
+    a.vecA &= d2r_aligned16(h_A[i]) ? 1 : 0;
+    a.vecB &= d2r_aligned16(h_B[i]) ? 1 : 0;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == D2R_BF16) return launch_grouped_tn<bf16_t>(a, h_A, h_B, h_C, h_dbias, count, st);
+  return launch_grouped_tn<float>(a, h_A, h_B, h_C, h_dbias, count, st);
 }

@@ -7,6 +7,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Grouped mode (weight-gradient GEMMs of identical shape deferred and launched together): operand pointers of problem
+// z = blockIdx.z, passed by value so that the launch needs no host-to-device copy and can be captured into a hipGraph.
+constexpr int D2R_GEMM_GROUP_MAX = 16;
+struct GemmGroup {
+  const void* A[D2R_GEMM_GROUP_MAX];
+  const void* B[D2R_GEMM_GROUP_MAX];
+  void* C[D2R_GEMM_GROUP_MAX];
+  float* dbias[D2R_GEMM_GROUP_MAX];
+};
+
 struct GemmArgs {
   const void* A;
   const void* B;
@@ -18,6 +28,7 @@ struct GemmArgs {
   float* dbias;  // TN only: dbias[m] += sum_k A[k,m]
   const void* G;  // optional [M,N] (layout of C): the result is multiplied by act_grad(gact, G[m,n])
   int gact;
+  int grouped;  // != 0: per-problem pointers come from the GemmGroup kernel argument
   int M, N, K, nh, splits, tiles_per_split;
   int64_t lda, ldb, ldc, ldr;
   int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh, sBiasB;

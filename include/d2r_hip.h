@@ -99,6 +99,15 @@ typedef struct {
 } d2r_gemm_desc;
 
 int d2r_gemm(const d2r_gemm_desc* d, void* stream);
+/* `count` weight-gradient GEMMs of ONE shape in launches of up to 16 problems:
+ *   C_i[M,N] (fp32, ldc) = beta * C_i + A_i^T B_i,   A_i [K,M] (lda), B_i [K,N] (ldb) of dtype;   dbias_i[m] += sum_k A_i[k,m]
+ * h_A / h_B / h_C / h_dbias are HOST arrays of device pointers (h_dbias may be NULL).  Replaces `count` d2r_gemm TN
+ * calls (dW = dY^T X of the 768x768 linears in models/Cells.py, Refinement.py, SelfAttention.py, XModules.py) that
+ * each needed split-K slabs and a reduce launch to fill the chip; the caller defers them, nothing in the backward
+ * pass reads a weight gradient.  Deterministic. */
+int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const void* const* h_A,
+                        const void* const* h_B, float* const* h_C, float* const* h_dbias, int count, float beta,
+                        void* stream);
 /* tuning switches for A/B measurements (tests/bench_gemm.py): LDS buffers (1|2), vectorised bf16 epilogue (0|1),
  * forced tile (-1 auto, 1: 64x64, 2: 128x64, 3: 128x128).  Defaults are the measured winners. */
 void d2r_gemm_tuning(int nbuf, int vepi, int tile);

@@ -494,3 +494,25 @@ def test_bert_layer_with_dropout_backward_is_consistent(gpu, monkeypatch):
     layer.eval()
     with torch.no_grad():
         assert torch.equal(layer(x0, mask), layer(x0, mask)), "eval mode must not drop anything"
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_grouped_weight_gradient_gemm(gpu, dtype):
+    """d2r_gemm_tn_grouped: 19 same-shape dW = dY^T X problems (two launches: 16 + 3) with bias-gradient side product and
+    accumulation into pre-filled sinks, against torch."""
+    from d2r_amd import _lib
+    from d2r_amd.functional import _parr, _stream
+    n, T, N, K = 19, 300, 136, 72
+    gs = [rnd(T, N, seed=i).to(dtype).to(gpu) for i in range(n)]
+    xs = [rnd(T, K, seed=100 + i).to(dtype).to(gpu) for i in range(n)]
+    sinks = [rnd(N, K, seed=200 + i).to(gpu) for i in range(n)]
+    bsinks = [rnd(N, seed=300 + i).to(gpu) for i in range(n)]
+    want_w = [s.double() + g.double().t() @ x.double() for s, g, x in zip(sinks, gs, xs)]
+    want_b = [b.double() + g.double().sum(0) for b, g in zip(bsinks, gs)]
+    dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    _lib.call("d2r_gemm_tn_grouped", dt, N, K, T, N, K, K, _parr(gs), _parr(xs), _parr(sinks), _parr(bsinks), n, 1.0, _stream())
+    torch.cuda.synchronize()
+    for i in range(n):
+        scale = float(want_w[i].abs().max())
+        assert float((sinks[i].double() - want_w[i]).abs().max()) <= 1e-5 * scale + 1e-6, i
+        assert float((bsinks[i].double() - want_b[i]).abs().max()) <= 1e-5 * float(want_b[i].abs().max()) + 1e-6, i
