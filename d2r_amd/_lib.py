@@ -43,7 +43,8 @@ class EncoderLayerDesc(C.Structure):
                                      "gw_qkv", "gw_o", "gw_1", "gw_2", "gb_qkv", "gb_o", "gb_1", "gb_2", "gln1_g", "gln1_b",
                                      "gln2_g", "gln2_b", "x", "y", "qkv", "ctx", "h1", "n1", "f_pre", "f", "h2", "lse",
                                      "mean1", "rstd1", "mean2", "rstd2", "dy", "dx", "scratch")]
-                + [("scratch_bytes", sz), ("splitk_ws", vp), ("splitk_bytes", sz), ("wgrad_stream", vp)])
+                + [("scratch_bytes", sz), ("splitk_ws", vp), ("splitk_bytes", sz), ("wgrad_stream", vp),
+                   ("defer_wgrad", i32), ("o_dy", vp * 4)])
 
 
 # name -> (restype, argtypes); every symbol include/d2r_hip.h declares

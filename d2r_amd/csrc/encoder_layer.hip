@@ -53,9 +53,16 @@ int fork_stream(void* stream, void* side) {
 
 // dx = dy W (+ residual);  gW += dy^T x, gb += colsum(dy).  The weight-gradient GEMM feeds nothing downstream in
 // the backward pass: with a side stream it is forked off BEFORE the dX GEMM and overlaps the rest of the chain.
-int linear_bwd(const d2r_encoder_layer_desc* L, int T, int N, int K, const void* dy, const void* x, const void* w,
+int linear_bwd(d2r_encoder_layer_desc* L, int which, int T, int N, int K, const void* dy, const void* x, const void* w,
                void* dx, const void* dx_residual, float* gw, float* gb, void* stream, const void* grad_ref = nullptr,
                int grad_act = D2R_ACT_NONE) {
+  L->o_dy[which] = dy;  // reported to the caller (deferred weight gradients need it)
+  if (L->defer_wgrad) {  // the caller launches dW / db later, grouped with the same product of other layers
+    Gemm gx(L->dtype, D2R_GEMM_NN, T, K, N, dy, N, w, K, dx, K, L->dtype);
+    gx.d.residual = dx_residual, gx.d.ldr = K;
+    gx.d.grad_ref = grad_ref, gx.d.grad_act = grad_act;
+    return d2r_gemm(&gx.d, stream);
+  }
   void* wstream = stream;
   if (L->wgrad_stream && L->wgrad_stream != stream) {
     if (int rc = fork_stream(stream, L->wgrad_stream)) return rc;
@@ -126,7 +133,7 @@ extern "C" int d2r_encoder_layer_fwd(const d2r_encoder_layer_desc* L, void* stre
   return D2R_OK;
 }
 
-extern "C" int d2r_encoder_layer_bwd(const d2r_encoder_layer_desc* L, void* stream) {
+extern "C" int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* L, void* stream) {
   D2R_TRY(check_desc(L, "d2r_encoder_layer_bwd"));
   D2R_REQUIRE(L->dy && L->dx && L->gw_qkv && L->gw_o && L->gw_1 && L->gw_2 && L->gb_qkv && L->gb_o && L->gb_1 && L->gb_2 &&
                   L->gln1_g && L->gln1_b && L->gln2_g && L->gln2_b, "d2r_encoder_layer_bwd: null gradient pointer");
@@ -152,26 +159,26 @@ extern "C" int d2r_encoder_layer_bwd(const d2r_encoder_layer_desc* L, void* stre
     void *d_h2 = a0, *d_n1 = a1, *d_h1 = a2, *d_ctx = a3;
     (void)a4;
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, L->dy, L->h2, L->ln2_g, L->mean2, L->rstd2, T, E, d_h2, nullptr, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));
-    D2R_TRY(linear_bwd(L, T, E, F, d_h2, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
-    D2R_TRY(linear_bwd(L, T, F, E, df, L->n1, L->w_1, d_n1, d_h2, L->gw_1, L->gb_1, stream));  // ffn path + skip
+    D2R_TRY(linear_bwd(L, 3, T, E, F, d_h2, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
+    D2R_TRY(linear_bwd(L, 2, T, F, E, df, L->n1, L->w_1, d_n1, d_h2, L->gw_1, L->gb_1, stream));  // ffn path + skip
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, d_h1, nullptr, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));
-    D2R_TRY(linear_bwd(L, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
+    D2R_TRY(linear_bwd(L, 1, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
     D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
                         L->mask, L->lse, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
                         L->L, L->L, dh, L->scale, stream));
-    D2R_TRY(linear_bwd(L, T, 3 * E, E, dqkv, L->x, L->w_qkv, L->dx, d_h1, L->gw_qkv, L->gb_qkv, stream));  // + skip
+    D2R_TRY(linear_bwd(L, 0, T, 3 * E, E, dqkv, L->x, L->w_qkv, L->dx, d_h1, L->gw_qkv, L->gb_qkv, stream));  // + skip
   } else {
     // y = h1 + ffn(h2), h2 = LN2(h1), h1 = x + attn(n1), n1 = LN1(x)
     void *d_h2 = a0, *d_h1 = a1, *d_ctx = a2, *d_n1 = a3;
     (void)a4;
-    D2R_TRY(linear_bwd(L, T, E, F, L->dy, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
-    D2R_TRY(linear_bwd(L, T, F, E, df, L->h2, L->w_1, d_h2, nullptr, L->gw_1, L->gb_1, stream));
+    D2R_TRY(linear_bwd(L, 3, T, E, F, L->dy, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
+    D2R_TRY(linear_bwd(L, 2, T, F, E, df, L->h2, L->w_1, d_h2, nullptr, L->gw_1, L->gb_1, stream));
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_h2, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, d_h1, L->dy, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // + skip
-    D2R_TRY(linear_bwd(L, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
+    D2R_TRY(linear_bwd(L, 1, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
     D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
                         L->mask, L->lse, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
                         L->L, L->L, dh, L->scale, stream));
-    D2R_TRY(linear_bwd(L, T, 3 * E, E, dqkv, L->n1, L->w_qkv, d_n1, nullptr, L->gw_qkv, L->gb_qkv, stream));
+    D2R_TRY(linear_bwd(L, 0, T, 3 * E, E, dqkv, L->n1, L->w_qkv, d_n1, nullptr, L->gw_qkv, L->gb_qkv, stream));
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->x, L->ln1_g, L->mean1, L->rstd1, T, E, L->dx, d_h1, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // + skip
   }
   return D2R_OK;

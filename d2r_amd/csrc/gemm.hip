@@ -52,9 +52,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   int tile_m, tile_n;
-  xcd_tile(g.xcd, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
   int z = blockIdx.z, split = 0;
+  if constexpr (GROUPED) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
+  else xcd_tile(g.xcd, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (g.splits > 1) {
     split = z;
     z = 0;
@@ -601,7 +602,7 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
   const int64_t es = (int64_t)d2r_esize(dtype);
   GemmArgs a = {};
   a.M = M, a.N = N, a.K = K, a.nh = 1, a.splits = 1, a.lda = lda, a.ldb = ldb, a.ldc = ldc;
-  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.xcd = 0, a.grouped = 1;
+  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.xcd = g_xcd, a.grouped = 1;
   a.vecA = (lda * es) % 16 == 0, a.vecB = (ldb * es) % 16 == 0, a.vecC = 0;
   for (int i = 0; i < count; ++i) {
     D2R_REQUIRE(h_A[i] && h_B[i] && h_C[i] && (!h_dbias || h_dbias[i]), "d2r_gemm_tn_grouped: null operand in problem %d", i);

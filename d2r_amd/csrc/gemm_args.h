@@ -64,6 +64,21 @@ __device__ __forceinline__ void xcd_tile(int enable, int& tile_m, int& tile_n) {
   tile_n = id - tile_m * gx;
 }
 
+// The same remap over a 3-D grid (z = problem of a grouped launch): every XCD gets a contiguous run of (z, tile_m,
+// tile_n), i.e. whole problems, so a problem's operand panels are fetched into ONE L2 instead of eight.
+__device__ __forceinline__ void xcd_tile_3d(int enable, int& tile_m, int& tile_n, int& z) {
+  const int gx = gridDim.x, gxy = gridDim.x * gridDim.y, nwg = gxy * gridDim.z;
+  int id = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+  if (enable && nwg >= 16) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  z = id / gxy;
+  const int rem = id - z * gxy;
+  tile_m = rem / gx;
+  tile_n = rem - tile_m * gx;
+}
+
 __device__ __forceinline__ void store_c(void* C, int c_dtype, int64_t idx, float v) {
   if (c_dtype == D2R_BF16) reinterpret_cast<bf16_t*>(C)[idx] = (bf16_t)v;
   else reinterpret_cast<float*>(C)[idx] = v;

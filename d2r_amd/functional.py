@@ -105,33 +105,47 @@ def wgrad_streams():
 DEFER_WGRAD = os.environ.get("D2R_DEFER_WGRAD", "1") != "0"
 _WGRAD_Q = {}  # stream handle -> {"stream": torch stream, "jobs": {shape key: [job, ...]}}
 _WGRAD_FLUSH_AT = 16
+D2R_LAYER_GROUP = int(os.environ.get("D2R_LAYER_GROUP", "6"))  # encoder layers per grouped launch of their (large) weight gradients
+# (measured at C2: 1 -> 32.6 ms/step, 2 -> 31.7, 4 / 6 / 13 -> 31.3-31.5; six keeps at most ~0.7 GB of scratch alive)
 
 
 def _defer_wgrad(g, x, lda_x, sink, bsink, N, K, M, w_master, bias):
     """Queue dW[N,K] += g[M,N]^T x[M,K] (and db[N] += colsum g) on the current stream."""
+    _defer_wgrad_raw(_dt(x), N, K, M, lda_x, g.data_ptr(), x.data_ptr(), sink.data_ptr(),
+                     None if bsink is None else bsink.data_ptr(), (w_master, bias), (g, x))
+
+
+def _defer_wgrad_raw(dt, N, K, M, lda_x, g_ptr, x_ptr, sink_ptr, bsink_ptr, params, keepalive, flush_at=None):
     cur = torch.cuda.current_stream()
     q = _WGRAD_Q.get(cur.cuda_stream)
     if q is None:
         q = _WGRAD_Q[cur.cuda_stream] = {"stream": cur, "jobs": {}}
-    key = (_dt(x), N, K, M, lda_x, bsink is not None)
+    key = (dt, N, K, M, lda_x, bsink_ptr is not None)
     jobs = q["jobs"].setdefault(key, [])
-    jobs.append((g, x, sink, bsink, w_master, bias))  # the tensors stay alive until the group is launched
-    if len(jobs) >= _WGRAD_FLUSH_AT:
+    jobs.append((g_ptr, x_ptr, sink_ptr, bsink_ptr, params, keepalive))  # keepalive: tensors the launch will read
+    if len(jobs) >= (flush_at or _WGRAD_FLUSH_AT):
         _flush_wgrad_group(key, q["jobs"].pop(key))
+
+
+def _iparr(ptrs):
+    arr = (C.c_void_p * len(ptrs))()
+    for i, v in enumerate(ptrs):
+        arr[i] = v
+    return arr
 
 
 def _flush_wgrad_group(key, jobs):
     dt, N, K, M, lda_x, has_b = key
     n = len(jobs)
-    A, B, Cc = _parr([j[0] for j in jobs]), _parr([j[1] for j in jobs]), _parr([j[2] for j in jobs])
-    D = _parr([j[3] for j in jobs]) if has_b else None
+    A, B, Cc = _iparr([j[0] for j in jobs]), _iparr([j[1] for j in jobs]), _iparr([j[2] for j in jobs])
+    D = _iparr([j[3] for j in jobs]) if has_b else None
     meta = None
     if _lib._timer is not None:
         meta = dict(group=f"gemm_{'bf16' if dt == BF16 else 'f32'}_TN", flops=2.0 * n * M * N * K,
                     bytes=float(n) * ((M * N + M * K) * (2 if dt == BF16 else 4) + 2 * N * K * 4))
     _lib.call("d2r_gemm_tn_grouped", dt, N, K, M, N, lda_x, K, A, B, Cc, D, n, 1.0, _stream(), meta=meta)
     for j in jobs:  # data-parallel bucket readiness (d2r_amd.dp)
-        for p in (j[4], j[5]):
+        for p in j[4]:
             cb = getattr(p, "_d2r_ready_cb", None) if p is not None else None
             if cb is not None:
                 cb(p)
@@ -761,7 +775,13 @@ class _EncoderLayer(torch.autograd.Function):
         dx = torch.empty_like(g)
         need = _lib.load().d2r_encoder_layer_bwd_scratch(d.B, d.L, d.E, d.F)
         side = wgrad_side_stream_handle()
-        if side is None:
+        defer = DEFER_WGRAD and side is None
+        d.defer_wgrad = int(defer)
+        if defer:  # the four weight gradients are launched later, grouped with the other layers': scratch must survive
+            scratch = torch.empty(need, dtype=torch.uint8, device=g.device)
+            ws = _workspace(64 << 20, g.device)
+            d.wgrad_stream = None
+        elif side is None:
             scratch = _layer_scratch(need, g.device)
             ws = _workspace(64 << 20, g.device)
             d.wgrad_stream = None
@@ -775,8 +795,21 @@ class _EncoderLayer(torch.autograd.Function):
         d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
         d.splitk_ws, d.splitk_bytes = ws.data_ptr(), ws.numel()
         _lib.call("d2r_encoder_layer_bwd", C.byref(d), _stream(), meta=dict(group="encoder_layer_bwd"))
+        if defer:
+            T, E, Fi = d.B * d.L, d.E, d.F
+            keep = (scratch, g, x, ctx.keep[0])
+            P = bundle.params  # (w, b) of qkv, o, fc1, fc2, then the LayerNorm pairs
+            attn_in = d.n1 if d.pre_ln else d.x
+            ffn_in = d.h2 if d.pre_ln else d.n1
+            for which, (N, K, xin, gw, gb) in enumerate(((3 * E, E, attn_in, d.gw_qkv, d.gb_qkv), (E, E, d.ctx, d.gw_o, d.gb_o),
+                                                          (Fi, E, ffn_in, d.gw_1, d.gb_1), (E, Fi, d.f, d.gw_2, d.gb_2))):
+                _defer_wgrad_raw(BF16, N, K, T, K, d.o_dy[which], xin, gw, gb, (P[2 * which], P[2 * which + 1]), keep,
+                                 flush_at=D2R_LAYER_GROUP)
+            ready = bundle.params[8:]  # LayerNorm gradients were accumulated inside the call
+        else:
+            ready = bundle.params
         ctx.keep = None
-        for p in bundle.params:  # data-parallel bucket readiness (d2r_amd.dp)
+        for p in ready:  # data-parallel bucket readiness (d2r_amd.dp)
             cb = getattr(p, "_d2r_ready_cb", None)
             if cb is not None:
                 cb(p)

@@ -315,10 +315,16 @@ typedef struct {
    * call; the caller joins it before anything reads the gradient sinks, and keeps x, the saved activations, dy and
    * scratch alive until it has drained.  NULL: everything on `stream`. */
   void* wgrad_stream;
+  /* bwd: != 0 skips the four weight-gradient GEMMs (and bias gradients); the caller launches them later, grouped with
+   * the same products of other layers (d2r_gemm_tn_grouped), from o_dy[] and the saved activations. */
+  int defer_wgrad;
+  /* bwd, written by the call: the output gradients of the qkv / out / fc1 / fc2 linears ([T,3E] [T,E] [T,F] [T,E], inside
+   * `scratch` or dy itself) — dW = o_dy^T x with x = x|n1, ctx, n1|h2, f. */
+  const void* o_dy[4];
 } d2r_encoder_layer_desc;
 size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F);
 int d2r_encoder_layer_fwd(const d2r_encoder_layer_desc* d, void* stream);
-int d2r_encoder_layer_bwd(const d2r_encoder_layer_desc* d, void* stream);
+int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K12 embeddings (models/modeling_unimo.py:87-118, 272-331)
