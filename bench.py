@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=48)
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="overlap bucketed grad all-reduce with backward")
+    ap.add_argument("--overlap", action="store_true", help="(default at N > 1) overlap the bucketed grad all-reduce with backward")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce the whole gradient buffer after backward")
     ap.add_argument("--bert-dropout", type=float, default=0.0,
                     help="hidden / attention-probability dropout of the BERT config (BASELINE.md section 3 benchmarks 0)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("D2R_BENCH_GRAPH", "0")),
@@ -143,7 +144,7 @@ def main():
     opt = FusedAdamW(store, lr=3e-5)
     total_steps = args.warmup + args.steps + 8
     sched = LinearWarmupSchedule(opt, 0.01 * total_steps, total_steps)
-    dp = DataParallel(store, opt, model, overlap=args.overlap)
+    dp = DataParallel(store, opt, model, overlap=not args.no_overlap)  # (no effect at N = 1)
     dp.broadcast_parameters()
     batch = synthetic_batch(args.batch, args.seq, args.image_size, dev, seed=rank)
 

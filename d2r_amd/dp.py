@@ -66,10 +66,13 @@ class FlatGradReducer:
         a, b = self.bounds[i]
         view = self.flat_g[a:b]
         if self.comm_stream is not None:
+            # A bucket holds gradients written from every compute stream of the step (the two encoder / routing
+            # streams and the launching stream; optionally the weight-gradient side streams): the collective must be
+            # ordered after all of them, not only after the stream the last readiness report came from.
+            from . import functional as F
             self.comm_stream.wait_stream(torch.cuda.current_stream())
-            from .functional import wgrad_streams
-            for side in wgrad_streams():  # weight-gradient GEMMs accumulate into flat_g on their own streams
-                self.comm_stream.wait_stream(side)
+            for st in list(F._COMPUTE_STREAMS) + F.wgrad_streams():
+                self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

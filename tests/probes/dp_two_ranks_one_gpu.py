@@ -1,0 +1,67 @@
+"""Two data-parallel ranks sharing cuda:0 over gloo (launched by tests/test_gpu_trainer.py through torch.distributed.run):
+the whole DataParallel machinery on real kernels — broadcast, sharded batch, bucketed all-reduce with and without
+overlap (readiness callbacks from the kernels' gradient sinks, deferred grouped weight gradients, whole-layer C calls),
+fused AdamW with grad_scale = 1/world.  Writes the final weights of both modes; they must be bit-identical."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import torch.distributed as dist
+
+out_dir = sys.argv[1]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+from d2r_amd import modules as M
+from d2r_amd.config import TextConfig, VisionConfig, default_args
+from d2r_amd.dp import DataParallel, shard_batch
+from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(3)
+ids = torch.randint(1000, 30000, (4, 16), generator=g); ids[:, 0] = 101
+full = (ids, torch.ones(4, 16, dtype=torch.long), torch.zeros(4, 16, dtype=torch.long), torch.randint(0, 3, (4,), generator=g),
+        torch.randn(4, 3, 64, 64, generator=g))
+batch = tuple(t.to(dev) for t in shard_batch(full, rank, world))
+results = {}
+for overlap in (False, True):
+    torch.manual_seed(100 + rank)  # different replicas on purpose: broadcast_parameters must make them identical
+    tc = TextConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vc = VisionConfig(num_hidden_layers=2, image_size=64, patch_size=32)
+    model = M.UnimoModelF(default_args(DR_step=3), vc, tc).to(dev)
+    model.set_compute_dtype(torch.bfloat16).train()
+    store = ParamStore(model, torch.bfloat16)
+    opt = FusedAdamW(store, lr=1e-3)
+    sched = LinearWarmupSchedule(opt, 0, 10)
+    dp = DataParallel(store, opt, model, bucket_mb=32, overlap=overlap)
+    assert dp.world == 2 and opt.grad_scale == 0.5
+    dp.broadcast_parameters()
+    losses = []
+    for _ in range(2):
+        dp.begin_step()
+        loss, _ = model(*batch)
+        loss.backward()
+        dp.reduce_gradients()
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    results[overlap] = (losses, store.flat_w.detach().cpu().clone())
+    entries = [(n, o, k) for n, _, o, k, _ in store.entries]
+    bounds = dp.reducer.bounds
+    if overlap:
+        launched_early = getattr(dp, "_early_launches", None)
+dist.barrier()
+same_modes = torch.equal(results[False][1], results[True][1])
+w = results[True][1].to(dev)
+other = w.clone()
+dist.broadcast(other, src=0)
+same_ranks = bool(torch.equal(other, w))
+diff = (results[False][1] != results[True][1]).nonzero().flatten()
+bad = sorted({n for n, o, k in entries if ((diff >= o) & (diff < o + k)).any()})
+torch.save({"losses": results[True][0], "losses_plain": results[False][0], "same_modes": same_modes, "same_ranks": same_ranks,
+            "n_diff": int(diff.numel()), "bad": bad[:40], "n_bad": len(bad), "bounds": bounds,
+            "bad_buckets": sorted({i for i, (a, b) in enumerate(bounds) if ((diff >= a) & (diff < b)).any()}),
+            "finite": bool(torch.isfinite(results[True][1]).all())}, os.path.join(out_dir, f"rank{rank}.pt"))
+dist.barrier()
+dist.destroy_process_group()

@@ -173,3 +173,23 @@ def test_streams_and_graph_replay_are_bit_identical_to_single_stream_eager(gpu):
                 bad = (a != b).nonzero().flatten()
                 names = sorted({n for n, o, k in got[4] if ((bad >= o) & (bad < o + k)).any()})
                 raise AssertionError(f"{tag}: {what} differs in {bad.numel()} elements of {names[:12]} ({len(names)} tensors)")
+
+
+def test_data_parallel_two_ranks_on_one_gpu(gpu, tmp_path):
+    """World size 2 with both ranks on cuda:0 (gloo backend — RCCL refuses two ranks per device): broadcast, sharded batch,
+    bucketed gradient all-reduce without and with overlap (bucket readiness reported by the kernels' gradient sinks, the
+    deferred grouped weight gradients and the whole-layer C calls), AdamW with grad_scale 1/2.  Overlap must not change a
+    single bit, and the two replicas must stay identical."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "probes", "dp_two_ranks_one_gpu.py"), str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for rank in (0, 1):
+        res = torch.load(os.path.join(str(tmp_path), f"rank{rank}.pt"))
+        assert res["finite"] and all(l == l for l in res["losses"]), res
+        assert res["same_modes"], ("overlapped all-reduce changed the result", {k: res[k] for k in res if k not in ("finite",)})
+        assert res["same_ranks"], "replicas diverged"
