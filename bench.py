@@ -126,7 +126,7 @@ def main():
     rank, world = init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)  # (% : gloo rehearsal on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -217,6 +217,10 @@ def main():
     value = world * args.batch * args.steps / dt
     log(f"timed region: {args.steps} steps, {ms:.2f} ms/step, {value:.1f} samples/s (host enqueue {host_ms:.2f} ms/step)")
 
+    # From here on no rank issues a gradient collective any more (the legs below are local measurements; rank 0 runs
+    # one more pass than the others): switch the overlap hooks off on every rank.
+    dp.overlap = False
+
     # SURVEY.md 8d also asks for fwd+bwd WITHOUT the optimiser: a short second timed loop (not `value`)
     def fwd_bwd_only():
         dp.begin_step()
@@ -253,14 +257,21 @@ def main():
         # Per-kernel durations: the same step, but launched op by op on ONE stream (whole-layer C calls and the
         # two-stream overlap switched off), so that every launch is bracketed by its own pair of HIP events and runs
         # alone on the GPU — the durations rocprofv3 --kernel-trace reports (it serialises dispatches too).
+        def local_step():  # the step without its collective: rank 0 is alone here
+            loss, _ = model(*batch)
+            loss.backward()
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+
         saved = (M.COMPOSITE_LAYERS, model.model.use_streams)
         M.COMPOSITE_LAYERS, model.model.use_streams = False, False
         try:
-            eager_step()
+            local_step()
             torch.cuda.synchronize()
             with KernelTimer() as kt:
                 for _ in range(2):
-                    eager_step()
+                    local_step()
             summ = kt.summary()
         finally:
             M.COMPOSITE_LAYERS, model.model.use_streams = saved

@@ -30,9 +30,10 @@ def init_process_group_from_env(backend: Optional[str] = None):
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    # D2R_DIST_BACKEND=gloo: rehearsal of the multi-rank control flow with several ranks on ONE GPU (RCCL refuses that)
+    backend = backend or os.environ.get("D2R_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 
