@@ -426,3 +426,44 @@ def test_default_init_gradients_vs_oracle(gpu, dtype):
                   "model.text_cls_pool.dense", "model.vision_cls_pool.dense"):
             assert part_cos[k] >= 0.99, (k, part_cos[k])
         assert min(part_cos.values()) >= 0.85, part_cos
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (3, 5)], ids=lambda s: f"B{s[0]}L{s[1]}")
+def test_degenerate_shapes_vs_oracle(gpu, shape, dtype):
+    """Smallest inputs the path admits — one sample, one text token (every text-side attention is 1x1, every
+    token-mean is the token itself), five image tokens — forward and backward against the oracle (fp32 tight, bf16 by
+    the default-init tolerances).  BatchNorm over a single scalar per sample and the [1,1] JS similarity are part of it."""
+    O, _ = _oracle()
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    B, L = shape
+    torch.manual_seed(7)
+    tc = TextConfig(num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vc = VisionConfig(num_hidden_layers=1, image_size=64, patch_size=32)
+    model = M.UnimoModelF(default_args(), vc, tc)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = O.OracleConfig(text_layers=1, vision_layers=1, image_size=64, patch_size=32)
+    ids, mask, tt, labels, images = O.synthetic_batch(cfg, B, L, seed=8)
+    osd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    lo, logits_o, _ = O.forward(osd, cfg, ids, mask, tt, labels, images.double(), train=True)
+    lo.backward()
+    model.to(gpu).set_compute_dtype(dtype).train()
+    ParamStore(model, dtype)
+    loss, logits = model(ids.to(gpu), mask.to(gpu), tt.to(gpu), labels.to(gpu), images.to(gpu))
+    loss.backward()
+    torch.cuda.synchronize()
+    lim = 1e-5 if dtype == torch.float32 else 5e-3
+    assert _err(logits, logits_o.detach()) <= lim and _err(loss, lo.detach()) <= lim, (_err(logits, logits_o.detach()), _err(loss, lo.detach()))
+    dot = ng = nr = 0.0
+    for name, p in model.named_parameters():
+        ref = osd[name].grad
+        if ref is None:
+            continue
+        got = p.grad.detach().double().cpu()
+        assert torch.isfinite(got).all(), name
+        dot, ng, nr = dot + float((got * ref).sum()), ng + float(got.pow(2).sum()), nr + float(ref.pow(2).sum())
+    cos = dot / max((ng * nr) ** 0.5, 1e-300)
+    assert cos >= (0.9999 if dtype == torch.float32 else 0.9), cos
