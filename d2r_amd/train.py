@@ -122,11 +122,17 @@ class MSDTrainer(BaseTrainer):
             ingest_pretrained(self.model, clip_model_dict, bert_model_dict)
             self.store.refresh_lowp()
         run_loss = torch.zeros((), dtype=torch.float32, device=self.args.device)
-        t0, seen = time.time(), 0
+        # throughput of the TRAINING loop only: the clock starts after a few warm-up steps (first-touch allocations,
+        # loader workers) and stops across evaluation
+        t_train, t_mark, seen, warm = 0.0, None, 0, 5
         epoch = 0
         for epoch in range(1, self.args.num_epochs + 1):
+            if self.step >= warm:
+                t_mark = time.time()
             for batch in self.train_data:
                 self.step += 1
+                if self.step == warm + 1 and t_mark is None:
+                    t_mark = time.time()
                 batch = self._to_device(batch)
                 self.dp.begin_step()
                 (loss, logits), labels = self._step(batch, mode="train")
@@ -136,16 +142,25 @@ class MSDTrainer(BaseTrainer):
                 self.optimizer.step()
                 self.scheduler.step()
                 self.optimizer.zero_grad()
-                seen += int(labels.shape[0]) * self.dp.world
+                if self.step > warm:
+                    seen += int(labels.shape[0]) * self.dp.world
                 if self.step % self.refresh_step == 0:
                     avg_loss = float(run_loss.item()) / self.refresh_step  # the only host sync of the loop
                     run_loss.zero_()
-                    self.samples_per_sec = seen / max(time.time() - t0, 1e-9)
-                    self.logger.info("step %d loss:%-6.5f samples/s:%.1f", self.step, avg_loss, self.samples_per_sec)
+                    if t_mark is not None and seen:
+                        self.samples_per_sec = seen / max(t_train + time.time() - t_mark, 1e-9)
+                    self.logger.info("step %d loss:%-6.5f samples/s:%.1f", self.step, avg_loss, self.samples_per_sec or 0.0)
                     if self.writer:
                         self.writer.add_scalar(tag="train_loss", scalar_value=avg_loss, global_step=self.step)
+            if t_mark is not None:
+                if self.args.device != "cpu" and torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                t_train += time.time() - t_mark
+                t_mark = None
             if epoch >= self.args.eval_begin_epoch and self.dev_data is not None:
                 self.evaluate(epoch)
+        if seen and t_train > 0:
+            self.samples_per_sec = seen / t_train
         if self.test_data is not None:
             if self.args.save_path is not None and os.path.exists(self.args.save_path + "best_model.pth"):
                 self.args.load_path = self.args.save_path + "best_model.pth"
