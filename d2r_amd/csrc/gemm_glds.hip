@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)  // operands swapped: the accumulator tile is C^T, a lane owns ONE row and 4 consecutive columns
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading buffer `cur` before it is refilled at t+1
   }
@@ -157,10 +158,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn0 + j * 16 + fr;
-        const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+        // acc[i][j][r] = C[wm0 + i*16 + fr][wn0 + j*16 + fq*4 + r]: four consecutive columns -> one 8-byte LDS store
+        const int col = n0 + wn0 + j * 16 + fq * 4;
+        Pack<bf16_t, 4> pk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cs[(i * 16 + fq * 4 + r) * LDE + j * 16 + fr] = (bf16_t)(g.alpha * acc[i][j][r] + bv);
+        for (int r = 0; r < 4; ++r) {
+          const float bv = (g.bias && col + r < g.N) ? g.bias[col + r] : 0.f;
+          pk.v[r] = (bf16_t)(g.alpha * acc[i][j][r] + bv);
+        }
+        st_pack<bf16_t, 4>(Cs + (i * 16 + fr) * LDE + j * 16 + fq * 4, pk);
       }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -210,16 +216,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int row = m0 + wm0 + i * 16 + fr;
+    if (row >= g.M) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn0 + j * 16 + fr;
-      if (col >= g.N) continue;
-      const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm0 + i * 16 + fq * 4 + r;
-        if (row >= g.M) continue;
-        float v = g.alpha * acc[i][j][r] + bv;
+        const int col = n0 + wn0 + j * 16 + fq * 4 + r;
+        if (col >= g.N) continue;
+        float v = g.alpha * acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
         const int64_t ci = (int64_t)row * g.ldc + col;
         if (g.P) store_c(g.P, g.c_dtype, ci, v);
         v = act_apply(g.act, v);

@@ -516,3 +516,19 @@ def test_grouped_weight_gradient_gemm(gpu, dtype):
         scale = float(want_w[i].abs().max())
         assert float((sinks[i].double() - want_w[i]).abs().max()) <= 1e-5 * scale + 1e-6, i
         assert float((bsinks[i].double() - want_b[i]).abs().max()) <= 1e-5 * float(want_b[i].abs().max()) + 1e-6, i
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(5, 61, 192, 136), (2, 128, 768, 768), (3, 131, 256, 72)], ids=lambda s: "x".join(map(str, s)))
+def test_linear_many_rows(gpu, dtype, shape):
+    """>= 128 rows: in bf16 the forward (NT) and dX (NN) products run on the LDS-DMA 128x64 kernel (gemm_glds.hip), the
+    workhorse of the real workload — ragged row / column edges, bias + GELU with saved pre-activation, bias + residual;
+    dW / db go through the deferred grouped path only with a ParamStore, here through the generic TN kernel."""
+    from d2r_amd import functional as F
+    B, L, K, N = shape
+    x, w, b, r = rnd(B, L, K), wt(N, K, dtype=dtype, scale=0.1), keep32(rnd(N, scale=0.5)), rnd(B, L, N, seed=7)
+    gelu = lambda v: 0.5 * v * (1 + torch.erf(v / math.sqrt(2)))
+    run_both(lambda x, w, b: F.linear(x, w, b, lp(w, dtype), act=3), lambda x, w, b: gelu(x @ w.t() + b), [x, w, b], dtype, gpu,
+             name=f"linear gelu {shape}")
+    run_both(lambda x, w, b, r: F.linear(x, w, b, lp(w, dtype), residual=r), lambda x, w, b, r: x @ w.t() + b + r,
+             [x, w, b, r], dtype, gpu, name=f"linear+res {shape}")
