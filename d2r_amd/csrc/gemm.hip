@@ -436,10 +436,13 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     int bn = 0;
     if (g_tile == 4) bn = 128;
     else if (g_tile == 5) bn = 64;
+    else if (g_tile == 6) bn = 129;  // 128x128 on eight waves (A/B runs)
     // measured (profiles/gemm_ab_r01_e.log): the 128x64 LDS-DMA kernel beats the register-staged 64x64 tiles on every
     // NT / NN shape of the workload (351 vs 275, 548 vs 422, 616 vs 343 TFLOP/s ...); weight-gradient GEMMs that carry
     // the bias-gradient side product stay on the generic kernel
-    else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN) bn = 64;
+    // wide outputs (N >= 1536: FFN up-projection, fused q|k|v, FFN dX): the 128x128 tile on eight waves fetches a third
+    // less from L2 per flop (NT 6304x3072x768: 561 vs 526, NN: 515 vs 452 TFLOP/s); narrow outputs keep the 128x64 tile
+    else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN) bn = a.N >= 1536 ? 129 : 64;
     if (a.dbias) bn = 0;
     if (bn) {
       GemmArgs b = a;

@@ -16,22 +16,24 @@
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
-template <int LAYOUT, int BN>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
-  constexpr int BM = 128, BK = 64;
+// NWN waves along N (2: four waves, 4: eight waves per workgroup); a wave owns 64 rows x BN/NWN columns.
+template <int LAYOUT, int BN, int NWN = 2>
+__global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g) {
+  constexpr int BM = 128, BK = 64, NW = 2 * NWN;
   constexpr bool A_KCONT = (LAYOUT != D2R_GEMM_TN);
   constexpr bool B_KCONT = (LAYOUT == D2R_GEMM_NT);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int WM = BM / 2, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF = A_BYTES + B_BYTES;
   // LDS-DMA instructions (1 KiB each) per tile and per wave
-  constexpr int IA = A_BYTES / 1024 / 4, IB = B_BYTES / 1024 / 4;
-  constexpr int SZ_EPI = 4 * WM * (WN + 8) * 2;
+  constexpr int IA = A_BYTES / 1024 / NW, IB = B_BYTES / 1024 / NW;
+  static_assert(IA * NW * 1024 == A_BYTES && IB * NW * 1024 == B_BYTES && IA >= 1 && IB >= 1, "tile does not split over the waves");
+  constexpr int SZ_EPI = NW * WM * (WN + 8) * 2;
   constexpr int SZ_ALL = 2 * BUF > SZ_EPI ? 2 * BUF : SZ_EPI;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SZ_ALL];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
   int tile_m, tile_n;
   xcd_tile(g.xcd, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   int64_t offA[IA], offB[IB];
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
-    const int ins = wave + 4 * i;
+    const int ins = wave + NW * i;
     if constexpr (A_KCONT) {  // 8 rows x 128 B per instruction
       const int row = ins * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
       const int grow = min(m0 + row, g.M - 1);
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   }
 #pragma unroll
   for (int i = 0; i < IB; ++i) {
-    const int ins = wave + 4 * i;
+    const int ins = wave + NW * i;
     if constexpr (B_KCONT) {
       const int row = ins * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
       const int grow = min(n0 + row, g.N - 1);
@@ -78,13 +80,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     for (int i = 0; i < IA; ++i) {
       const bf16_t* src = A + offA[i] + (A_KCONT ? (int64_t)k0 : (int64_t)k0 * g.lda);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
       const bf16_t* src = B + offB[i] + (B_KCONT ? (int64_t)k0 : (int64_t)k0 * g.ldb);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
     }
   };
 
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
       issue(t + 1, cur ^ 1);  // buffer cur^1 was last read in iteration t-1; every wave has passed its closing barrier
       if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if constexpr (IA + IB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -238,6 +241,11 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
 
 template <int LAYOUT>
 static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
+  if (bn == 129) {  // 128 x 128 tile on EIGHT waves (2 x 4): per wave as the 128x64 kernel, a third less L2 traffic per flop
+    dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
+    hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128, 4>), grid, dim3(512), 0, st, a);
+    return;
+  }
   if (bn == 128) {
     dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
     hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128>), grid, dim3(256), 0, st, a);
@@ -250,6 +258,7 @@ static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
 // Returns 1 when the launch was taken by the LDS-DMA kernel, 0 when the shape is not eligible.
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st) {
   if (batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
+  if (bn == 129 && a.N < 128) return 0;
   if (!a.vecA || !a.vecB) return 0;
   if (a.G && !(a.vecC && a.c_dtype == D2R_BF16)) return 0;  // the activation-gradient epilogue is in the vectorised path only
   const bool a_strided = layout == D2R_GEMM_TN, b_strided = layout != D2R_GEMM_NT;
