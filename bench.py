@@ -122,6 +122,8 @@ def main():
     from d2r_amd.dp import DataParallel, init_process_group_from_env
     from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
 
+    import d2r_amd
+    d2r_amd.configure_runtime()
     log("imports done")
     rank, world = init_process_group_from_env()
     if world != args.gpus:

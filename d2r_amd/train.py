@@ -89,6 +89,8 @@ class MSDTrainer(BaseTrainer):
         self.model.to(self.args.device)
         self.model.set_compute_dtype(dtype)
         self.store = ParamStore(self.model, dtype)
+        from . import configure_runtime
+        configure_runtime()
         self.optimizer = FusedAdamW(self.store, lr=self.args.lr, fc_lr=5e-2, weight_decay=1e-2)
         self.dp = DataParallel(self.store, self.optimizer, self.model,
                                overlap=bool(getattr(self.args, "dp_overlap", False)))

@@ -36,6 +36,7 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"enqueue {1e3 * (t1 - t0) / 5:.2f} ms/step, drained after another {1e3 * (t2 - t1):.2f} ms")
+torch.autograd.set_multithreading_enabled(False)  # backward functions run in this thread: visible to cProfile
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(5):
@@ -43,5 +44,5 @@ for _ in range(5):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(30)
+st.sort_stats("tottime").print_stats(45)
 st.sort_stats("cumulative").print_stats("functional.py|modules.py", 45)
