@@ -105,8 +105,9 @@ def wgrad_streams():
 DEFER_WGRAD = os.environ.get("D2R_DEFER_WGRAD", "1") != "0"
 _WGRAD_Q = {}  # stream handle -> {"stream": torch stream, "jobs": {shape key: [job, ...]}}
 _WGRAD_FLUSH_AT = 16
-D2R_LAYER_GROUP = int(os.environ.get("D2R_LAYER_GROUP", "6"))  # encoder layers per grouped launch of their (large) weight gradients
-# (measured at C2: 1 -> 32.6 ms/step, 2 -> 31.7, 4 / 6 / 13 -> 31.3-31.5; six keeps at most ~0.7 GB of scratch alive)
+D2R_LAYER_GROUP = int(os.environ.get("D2R_LAYER_GROUP", "7"))  # encoder layers per grouped launch of their (large) weight gradients
+# (measured at C2: 1 -> 32.6 ms/step, 2 -> 31.7, 4 / 6 / 13 -> 31.3-31.5; each stream runs 13 composite layers per step, so seven
+# gives groups of 7 + 6 and no single-problem launch; at most ~0.8 GB of scratch kept alive)
 
 
 def _defer_wgrad(g, x, lda_x, sink, bsink, N, K, M, w_master, bias):
@@ -364,9 +365,10 @@ class _Linear(torch.autograd.Function):
                 db_ptr = bsink.data_ptr()
         if ctx.w_needs:
             sink = getattr(ctx.w_master, "_d2r_grad", None)  # flat fp32 gradient buffer (d2r_amd.params.ParamStore)
-            if (sink is not None and DEFER_WGRAD and not WGRAD_STREAMS and db is None and N * K <= 1500000
+            if (sink is not None and DEFER_WGRAD and not WGRAD_STREAMS and db is None and 262144 <= N * K <= 1500000
                     and M >= 1024 and lda == K):
-                # small-output weight gradient: queued, launched with up to fifteen others of its shape (grouped GEMM).
+                # small-output weight gradient: queued, launched with up to fifteen others of its shape (grouped GEMM;
+                # below 64 output tiles a group cannot fill the chip and split-K on the spot is faster).
                 # The queue holds a reference to g, so autograd cannot accumulate into it in place meanwhile (it only
                 # does that to tensors it owns exclusively) even when g is also handed on as the skip gradient.
                 _defer_wgrad(g, x, lda, sink, bsink if want_db else None, N, K, M, ctx.w_master, ctx.bias if want_db else None)
