@@ -103,6 +103,7 @@ def wgrad_streams():
 # sixteen at a time by d2r_gemm_tn_grouped (2x faster per GEMM, one launch instead of thirty-two).
 # ------------------------------------------------------------------------------------------------------
 DEFER_WGRAD = os.environ.get("D2R_DEFER_WGRAD", "1") != "0"
+DEFER_SHORT_WGRAD = os.environ.get("D2R_DEFER_SHORT_WGRAD", "1") != "0"  # also the rank-B updates of the pooled-vector linears
 _WGRAD_Q = {}  # stream handle -> {"stream": torch stream, "jobs": {shape key: [job, ...]}}
 _WGRAD_FLUSH_AT = 16
 D2R_LAYER_GROUP = int(os.environ.get("D2R_LAYER_GROUP", "7"))  # encoder layers per grouped launch of their (large) weight gradients
@@ -366,7 +367,7 @@ class _Linear(torch.autograd.Function):
         if ctx.w_needs:
             sink = getattr(ctx.w_master, "_d2r_grad", None)  # flat fp32 gradient buffer (d2r_amd.params.ParamStore)
             if (sink is not None and DEFER_WGRAD and not WGRAD_STREAMS and db is None and 262144 <= N * K <= 1500000
-                    and M >= 1024 and lda == K):
+                    and (M >= 1024 or DEFER_SHORT_WGRAD) and lda == K):
                 # small-output weight gradient: queued, launched with up to fifteen others of its shape (grouped GEMM;
                 # below 64 output tiles a group cannot fill the chip and split-K on the spot is faster).
                 # The queue holds a reference to g, so autograd cannot accumulate into it in place meanwhile (it only
@@ -1384,13 +1385,12 @@ class _ClipEmbed(torch.autograd.Function):
         dcls = torch.empty(E, dtype=torch.float32, device=g.device)
         dpos = torch.empty(ntok, E, dtype=torch.float32, device=g.device)
         _lib.call("d2r_clip_embed_bwd", _dt(g), g.data_ptr(), B, ntok, E, dcls.data_ptr(), dpos.data_ptr(), _stream())
-        # dW[E,K] = sum_b dY_b^T patches_b : B accumulating TN GEMMs would serialise; batch them through beta
+        # dW[E,K] = dY_patch^T patches over all B*npatch rows: the class-token rows are dropped from dY by one strided copy,
+        # then ONE split-K weight-gradient GEMM (was: one accumulating GEMM per sample)
         dw = torch.empty(E, K, dtype=torch.float32, device=g.device)
-        es = g.element_size()
-        for b in range(B):
-            gemm(GEMM_TN, E, K, npatch, g.data_ptr() + (b * ntok + 1) * E * es, E,
-                 patches.data_ptr() + b * npatch * K * es, K, dw.data_ptr(), K, dtype=_dt(g), c_dtype=F32,
-                 beta=0.0 if b == 0 else 1.0)
+        gp = g[:, 1:, :].contiguous()
+        gemm(GEMM_TN, E, K, B * npatch, gp.data_ptr(), E, patches.data_ptr(), K, dw.data_ptr(), K, dtype=_dt(g), c_dtype=F32,
+             beta=0.0, splitk_ws=_workspace(64 << 20, g.device))
         return None, dw.view(wshape), None, dcls, dpos, None
 
 
