@@ -6,9 +6,11 @@ local-batch BatchNorm statistics and local [b,b] JS loss per rank, gradients ave
 The 1/world factor is folded into the fused AdamW kernel (``grad_scale``), so the collective is a plain SUM.
 
 Buckets are contiguous slices of ``ParamStore.flat_g``.  With ``overlap=True`` a bucket's all-reduce is issued
-on a side stream as soon as every parameter in it has its gradient (readiness is counted from autograd's
-post-accumulate hooks and from the dW-sink callback of functional._Linear), overlapping with the rest of
-backward; ``finish()`` joins them before the optimiser step.
+on a side stream as soon as every parameter in it has its WHOLE gradient, overlapping with the rest of backward;
+``finish()`` joins them before the optimiser step.  Gradient pieces report from autograd's post-accumulate hooks, from
+the dW-sink callbacks of functional._Linear / the whole-layer C calls and from the deferred grouped launches; a
+parameter shared by several call sites reports several times per step, so the first overlapped step only counts the
+reports and later steps wait for the last one (DataParallel._ready).
 """
 from __future__ import annotations
 
@@ -95,11 +97,11 @@ class FlatGradReducer:
 
 class DataParallel:
     def __init__(self, store: ParamStore, optimizer, model: torch.nn.Module, bucket_mb: int = 128, group=None,
-                 overlap: bool = False):
+                 overlap: bool = False, bucket_elems: Optional[int] = None):
         self.store, self.opt, self.model, self.group = store, optimizer, model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.reducer = FlatGradReducer(store.flat_g, bucket_mb * (1 << 20) // 4, group) if self.world > 1 else None
+        self.reducer = FlatGradReducer(store.flat_g, bucket_elems or bucket_mb * (1 << 20) // 4, group) if self.world > 1 else None
         optimizer.grad_scale = 1.0 / self.world
         self.overlap = overlap and self.world > 1
         self._pending: List[int] = []
@@ -119,6 +121,11 @@ class DataParallel:
         self.store.refresh_lowp()
 
     # -- readiness counting for overlap ---------------------------------------------------------------
+    # A parameter may receive its gradient in several pieces per step (a weight shared by two call sites, one piece
+    # written on the spot and one by a deferred grouped launch at the end of backward, an autograd-accumulated piece next
+    # to a sink-written one).  Every piece reports through _ready; the FIRST overlapped step only counts the reports per
+    # parameter (its buckets are reduced after backward), later steps mark a parameter ready at its last expected
+    # report.  A report that arrives after its bucket's collective was issued is a hard error, not a silent wrong sum.
     def _install_hooks(self):
         bounds = self.reducer.bounds
         self._count0 = [0] * len(bounds)
@@ -131,21 +138,37 @@ class DataParallel:
             self._bucket_of[id(p)] = (bi, be)
             p._d2r_ready_cb = self._ready
             p.register_post_accumulate_grad_hook(self._ready)
+        self._expect = None  # id(parameter) -> reports per step, learnt in the first overlapped step
+        from . import functional as F
+        F.EARLY_FLUSH = True  # queued weight gradients of the routing modules go out before the encoders' backward
         self.begin_step()
 
     def begin_step(self):
         if self.overlap:
             self._pending = list(self._count0)
-            self._seen = set()
+            self._got = {}
+            self._launched = [False] * len(self._count0)
 
     def _ready(self, p):
-        if not self.overlap or id(p) in self._seen:
+        if not self.overlap:
             return
-        self._seen.add(id(p))
-        bi, be = self._bucket_of[id(p)]
+        pid = id(p)
+        n = self._got[pid] = self._got.get(pid, 0) + 1
+        if self._expect is None:  # calibration step
+            return
+        want = self._expect.get(pid, 1)
+        if n < want:
+            return
+        bi, be = self._bucket_of[pid]
+        if n > want:
+            if any(self._launched[i] for i in range(bi, be + 1)):
+                raise RuntimeError("data-parallel overlap: a parameter received a gradient piece after its bucket's all-reduce was "
+                                   "issued (the number of pieces per step changed); run with overlap=False")
+            return
         for i in range(bi, be + 1):
             self._pending[i] -= 1
             if self._pending[i] == 0:
+                self._launched[i] = True
                 self.reducer.launch_bucket(i)
 
     # -- per step -------------------------------------------------------------------------------------
@@ -153,9 +176,12 @@ class DataParallel:
         if self.world == 1:
             return
         if self.overlap:
-            # buckets whose parameters never reported (unused this step) are reduced now
-            for i, c in enumerate(self._pending):
-                if c > 0:
+            if self._expect is None:
+                self._expect = dict(self._got)
+            # buckets whose parameters did not all report (unused this step, or the calibration step) are reduced now
+            for i, done in enumerate(self._launched):
+                if not done:
+                    self._launched[i] = True
                     self.reducer.launch_bucket(i)
             self.reducer.finish()
         else:

@@ -153,6 +153,24 @@ def _flush_wgrad_group(key, jobs):
                 cb(p)
 
 
+EARLY_FLUSH = False  # set by d2r_amd.dp when the gradient all-reduce overlaps with backward
+_early_flushed = set()
+
+
+def _flush_before_encoders():
+    """Overlapped data parallelism: the routing modules' queued weight gradients are launched when the backward pass of a
+    stream reaches its first whole encoder layer (everything downstream of the encoders is done by then), so that their
+    buckets can be reduced during the encoders' backward instead of after it."""
+    h = torch.cuda.current_stream().cuda_stream
+    if h in _early_flushed:
+        return
+    _early_flushed.add(h)
+    q = _WGRAD_Q.get(h)
+    if q is not None:
+        for key in list(q["jobs"]):
+            _flush_wgrad_group(key, q["jobs"].pop(key))
+
+
 def flush_wgrads():
     """Launches every queued weight-gradient group on the stream it was queued on.  Runs at the end of each backward
     pass (before the streams are joined) and may be called by anything that needs the gradients earlier."""
@@ -178,6 +196,7 @@ def _backward_join_cb():
     a host read of .grad) is ordered after ALL gradient writes — independent of which autograd leaves happened to run."""
     global _join_queued
     _join_queued = False
+    _early_flushed.clear()
     flush_wgrads()
     cur = torch.cuda.current_stream()
     for st in _COMPUTE_STREAMS:
@@ -772,6 +791,8 @@ class _EncoderLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         _ensure_backward_join()
+        if EARLY_FLUSH:
+            _flush_before_encoders()
         (x,) = ctx.saved_tensors
         d, bundle = ctx.d, ctx.bundle
         g = g.contiguous()

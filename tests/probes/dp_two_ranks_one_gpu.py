@@ -2,7 +2,8 @@
 the whole DataParallel machinery on real kernels — broadcast, sharded batch, bucketed all-reduce with and without
 overlap (readiness callbacks from the kernels' gradient sinks, deferred grouped weight gradients, whole-layer C calls),
 fused AdamW with grad_scale = 1/world.  Writes the final weights of both modes; they must be bit-identical."""
-import os, sys
+import faulthandler, os, sys
+faulthandler.dump_traceback_later(int(os.environ.get("D2R_PROBE_DUMP_S", "150")), exit=True)  # a hang ends in tracebacks, not silence
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.distributed as dist
@@ -31,12 +32,12 @@ for overlap in (False, True):
     model.set_compute_dtype(torch.bfloat16).train()
     store = ParamStore(model, torch.bfloat16)
     opt = FusedAdamW(store, lr=1e-3)
-    sched = LinearWarmupSchedule(opt, 0, 10)
+    sched = LinearWarmupSchedule(opt, 0, 12)
     dp = DataParallel(store, opt, model, bucket_mb=32, overlap=overlap)
     assert dp.world == 2 and opt.grad_scale == 0.5
     dp.broadcast_parameters()
     losses = []
-    for _ in range(2):
+    for _ in range(3):  # (overlap: the first step calibrates the per-parameter report counts)
         dp.begin_step()
         loss, _ = model(*batch)
         loss.backward()
@@ -50,14 +51,21 @@ for overlap in (False, True):
     entries = [(n, o, k) for n, _, o, k, _ in store.entries]
     bounds = dp.reducer.bounds
     if overlap:
-        launched_early = getattr(dp, "_early_launches", None)
+        multi = sum(1 for v in dp._expect.values() if v > 1)
+        print(f"rank {rank}: {len(dp._expect)} reporting parameters, {multi} of them in more than one piece", flush=True)
+        if rank == 0 and os.environ.get("D2R_PROBE_VERBOSE"):
+            import collections
+            names = {id(p): n for n, p, _, _, _ in store.entries}
+            print("pieces histogram:", sorted(collections.Counter(dp._expect.values()).items()), flush=True)
+            for pid, v in list(dp._expect.items()):
+                print("  ", v, names.get(pid, "<fused leaf>"), flush=True)
 dist.barrier()
 same_modes = torch.equal(results[False][1], results[True][1])
 w = results[True][1].to(dev)
 other = w.clone()
 dist.broadcast(other, src=0)
 same_ranks = bool(torch.equal(other, w))
-diff = (results[False][1] != results[True][1]).nonzero().flatten()
+diff = (results[False][1] != results[True][1]).nonzero().flatten()[:4096]
 bad = sorted({n for n, o, k in entries if ((diff >= o) & (diff < o + k)).any()})
 torch.save({"losses": results[True][0], "losses_plain": results[False][0], "same_modes": same_modes, "same_ranks": same_ranks,
             "n_diff": int(diff.numel()), "bad": bad[:40], "n_bad": len(bad), "bounds": bounds,

@@ -28,6 +28,61 @@ def _routing_grads(shard):
     return torch.cat([osd["M." + k].grad.flatten() for k in names])
 
 
+class _FakeStore:
+    """Three 100-element parameters in one flat gradient buffer (what DataParallel needs of a ParamStore)."""
+
+    def __init__(self):
+        self.flat_g = torch.zeros(300)
+        self.params = [torch.zeros(100, requires_grad=True) for _ in range(3)]
+        self.dead = []
+
+    def units(self):
+        return [(p, 100 * i, 100) for i, p in enumerate(self.params)]
+
+
+class _FakeOpt:
+    grad_scale = 1.0
+
+
+def _overlap_readiness(rank):
+    """Overlapped bucket launches when a parameter's gradient arrives in two pieces per step (one written during
+    backward, one by a deferred launch at its end): the first step calibrates, later steps launch each bucket at the LAST
+    piece; a piece after the launch is a loud error."""
+    from d2r_amd.dp import DataParallel
+    store = _FakeStore()
+    dp = DataParallel(store, _FakeOpt(), None, overlap=True, bucket_elems=100)
+    p0, p1, p2 = store.params
+    order = []
+    launch = dp.reducer.launch_bucket
+    dp.reducer.launch_bucket = lambda i: (order.append(i), launch(i))[1]
+
+    def step(extra_piece=False):
+        store.flat_g.zero_()
+        order.clear()
+        dp.begin_step()
+        store.flat_g[200:300] += rank + 1          # first piece of p2
+        dp._ready(p2)
+        store.flat_g[100:200] += 5 * (rank + 1)
+        dp._ready(p1)
+        store.flat_g[0:100] += 7 * (rank + 1)
+        dp._ready(p0)
+        store.flat_g[200:300] += 10 * (rank + 1)   # second piece of p2, e.g. from the grouped launch at the end of backward
+        dp._ready(p2)
+        if extra_piece:
+            with pytest.raises(RuntimeError, match="after its bucket"):
+                dp._ready(p2)
+        dp.reduce_gradients()
+        want = torch.cat([torch.full((100,), 21.0), torch.full((100,), 15.0), torch.full((100,), 33.0)])
+        assert torch.equal(store.flat_g, want), store.flat_g[::100]
+
+    step()
+    assert order == [0, 1, 2], order            # calibration step: everything after "backward"
+    assert dp._expect[id(p2)] == 2 and dp._expect[id(p1)] == 1
+    step()
+    assert order == [1, 0, 2], order            # overlapped: a bucket goes out at the last piece of its last parameter
+    step(extra_piece=True)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,6 +110,7 @@ def _worker(rank, world, port, q):
             q.put(float((avg - ref).abs().max() / (ref.abs().max() + 1e-12)))
         with pytest.raises(ValueError):
             shard_batch((torch.zeros(3, 2),), rank, world)
+        _overlap_readiness(rank)
     finally:
         dist.barrier()
         dist.destroy_process_group()
