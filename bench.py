@@ -302,15 +302,19 @@ def main():
         total_ms = sum(e["ms_per_step"] for e in kernels)
         dom = next((e for e in kernels if "bound" in e), None)
         if dom is not None:
-            traffic = None  # HBM bytes per launch of that kernel family from the committed rocprofv3 --pmc passes
+            # HBM bytes of that kernel family from the committed rocprofv3 --pmc passes of the real step, per training step,
+            # divided by THIS pass's launches per step: comparable with the algorithmic bytes per launch
+            traffic = None
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")) as f:
-                    traffic = json.load(f).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+                    per_step = json.load(f).get(dom["kernel"], {}).get("hbm_bytes_per_step")
+                if per_step:
+                    traffic = round(per_step / max(dom["launches_per_step"], 1))
             except OSError:
                 pass
             out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                                "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic,
-                               "traffic_source": "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950)" if traffic else None,
+                               "traffic_source": "profiles/pmc_traffic_r01.json: family HBM bytes per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950) / launches per step of this pass" if traffic else None,
                                "algorithmic_bytes_per_launch": dom.get("algo_bytes_per_launch"),
                                "avg_launch_us": dom["avg_us"], "share_of_kernel_time": round(dom["ms_per_step"] / max(total_ms, 1e-9), 3)}
         log("instrumented (per-kernel HIP event) pass done")

@@ -54,11 +54,17 @@ def load(path, counter):
 
 fetch, n_f = load(sys.argv[1], "FETCH_SIZE")
 write, n_w = load(sys.argv[2], "WRITE_SIZE")
-out = {"_doc": "HBM bytes per launch from rocprofv3 --pmc (FETCH_SIZE x2 on gfx950, WRITE_SIZE exact); bench.py --steps 2 --warmup 1, bf16 C2 workload"}
+# steps of the profiled command: 1 warm-up + 2 timed + 4 of the fwd+bwd-only leg (bench.py --steps 2 --warmup 1) = 7
+STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 7
+out = {"_doc": "HBM bytes from rocprofv3 --pmc (FETCH_SIZE x2 on gfx950, WRITE_SIZE exact); bench.py --steps 2 --warmup 1, bf16 C2 "
+               "workload (%d steps in the run).  *_per_launch: per GEMM kernel of the REAL step (a grouped weight-gradient launch "
+               "holds 6-16 problems); hbm_bytes_per_step: family total per training step - bench.py divides it by the launches "
+               "per step of its per-kernel pass to compare with the algorithmic bytes per launch." % STEPS,
+       "_steps": STEPS}
 for fam in sorted(fetch):
     n = max(n_f[fam], 1)
     rd, wr = 2.0 * fetch[fam] / n, write.get(fam, 0.0) / max(n_w.get(fam, 0), 1)
     out[fam] = {"launches_profiled": n_f[fam], "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
-                "hbm_bytes_per_launch": round(rd + wr)}
+                "hbm_bytes_per_launch": round(rd + wr), "hbm_bytes_per_step": round((rd + wr) * n / STEPS)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
