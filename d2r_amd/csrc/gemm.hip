@@ -589,6 +589,11 @@ static int launch_grouped_tn(const GemmArgs& base, const void* const* A, const v
     GemmArgs a = base;
     a.dbias = dbias ? reinterpret_cast<float*>(1) : nullptr;  // per-problem pointer substituted in the kernel; non-null enables the path
     dim3 grid(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 64), n);
+    // Operand strips fetched past L2 per round of resident workgroups (profiles/gemm_grouped_pmc_r01.txt): with whole
+    // problems per XCD a round covers (resident / grid.x) row strips + grid.x column strips - right for 12 tile columns
+    // (1.5x the operand bytes fetched vs 4.5x), wrong for 48 (6.3x): there the plain round-robin order, which gives an
+    // XCD every eighth tile column, fetches 2.5x.
+    if (grid.x >= 24 && grid.x % 8 == 0) a.xcd = 0;
     hipLaunchKernelGGL((gemm_kernel<T, D2R_GEMM_TN, 64, 64, 2, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
     if (int rc = d2r_check_launch("d2r_gemm_tn_grouped")) return rc;
   }

@@ -497,12 +497,14 @@ def test_bert_layer_with_dropout_backward_is_consistent(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_grouped_weight_gradient_gemm(gpu, dtype):
-    """d2r_gemm_tn_grouped: 19 same-shape dW = dY^T X problems (two launches: 16 + 3) with bias-gradient side product and
-    accumulation into pre-filled sinks, against torch."""
+@pytest.mark.parametrize("shape", [(19, 300, 136, 72), (3, 200, 72, 1536)], ids=["19x136x72", "3x72x1536"])
+def test_grouped_weight_gradient_gemm(gpu, dtype, shape):
+    """d2r_gemm_tn_grouped: same-shape dW = dY^T X problems (19: two launches, 16 + 3; 24 tile columns: the launch order
+    without the whole-problem-per-XCD remap) with bias-gradient side product and accumulation into pre-filled sinks,
+    against torch."""
     from d2r_amd import _lib
     from d2r_amd.functional import _parr, _stream
-    n, T, N, K = 19, 300, 136, 72
+    n, T, N, K = shape
     gs = [rnd(T, N, seed=i).to(dtype).to(gpu) for i in range(n)]
     xs = [rnd(T, K, seed=100 + i).to(dtype).to(gpu) for i in range(n)]
     sinks = [rnd(N, K, seed=200 + i).to(gpu) for i in range(n)]
