@@ -54,8 +54,9 @@ def parse():
     ap.add_argument("--dr-step", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=48)
+    ap.add_argument("--cpu-samples", type=int, default=32, help="batch of the CPU baseline (BASELINE.md section 3: the benchmark batch)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short fp32-path timing reported next to the headline")
     ap.add_argument("--overlap", action="store_true", help="(default at N > 1) overlap the bucketed grad all-reduce with backward")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce the whole gradient buffer after backward")
     ap.add_argument("--bert-dropout", type=float, default=0.0,
@@ -79,7 +80,11 @@ def synthetic_batch(B, L, image_size, device, seed):
 
 
 def cpu_baseline(args, sd_cpu):
-    """Oracle (CPU port of the reference's maths) fwd+bwd on the host cores, bounded sample of the same workload."""
+    """The pinned oracle (CPU port of the reference's maths; the reference itself cannot travel to the GPU box) timed on
+    the host cores by BASELINE.md section 3: the benchmark's own batch (32 samples, same synthetic tensors), fp32, train
+    mode, dropout 0, 1 warm-up + the median of 3 timed fwd+bwd iterations."""
+    import platform
+    import statistics
     import torch
     from oracle import d2r_oracle as O
     try:
@@ -90,10 +95,10 @@ def cpu_baseline(args, sd_cpu):
     torch.set_num_threads(cores)
     cfg = O.OracleConfig(text_layers=args.layers, vision_layers=args.layers, image_size=args.image_size,
                          patch_size=args.patch, DR_step=args.dr_step)
-    n = args.cpu_samples
+    nb = args.cpu_samples
+    ids, mask, tt, labels, images = synthetic_batch(nb, args.seq, args.image_size, "cpu", seed=0)
 
-    def run(nb):
-        ids, mask, tt, labels, images = synthetic_batch(nb, args.seq, args.image_size, "cpu", seed=0)
+    def run():
         sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
               for k, v in sd_cpu.items()}
         t0 = time.time()
@@ -101,19 +106,46 @@ def cpu_baseline(args, sd_cpu):
         loss.backward()
         return time.time() - t0
 
-    log("cpu baseline: warm-up sample")
-    run(1)  # warm-up (thread pool, allocator)
-    log(f"cpu baseline: timing {n} samples")
-    dt = run(n)
-    log(f"cpu baseline: {n / dt:.3f} samples/s")
-    return {"value": round(n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} samples of the same workload (L={args.seq}, {(args.image_size // args.patch) ** 2 + 1} image tokens, "
-                      f"{args.layers}+{args.layers} encoder layers, DR_step {args.dr_step}), 1 fwd+bwd iteration, fp32, "
-                      f"torch CPU {torch.get_num_threads()} threads, {dt:.1f} s"}
+    log(f"cpu baseline: warm-up iteration (batch {nb}, {cores} threads)")
+    run()
+    times = []
+    for i in range(3):
+        times.append(run())
+        log(f"cpu baseline: timed iteration {i + 1}/3: {times[-1]:.1f} s")
+    dt = statistics.median(times)
+    cpu_model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), cpu_model)
+    except OSError:
+        pass
+    return {"value": round(nb / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"batch {nb} of the same workload (L={args.seq}, {(args.image_size // args.patch) ** 2 + 1} image tokens, "
+                      f"{args.layers}+{args.layers} encoder layers, DR_step {args.dr_step}), fp32, train mode, 1 warm-up + median of 3 "
+                      f"timed fwd+bwd iterations ({', '.join(f'{t:.1f}' for t in times)} s), torch CPU {torch.get_num_threads()} threads "
+                      f"of {os.cpu_count()} host CPUs ({cpu_model})"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks as a CHILD process (this process has
+    not touched the GPU — torch is not even imported yet — and never re-execs), relay its output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
     from d2r_amd import modules as M
@@ -166,6 +198,9 @@ def main():
         torch.cuda.synchronize()
 
     eager_step = step
+    if args.graph and args.bert_dropout > 0.0:
+        raise SystemExit("--graph 1 with --bert-dropout > 0: the dropout seeds are host scalars baked into kernel arguments, a "
+                         "replayed graph would reuse one mask every step")
     if args.graph:
         # The step is ~1500 short launches; replaying them from one hipGraph removes the host launch cost and lets
         # the two encoder/interaction streams really overlap.  Same kernels, same order, same buffers as eager.
@@ -178,12 +213,14 @@ def main():
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         static = {}
+        was_overlap, dp.overlap = dp.overlap, False  # no readiness hooks / collectives inside the capture
         with torch.cuda.graph(graph):
             static["loss"], static["logits"] = model(*batch)
             static["loss"].backward()
             if world == 1:
                 opt.step_captured()
                 opt.zero_grad()
+        del was_overlap  # at N > 1 the captured fwd+bwd is followed by the plain (non-overlapped) bucketed all-reduce
         log("hipGraph of the step captured")
 
         def step():
@@ -305,16 +342,20 @@ def main():
             # HBM bytes of that kernel family from the committed rocprofv3 --pmc passes of the real step, per training step,
             # divided by THIS pass's launches per step: comparable with the algorithmic bytes per launch
             traffic = None
+            pmc_file = None
             try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")) as f:
-                    per_step = json.load(f).get(dom["kernel"], {}).get("hbm_bytes_per_step")
-                if per_step:
-                    traffic = round(per_step / max(dom["launches_per_step"], 1))
+                cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("pmc_traffic_r") and f.endswith(".json"))
+                pmc_file = cands[-1] if cands else None
+                if pmc_file:
+                    with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+                        per_step = json.load(f).get(dom["kernel"], {}).get("hbm_bytes_per_step")
+                    if per_step:
+                        traffic = round(per_step / max(dom["launches_per_step"], 1))
             except OSError:
                 pass
             out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                                "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic,
-                               "traffic_source": "profiles/pmc_traffic_r01.json: family HBM bytes per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950) / launches per step of this pass" if traffic else None,
+                               "traffic_source": f"profiles/{pmc_file}: family HBM bytes per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950) / launches per step of this pass" if traffic else None,
                                "algorithmic_bytes_per_launch": dom.get("algo_bytes_per_launch"),
                                "avg_launch_us": dom["avg_us"], "share_of_kernel_time": round(dom["ms_per_step"] / max(total_ms, 1e-9), 3)}
         log("instrumented (per-kernel HIP event) pass done")
@@ -324,6 +365,27 @@ def main():
         top = kernels[:20]
         out["roofline_kernels"] = top + [e for e in kernels[20:] if e["kernel"].startswith(named)]
         out["kernel_ms_per_step_total"] = round(total_ms, 3)
+
+    if rank == 0 and world == 1 and args.dtype != "f32" and not args.no_fp32_leg:
+        # The same step on the fp32 HIP path (exact-f32 MFMA, the parity reference: logits within 1e-7 of the reference),
+        # reported NEXT to the headline so that the price of the 16-bit compute dtype is visible; never `value`.
+        try:
+            model.set_compute_dtype(torch.float32)
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            f_ms = (time.perf_counter() - t2) / 3 * 1e3
+            out["fp32_path"] = {"ms_per_step": round(f_ms, 2), "samples_per_s": round(args.batch / f_ms * 1e3, 2),
+                                "note": "same step, fp32 activations / weights / MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate)"}
+            log(f"fp32 path: {f_ms:.1f} ms/step")
+        except Exception as e:
+            out["fp32_path"] = {"error": repr(e)}
+        finally:
+            model.set_compute_dtype(dtype)
 
     if sd_cpu is not None:
         try:

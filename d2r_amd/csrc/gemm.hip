@@ -616,6 +616,12 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
     D2R_REQUIRE(h_A[i] && h_B[i] && h_C[i] && (!h_dbias || h_dbias[i]), "d2r_gemm_tn_grouped: null operand in problem %d", i);
     a.vecA &= d2r_aligned16(h_A[i]) ? 1 : 0;
     a.vecB &= d2r_aligned16(h_B[i]) ? 1 : 0;
+    // the problems of one launch run in parallel and each workgroup does a non-atomic C = beta*C + A^T B (dbias += ...):
+    // two problems sharing an output would race
+    for (int j = 0; j < i; ++j) {
+      D2R_REQUIRE(h_C[i] != h_C[j], "d2r_gemm_tn_grouped: problems %d and %d write the same C", j, i);
+      D2R_REQUIRE(!h_dbias || h_dbias[i] != h_dbias[j], "d2r_gemm_tn_grouped: problems %d and %d write the same dbias", j, i);
+    }
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == D2R_BF16) return launch_grouped_tn<bf16_t>(a, h_A, h_B, h_C, h_dbias, count, st);

@@ -120,6 +120,23 @@ class DataParallel:
             dist.broadcast(b, src=src, group=self.group)
         self.store.refresh_lowp()
 
+    def sync_buffers(self):
+        """BatchNorm running statistics are updated from each rank's LOCAL batch and drift apart after the initial
+        broadcast (DDP would re-broadcast rank 0's every step); before evaluation / checkpointing they are replaced by
+        their mean over ranks (integer buffers such as num_batches_tracked: rank 0's value)."""
+        if self.world == 1:
+            return
+        for b in self.model.buffers():
+            if b.is_floating_point():
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+                b.div_(self.world)
+            else:
+                dist.broadcast(b, src=0, group=self.group)
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
     # -- readiness counting for overlap ---------------------------------------------------------------
     # A parameter may receive its gradient in several pieces per step (a weight shared by two call sites, one piece
     # written on the spot and one by a deferred grouped launch at the end of backward, an autograd-accumulated piece next

@@ -124,6 +124,11 @@ def _defer_wgrad_raw(dt, N, K, M, lda_x, g_ptr, x_ptr, sink_ptr, bsink_ptr, para
         q = _WGRAD_Q[cur.cuda_stream] = {"stream": cur, "jobs": {}}
     key = (dt, N, K, M, lda_x, bsink_ptr is not None)
     jobs = q["jobs"].setdefault(key, [])
+    # a parameter used at two call sites: its two products must not share a launch (the problems of a grouped launch run
+    # in parallel and accumulate non-atomically) — launch what is queued first
+    if any(j[2] == sink_ptr or (bsink_ptr is not None and j[3] == bsink_ptr) for j in jobs):
+        _flush_wgrad_group(key, q["jobs"].pop(key))
+        jobs = q["jobs"].setdefault(key, [])
     jobs.append((g_ptr, x_ptr, sink_ptr, bsink_ptr, params, keepalive))  # keepalive: tensors the launch will read
     if len(jobs) >= (flush_at or _WGRAD_FLUSH_AT):
         _flush_wgrad_group(key, q["jobs"].pop(key))

@@ -104,7 +104,7 @@ def main(argv=None):
     def loader(n, seed, shuffle):
         ds = SyntheticMSDDataset(n, args.max_seq, args.image_size, args.num_classes, seed=seed, num_image_tokens=ntok)
         sampler = None
-        if world > 1:
+        if world > 1 and shuffle:  # only the TRAINING set is sharded; every rank evaluates the whole dev / test set
             sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle,
                                                                       seed=args.seed)
         return make_loader(ds, per_rank, shuffle, args.num_workers, drop_last=shuffle, sampler=sampler)

@@ -26,47 +26,41 @@ from .params import FusedAdamW, LinearWarmupSchedule, ParamStore
 
 
 def get_four_metrics(labels, predicted_labels, type="weighted"):
-    """Weighted accuracy / recall / precision / F1 (modules/train.py:23-30)."""
-    from sklearn.metrics import accuracy_score, f1_score, precision_score, recall_score
-    acc = accuracy_score(labels, predicted_labels)
-    f1 = f1_score(labels, predicted_labels, average=type)
-    recall = recall_score(labels, predicted_labels, average=type)
-    precision = precision_score(labels, predicted_labels, average=type)
-    return acc, recall, precision, f1
+    """(accuracy, recall, precision, F1) with sklearn's class-support weighting — the tuple order the reference's
+    loops unpack (modules/train.py:23-30, used at :195 and :255)."""
+    from sklearn.metrics import accuracy_score, precision_recall_fscore_support
+    precision, recall, f1, _ = precision_recall_fscore_support(labels, predicted_labels, average=type, zero_division="warn")
+    return accuracy_score(labels, predicted_labels), recall, precision, f1
+
+
+def _pretrained_source(name: str):
+    """Where a model key comes from: ('clip' | 'bert' | None, key inside that checkpoint).  The reference's rule
+    (modules/train.py:95-107): a key containing 'vision' is looked up in the CLIP-ViT state dict with every 'vision_' and
+    'model.' removed; otherwise a key containing 'text' is looked up in the BERT state dict with 'text_' and 'model.' removed."""
+    for marker, source in (("vision", "clip"), ("text", "bert")):
+        if marker in name:
+            return source, name.replace(marker + "_", "").replace("model.", "")
+    return None, None
 
 
 def ingest_pretrained(model, clip_model_dict, bert_model_dict):
-    """The reference's key-rename ingest (modules/train.py:92-111): every CLIP-ViT / BERT key must be consumed."""
-    vision_names, text_names = [], []
-    model_dict = model.state_dict()
-    for name in model_dict:
-        if "vision" in name:
-            clip_name = name.replace("vision_", "").replace("model.", "")
-            if clip_name in clip_model_dict:
-                vision_names.append(clip_name)
-                model_dict[name] = clip_model_dict[clip_name]
-        elif "text" in name:
-            text_name = name.replace("text_", "").replace("model.", "")
-            if text_name in bert_model_dict:
-                text_names.append(text_name)
-                model_dict[name] = bert_model_dict[text_name]
-    assert len(vision_names) == len(clip_model_dict) and len(text_names) == len(bert_model_dict), \
-        (len(vision_names), len(clip_model_dict), len(text_names), len(bert_model_dict))
-    model.load_state_dict(model_dict)
+    """Copies pretrained CLIP-ViT / BERT tensors into the model by the rename rule above and insists, like the reference
+    (modules/train.py:109-110), that EVERY key of both checkpoints found a destination."""
+    merged = model.state_dict()
+    sources = {"clip": clip_model_dict, "bert": bert_model_dict}
+    used = {"clip": set(), "bert": set()}
+    for name in list(merged):
+        source, key = _pretrained_source(name)
+        if source is not None and key in sources[source]:
+            merged[name] = sources[source][key]
+            used[source].add(key)
+    for source, ckpt in sources.items():
+        missing = [k for k in ckpt if k not in used[source]]
+        assert not missing, f"{len(missing)} pretrained {source} tensors have no destination in the model, e.g. {missing[:5]}"
+    model.load_state_dict(merged)
 
 
-class BaseTrainer(object):
-    def train(self):
-        raise NotImplementedError()
-
-    def evaluate(self):
-        raise NotImplementedError()
-
-    def test(self):
-        raise NotImplementedError()
-
-
-class MSDTrainer(BaseTrainer):
+class MSDTrainer:
     def __init__(self, train_data=None, dev_data=None, test_data=None, model=None, args=None, logger=None,
                  writer=None) -> None:
         self.train_data, self.dev_data, self.test_data = train_data, dev_data, test_data
@@ -129,6 +123,9 @@ class MSDTrainer(BaseTrainer):
         t_train, t_mark, seen, warm = 0.0, None, 0, 5
         epoch = 0
         for epoch in range(1, self.args.num_epochs + 1):
+            sampler = getattr(self.train_data, "sampler", None)
+            if hasattr(sampler, "set_epoch"):  # DistributedSampler: a new shuffle every epoch
+                sampler.set_epoch(epoch)
             if self.step >= warm:
                 t_mark = time.time()
             for batch in self.train_data:
@@ -186,6 +183,10 @@ class MSDTrainer(BaseTrainer):
                 "loss": float(total_loss.item())}
 
     def evaluate(self, epoch):
+        # Data parallel: every rank evaluates the WHOLE dev set (the loaders of d2r_amd.run shard only the training set), on
+        # identical weights and — after the line below — identical BatchNorm running statistics, so every rank takes the
+        # same best-model decision and rank 0's checkpoint is the model all ranks hold.
+        self.dp.sync_buffers()
         self.model.eval()
         self.logger.info("***** Running evaluate *****")
         self.logger.info("  Num instance = %d", len(self.dev_data) * self.args.batch_size)
@@ -210,6 +211,7 @@ class MSDTrainer(BaseTrainer):
                 os.makedirs(self.args.save_path, exist_ok=True)
                 torch.save(self.model.state_dict(), self.args.save_path + "best_model.pth")
                 self.logger.info("Save best model at {}".format(self.args.save_path))
+            self.dp.barrier()  # nobody looks for / loads best_model.pth while rank 0 is still writing it
         self.model.train()
         return result
 

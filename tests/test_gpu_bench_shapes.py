@@ -1,0 +1,250 @@
+"""Parity AT THE SHAPES THE BENCHMARK RUNS (BASELINE configs[1] = C2: 32 x 128 text tokens = 4096 rows, 32 x 197 image
+tokens = 6304 rows, hidden 768 / 2304 / 3072) — the kernel variants that dominate bench.py's timed region:
+
+  * d2r_gemm in NT / NN / TN at (M,N,K) = (6304,3072,768), (6304,768,3072), (4096,2304,768), with the epilogues the
+    encoder layers use (bias + GELU with saved pre-activation, bias + residual, beta accumulation, the activation
+    backward `grad_ref` of the dX GEMM), against an fp64 product on the host;
+  * d2r_gemm_tn_grouped with the 7 x (3072 x 768) weight-gradient problems of a group of encoder layers;
+  * the single-head cross-modal attention core at Lq/Lk = 128/197 and 197/128 with the reference's real temperature
+    100/sqrt(768) on unit-variance tokens (near one-hot softmax), forward and backward;
+  * the whole UnimoModelF forward + backward at the C2 shape (12 + 12 layers, L = 128, 197 image tokens; batch 8 so that
+    every >= 1024-row LDS-DMA / grouped variant is taken) against the pinned oracle run in fp32 on the host.
+All product calls go through the C ABI.  Tolerances are written next to each assert."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GEMM_SHAPES = [(6304, 3072, 768), (6304, 768, 3072), (4096, 2304, 768)]
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed * 7919 + sum(shape))
+    return scale * torch.randn(tuple(shape), generator=g)
+
+
+def _gemm_desc(layout, M, N, K, A, B, Cc, *, dtype, c_dtype, bias=None, act=0, residual=None, preact=None, beta=0.0,
+               grad_ref=None, grad_act=0, ws=None):
+    from d2r_amd import _lib
+    lda = K if layout != _lib.GEMM_TN else M
+    ldb = K if layout == _lib.GEMM_NT else N
+    d = _lib.GemmDesc(dtype=dtype, c_dtype=c_dtype, layout=layout, act=act, M=M, N=N, K=K, nb=1, nh=1, alpha=1.0, beta=beta,
+                      A=A.data_ptr(), lda=lda, B=B.data_ptr(), ldb=ldb, C=Cc.data_ptr(), ldc=N,
+                      bias=None if bias is None else bias.data_ptr(),
+                      residual=None if residual is None else residual.data_ptr(), ldr=N,
+                      preact=None if preact is None else preact.data_ptr())
+    if grad_ref is not None:
+        d.grad_ref, d.grad_act = grad_ref.data_ptr(), grad_act
+    if ws is not None:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    return d
+
+
+def _call_gemm(d):
+    from d2r_amd import _lib
+    from d2r_amd.functional import _stream
+    _lib.call("d2r_gemm", C.byref(d), _stream())
+    torch.cuda.synchronize()
+
+
+def _max_rel(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gemm_nt_bias_gelu_preact_and_residual(gpu, shape):
+    """y = gelu(x W^T + b) with the saved pre-activation (FFN up-projection) and y = x W^T + b + r (output projections)."""
+    from d2r_amd import _lib
+    M, N, K = shape
+    x = _rnd(M, K, seed=1).bfloat16()
+    w = _rnd(N, K, seed=2, scale=0.03).bfloat16()
+    b = _rnd(N, seed=3, scale=0.5)
+    r = _rnd(M, N, seed=4).bfloat16()
+    ref = x.double() @ w.double().t() + b.double()
+    xg, wg, bg, rg = x.to(gpu), w.to(gpu), b.to(gpu), r.to(gpu)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=gpu)
+    pre = torch.empty_like(y)
+    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y, dtype=_lib.BF16, c_dtype=_lib.BF16, bias=bg, act=_lib.ACT_GELU, preact=pre))
+    # bf16 output: one rounding of an fp32-accumulated value -> <= 2^-8 relative per element (+ accumulation noise)
+    assert _max_rel(pre, ref) <= 6e-3
+    assert _max_rel(y, torch.nn.functional.gelu(ref)) <= 6e-3
+    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y, dtype=_lib.BF16, c_dtype=_lib.BF16, bias=bg, residual=rg))
+    assert _max_rel(y, ref + r.double()) <= 6e-3
+    # fp32 output of the same product: only the fp32 accumulation order differs from the fp64 sum
+    y32 = torch.empty(M, N, dtype=torch.float32, device=gpu)
+    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y32, dtype=_lib.BF16, c_dtype=_lib.F32, bias=bg))
+    assert _max_rel(y32, ref) <= 2e-5
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gemm_nn_dx_with_activation_backward_and_accumulate(gpu, shape):
+    """dX = dY W (NN, the direction no other test runs on the 128x128 LDS-DMA tile), (i) plain, (ii) multiplied by
+    gelu'(pre) in the epilogue (`grad_ref`: the FFN's activation backward), (iii) accumulated onto an existing
+    gradient (beta = 1: skip-connection / multi-consumer gradients)."""
+    from d2r_amd import _lib
+    M, N, K = shape  # output [M,N], reduction K: dY [M,K], W [K,N]
+    dy = _rnd(M, K, seed=5).bfloat16()
+    w = _rnd(K, N, seed=6, scale=0.03).bfloat16()
+    pre = _rnd(M, N, seed=7).bfloat16()
+    old = _rnd(M, N, seed=8).bfloat16()
+    ref = dy.double() @ w.double()
+    dyg, wg, preg = dy.to(gpu), w.to(gpu), pre.to(gpu)
+    dx = torch.empty(M, N, dtype=torch.bfloat16, device=gpu)
+    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, dx, dtype=_lib.BF16, c_dtype=_lib.BF16))
+    assert _max_rel(dx, ref) <= 6e-3
+    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, dx, dtype=_lib.BF16, c_dtype=_lib.BF16, grad_ref=preg, grad_act=_lib.ACT_GELU))
+    p = pre.double()
+    gelu_grad = 0.5 * (1 + torch.erf(p / math.sqrt(2))) + p * torch.exp(-0.5 * p * p) / math.sqrt(2 * math.pi)
+    assert _max_rel(dx, ref * gelu_grad) <= 6e-3
+    acc = old.to(gpu).clone()
+    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, acc, dtype=_lib.BF16, c_dtype=_lib.BF16, beta=1.0))
+    assert _max_rel(acc, ref + old.double()) <= 6e-3
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gemm_tn_weight_gradient_with_bias_gradient(gpu, shape):
+    """dW[N,K] += dY[M,N]^T X[M,K] reduced over the M token rows, fp32 output accumulated into a pre-filled sink, with
+    the bias gradient (column sums of dY) as a side product — split-K slabs + the fixed-order reduce."""
+    from d2r_amd import _lib
+    T, N, K = shape
+    dy = _rnd(T, N, seed=9).bfloat16()
+    x = _rnd(T, K, seed=10).bfloat16()
+    sink0, bsink0 = _rnd(N, K, seed=11), _rnd(N, seed=12)
+    ref = sink0.double() + dy.double().t() @ x.double()
+    refb = bsink0.double() + dy.double().sum(0)
+    sink, bsink = sink0.to(gpu), bsink0.to(gpu)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    d = _gemm_desc(_lib.GEMM_TN, N, K, T, dy.to(gpu), x.to(gpu), sink, dtype=_lib.BF16, c_dtype=_lib.F32, beta=1.0, ws=ws)
+    d.dbias = bsink.data_ptr()
+    _call_gemm(d)
+    assert _max_rel(sink, ref) <= 2e-5
+    assert _max_rel(bsink, refb) <= 2e-5
+
+
+def test_grouped_weight_gradients_of_seven_encoder_layers(gpu):
+    """d2r_gemm_tn_grouped exactly as a group of seven BertLayers launches it: 7 x (3072 x 768) over 4096 token rows, and
+    the transposed FFN-down shape 7 x (768 x 3072) (24 / 6 tile columns: both launch orders), accumulated into pre-filled
+    fp32 sinks with bias gradients."""
+    from d2r_amd import _lib
+    from d2r_amd.functional import _parr, _stream
+    for (T, N, K) in ((4096, 3072, 768), (4096, 768, 3072)):
+        n = 7
+        gs = [_rnd(T, N, seed=20 + i).bfloat16().to(gpu) for i in range(n)]
+        xs = [_rnd(T, K, seed=40 + i).bfloat16().to(gpu) for i in range(n)]
+        sinks = [_rnd(N, K, seed=60 + i).to(gpu) for i in range(n)]
+        bsinks = [_rnd(N, seed=80 + i).to(gpu) for i in range(n)]
+        want_w = [(s.double() + g.double().t() @ x.double()).cpu() for s, g, x in zip(sinks, gs, xs)]  # fp64 on the device: plumbing
+        want_b = [(b.double() + g.double().sum(0)).cpu() for b, g in zip(bsinks, gs)]
+        _lib.call("d2r_gemm_tn_grouped", _lib.BF16, N, K, T, N, K, K, _parr(gs), _parr(xs), _parr(sinks), _parr(bsinks), n, 1.0, _stream())
+        torch.cuda.synchronize()
+        for i in range(n):
+            assert _max_rel(sinks[i], want_w[i]) <= 2e-5, (T, N, K, i)
+            assert _max_rel(bsinks[i], want_b[i]) <= 2e-5, (T, N, K, i)
+
+
+def test_grouped_weight_gradient_rejects_a_repeated_sink(gpu):
+    """Two problems of one launch writing the same C (a parameter used at two call sites) would be a silent
+    read-modify-write race between workgroups: the C ABI refuses it."""
+    from d2r_amd import D2RError, _lib
+    from d2r_amd.functional import _parr, _stream
+    g = _rnd(128, 64).bfloat16().to(gpu)
+    x = _rnd(128, 64, seed=1).bfloat16().to(gpu)
+    sink = torch.zeros(64, 64, device=gpu)
+    with pytest.raises(D2RError):
+        _lib.call("d2r_gemm_tn_grouped", _lib.BF16, 64, 64, 128, 64, 64, 64, _parr([g, g]), _parr([x, x]), _parr([sink, sink]), None, 2, 1.0, _stream())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("lq,lk", [(128, 197), (197, 128)])
+def test_cross_modal_attention_core_at_the_real_temperature(gpu, dtype, lq, lk):
+    """softmax(100 q k^T / sqrt(768)) v on unit-variance tokens projected by default-init Linears (element std 0.58: the
+    logits have a standard deviation of ~33, the softmax is near one-hot — the regime the reference runs in, SURVEY.md
+    section 7), forward and backward against fp64 on identical (dtype-rounded) inputs.
+    Tolerance: 2e-5 (fp32) / 2.5e-2 (bf16: P and dS are rounded to bf16 MFMA operands) of the output / gradient scale."""
+    from d2r_amd import functional as F
+    B, E = 4, 768
+    scale = 100.0 / math.sqrt(E)
+    q = _rnd(B, lq, E, seed=1, scale=0.577).to(dtype)
+    k = _rnd(B, lk, E, seed=2, scale=0.577).to(dtype)
+    v = _rnd(B, lk, E, seed=3).to(dtype)
+    w = _rnd(B, lq, E, seed=4)
+    qg, kg, vg = (t.to(gpu).requires_grad_(True) for t in (q, k, v))
+    o = F.attention(qg, kg, vg, 1, scale)
+    (o.float() * w.to(gpu)).sum().backward()
+    torch.cuda.synchronize()
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    p = torch.softmax(scale * qr @ kr.transpose(1, 2), -1)
+    orf = p @ vr
+    (orf * w.double()).sum().backward()
+    assert float(p.max(-1).values.median()) > 0.9, "this test is meant to run in the near-one-hot regime"
+    tol = 2e-5 if dtype == torch.float32 else 2.5e-2
+    for name, got, ref in (("o", o, orf), ("dq", qg.grad, qr.grad), ("dk", kg.grad, kr.grad), ("dv", vg.grad, vr.grad)):
+        err = float((got.detach().double().cpu() - ref.detach()).abs().max())
+        s = float(ref.detach().abs().max())
+        assert err <= tol * s + 1e-7, f"{name}: err {err:.3e} vs scale {s:.3e} ({dtype}, Lq={lq}, Lk={lk})"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_model_at_the_benchmark_shape_vs_oracle(gpu, dtype):
+    """UnimoModelF forward + backward at the C2 shape (L = 128, 197 image tokens, 12 + 12 encoder layers, DR_step 3;
+    batch 8 -> 1024 text rows and 1576 image rows: every LDS-DMA / grouped GEMM variant, the whole-layer C calls, the
+    fused attention cores and the deferred grouped weight gradients of bench.py run) at the reference's construction-time
+    init, against the pinned oracle in fp32 on the host.
+
+    fp32 compute : |logits|, |loss| errors <= 2e-5; global gradient cosine >= 0.9999.
+    bf16 compute : the error is printed next to the emulated floor ("bf16 MFMA operands, fp32 everything else" applied
+                   to the oracle, tests/lowp_emulation.py); asserted: <= max(1e-3, 3 x floor) for logits and loss, global
+                   gradient cosine >= 0.9."""
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    from lowp_emulation import lowp_floor
+    from oracle import d2r_oracle as O
+    torch.manual_seed(2023)
+    layers, B, L = 12, 8, 128
+    tc = TextConfig(num_hidden_layers=layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vc = VisionConfig(num_hidden_layers=layers, image_size=224, patch_size=16)
+    model = M.UnimoModelF(default_args(), vc, tc)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = O.OracleConfig(text_layers=layers, vision_layers=layers, image_size=224, patch_size=16)
+    batch = O.synthetic_batch(cfg, B, L, seed=9, ragged=False)
+    ids, mask, tt, labels, images = batch
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    lo, logits_o, _ = O.forward(osd, cfg, ids, mask, tt, labels, images, train=True)
+    lo.backward()
+    model.to(gpu).set_compute_dtype(dtype).train()
+    ParamStore(model, dtype)
+    loss, logits = model(*[t.to(gpu) for t in batch])
+    loss.backward()
+    torch.cuda.synchronize()
+    e_logit = float((logits.double().cpu() - logits_o.detach().double()).abs().max())
+    e_loss = abs(float(loss) - float(lo))
+    dot = ng = nr = 0.0
+    for name, p in model.named_parameters():
+        ref = osd[name].grad
+        if ref is None:
+            continue
+        got = p.grad.detach().float().cpu()
+        assert torch.isfinite(got).all(), name
+        dot, ng, nr = dot + float((got.double() * ref.double()).sum()), ng + float(got.double().pow(2).sum()), nr + float(ref.double().pow(2).sum())
+    cos = dot / max((ng * nr) ** 0.5, 1e-300)
+    if dtype == torch.float32:
+        print(f"[C2-shape fp32] logits err {e_logit:.2e} loss err {e_loss:.2e} gradient cosine {cos:.6f}")
+        assert e_logit <= 2e-5 and e_loss <= 2e-5, (e_logit, e_loss)
+        assert cos >= 0.9999, cos
+    else:
+        fl, flog = lowp_floor(sd, cfg, batch, True, torch.bfloat16)
+        f_logit = float((flog.double() - logits_o.detach().double()).abs().max())
+        f_loss = abs(float(fl) - float(lo))
+        print(f"[C2-shape bf16] logits err {e_logit:.2e} (emulated bf16-operand floor {f_logit:.2e}) loss err {e_loss:.2e} "
+              f"(floor {f_loss:.2e}) gradient cosine {cos:.4f}; north-star tolerance 1e-3")
+        assert e_logit <= max(1e-3, 3 * f_logit), (e_logit, f_logit)
+        assert e_loss <= max(1e-3, 3 * f_loss), (e_loss, f_loss)
+        assert cos >= 0.9, cos

@@ -186,11 +186,20 @@ def test_data_parallel_two_ranks_on_one_gpu(gpu, tmp_path):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "probes", "dp_two_ranks_one_gpu.py"), str(tmp_path)]
+    # A hang (deadlocked collective, a bucket that never becomes ready) must FAIL: the probe dumps every thread's
+    # traceback and exits after 150 s (faulthandler), and whatever is left after 240 s is killed by process group.
+    import signal
+    proc = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                            env=dict(os.environ, D2R_PROBE_DUMP_S="150", D2R_PROBE_VERBOSE="1"))
     try:
-        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=180)
+        out, err = proc.communicate(timeout=240)
     except subprocess.TimeoutExpired:
-        pytest.skip("the two gloo ranks did not finish in 180 s on this box (host-staged 0.7 GB all-reduces; usually 10-20 s)")
-    assert r.returncode == 0, r.stderr[-3000:]
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        pytest.fail("the two data-parallel ranks did not finish in 240 s (usually 10-20 s): hang.\n--- stdout\n"
+                    + out[-3000:] + "\n--- stderr\n" + err[-6000:])
+    assert proc.returncode == 0, "two-rank probe failed (a faulthandler dump below means it hung for 150 s)\n--- stdout\n" \
+        + out[-3000:] + "\n--- stderr\n" + err[-6000:]
     for rank in (0, 1):
         res = torch.load(os.path.join(str(tmp_path), f"rank{rank}.pt"))
         assert res["finite"] and all(l == l for l in res["losses"]), res

@@ -103,6 +103,48 @@ def test_ingest_rename_rule_and_coverage_assert():
         ingest_pretrained(model, clip, bert)
 
 
+def test_ingest_consumes_every_key_of_real_huggingface_checkpoints():
+    """modules/train.py:92-111 against the key lists the reference really passes in (run.py:124-153):
+    ``CLIPModel(...).vision_model.state_dict()`` and ``BertModel(...).state_dict()`` built offline from configs (random
+    weights; 2 layers to keep it light — the key pattern per layer is what matters).  Every tensor of both checkpoints
+    must find a destination, the values must arrive, and nothing else in the model may change."""
+    transformers = pytest.importorskip("transformers")
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd import modules as M
+    from d2r_amd.train import ingest_pretrained
+    layers = 2
+    bcfg = transformers.BertConfig(num_hidden_layers=layers)
+    ccfg = transformers.CLIPVisionConfig(num_hidden_layers=layers, image_size=64, patch_size=32)
+    torch.manual_seed(0)
+    bert_sd = transformers.BertModel(bcfg).state_dict()
+    clip_model = transformers.CLIPModel(transformers.CLIPConfig(vision_config=ccfg.to_dict(), text_config=dict(num_hidden_layers=1)))
+    clip_sd = clip_model.vision_model.state_dict()  # exactly what run.py:126,151 hands to the trainer
+    assert any(k.startswith("encoder.layer.1.") for k in bert_sd) and "pooler.dense.weight" in bert_sd
+    assert "embeddings.patch_embedding.weight" in clip_sd and "pre_layrnorm.weight" in clip_sd
+    model = M.UnimoModelF(default_args(), VisionConfig(num_hidden_layers=layers, image_size=64, patch_size=32),
+                          TextConfig(num_hidden_layers=layers))
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    ingest_pretrained(model, clip_sd, bert_sd)
+    after = model.state_dict()
+    # spot values, one per family
+    pairs = [("model.encoder.text_layer.1.attention.self.query.weight", bert_sd["encoder.layer.1.attention.self.query.weight"]),
+             ("model.text_embeddings.word_embeddings.weight", bert_sd["embeddings.word_embeddings.weight"]),
+             ("model.text_pooler.dense.weight", bert_sd["pooler.dense.weight"]),
+             ("model.encoder.vision_layers.0.mlp.fc1.weight", clip_sd["encoder.layers.0.mlp.fc1.weight"]),
+             ("model.vision_embeddings.patch_embedding.weight", clip_sd["embeddings.patch_embedding.weight"]),
+             ("model.vision_pre_layrnorm.weight", clip_sd["pre_layrnorm.weight"]),
+             ("model.vision_post_layernorm.bias", clip_sd["post_layernorm.bias"])]
+    for name, src in pairs:
+        assert torch.equal(after[name], src), name
+    n_float = lambda sd: sum(1 for v in sd.values())
+    changed = [k for k in after if not torch.equal(after[k], before[k])]
+    assert len(changed) <= n_float(bert_sd) + n_float(clip_sd)
+    assert not [k for k in changed if "itr_module" in k or "block_fusion" in k or k.startswith("fc.")], "ingest touched routing / head weights"
+    # a checkpoint key without a destination is an error, as in the reference
+    with pytest.raises(AssertionError):
+        ingest_pretrained(model, dict(clip_sd, **{"encoder.layers.99.bogus": torch.zeros(1)}), bert_sd)
+
+
 def test_library_exports_every_declared_symbol():
     from d2r_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "d2r_hip.h")).read()
