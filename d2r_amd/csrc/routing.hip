@@ -16,7 +16,8 @@ struct MPtrs8 {
 };
 
 #define TH_GATE 1e-4f          /* self.threshold (models/DynamicInteraction.py:24) */
-#define TH_GATE_FINAL ((float)(1e-4 / 6.0))
+// final layer: self.threshold / self.num_cell (models/DynamicInteraction.py:109), evaluated in double like Python, compared in fp32
+__device__ __forceinline__ float th_gate_final(int nc) { return (float)(1e-4 / (double)nc); }
 #define EPS_NORM 1e-8f
 
 // =====================================================================================================
@@ -114,7 +115,10 @@ extern "C" int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, i
 }
 
 // =====================================================================================================
-// K8 forward.  gates: fp32 [6, B, P] (cell-major).  Cells 1 (GLAC) and 5 (GESC) are [B,D] broadcasts.
+// K8 forward.  gates: fp32 [nc, B, P] (cell-major).  Cells 1 (GLAC) and 5 (GESC) are [B,D] broadcasts.
+// nc = number of cells of the layer: the first nc of [RIC, GLAC, IMRC, CMRC, CRCMC, GESC] (6 in the reference, which
+// hard-indexes them, models/DynamicInteraction.py:41-48; 2..5 = the declared-subset extension of SURVEY.md section 8c);
+// P = nc outputs (first / middle layers) or 1 (final layer).  probs: [B, P, nc].
 // =====================================================================================================
 template <typename T, int VEC>
 __device__ __forceinline__ void ld_f(const T* p, float (&o)[VEC]) {
@@ -132,7 +136,7 @@ __device__ __forceinline__ void st_f(T* p, const float (&o)[VEC]) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* __restrict__ gates, int B, int L, int D,
-                                                       MPtrs8 outs, float* __restrict__ probs) {
+                                                       int nc, MPtrs8 outs, float* __restrict__ probs) {
   constexpr int VEC = PackOf<T>::N;
   __shared__ float c[6][6];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* 
     float g[6], S = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = gates[((int64_t)j * B + b) * 6 + i];
+      g[j] = (j < nc && i < nc) ? gates[((int64_t)j * B + b) * nc + i] : 0.f;
       S += g[j];
     }
     const float skip = S < TH_GATE ? 1.f : 0.f;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* 
     for (int j = 0; j < 6; ++j) {
       const float ph = g[j] / (S + EPS_NORM);
       c[i][j] = ph + (j == 0 ? skip : 0.f);
-      if (blockIdx.x == 0) probs[((int64_t)b * 6 + i) * 6 + j] = ph;
+      if (blockIdx.x == 0 && i < nc && j < nc) probs[((int64_t)b * nc + i) * nc + j] = ph;
     }
   }
   __syncthreads();
@@ -162,13 +166,18 @@ __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* 
     ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, e[0]);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) e[0][j] = fmaxf(e[0][j], 0.f);
-    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[1]) + boff, e[1]);
-    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[2]) + off, e[2]);
-    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[3]) + off, e[3]);
-    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[4]) + off, e[4]);
-    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e[5]);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {  // (absent cells of a declared subset: zero coefficient, nothing read; block-uniform)
+      if (k < nc) {
+        ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + ((k == 1 || k == 5) ? boff : off), e[k]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) e[k][j] = 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
+      if (i >= nc) break;
       float o[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -185,19 +194,20 @@ __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* 
 // final layer (P = 1): out = sum_j (g_j emb_j + s_j ref_j) / (sum s + sum g)
 template <typename T>
 __global__ __launch_bounds__(256) void agg_fwd1_kernel(Ptrs8 embs, Ptrs8 refs, const float* __restrict__ gates, int B,
-                                                       int L, int D, T* __restrict__ out, float* __restrict__ probs) {
+                                                       int L, int D, int nc, T* __restrict__ out, float* __restrict__ probs) {
   constexpr int VEC = PackOf<T>::N;
   __shared__ float cg[6], cs[6];
   const int b = blockIdx.y, tid = threadIdx.x;
   if (tid == 0) {
     float g[6], s[6], sg = 0.f, ss = 0.f;
+    const float thf = th_gate_final(nc);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = gates[(int64_t)j * B + b];
-      s[j] = g[j] < TH_GATE_FINAL ? 1.f : 0.f;
+      g[j] = j < nc ? gates[(int64_t)j * B + b] : 0.f;
+      s[j] = (j < nc && g[j] < thf) ? 1.f : 0.f;
       sg += g[j];
       ss += s[j];
-      if (blockIdx.x == 0) probs[(int64_t)b * 6 + j] = g[j];
+      if (blockIdx.x == 0 && j < nc) probs[(int64_t)b * nc + j] = g[j];
     }
     const float inv = 1.f / (ss + sg);
 #pragma unroll
@@ -218,6 +228,7 @@ __global__ __launch_bounds__(256) void agg_fwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
     for (int j = 0; j < VEC; ++j) o[j] = cg[0] * fmaxf(e[j], 0.f) + cs[0] * e[j];
 #pragma unroll
     for (int k = 1; k < 6; ++k) {
+      if (k >= nc) break;
       const bool bc = (k == 1 || k == 5);
       ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + (bc ? boff : off), e);
 #pragma unroll
@@ -239,17 +250,18 @@ static int agg_chunks(int L, int D, int VEC) {
 }
 
 extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, const void* const* h_refs,
-                                       const float* gates, int B, int L, int D, int P, void* const* h_outs,
+                                       const float* gates, int B, int L, int D, int ncell, int P, void* const* h_outs,
                                        float* probs, void* stream) {
   D2R_REQUIRE(h_embs && gates && h_outs && probs, "d2r_route_aggregate_fwd: null pointer");
-  D2R_REQUIRE(P == 6 || P == 1, "d2r_route_aggregate_fwd: P=%d (must be 6 or 1)", P);
-  D2R_REQUIRE(P == 6 || h_refs, "d2r_route_aggregate_fwd: the final layer needs refs");
+  D2R_REQUIRE(ncell >= 2 && ncell <= 6, "d2r_route_aggregate_fwd: ncell=%d (2..6)", ncell);
+  D2R_REQUIRE(P == ncell || P == 1, "d2r_route_aggregate_fwd: P=%d (must be ncell=%d or 1)", P, ncell);
+  D2R_REQUIRE(P != 1 || h_refs, "d2r_route_aggregate_fwd: the final layer needs refs");
   D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_route_aggregate_fwd: bad dtype %d", dtype);
   const int VEC = dtype == D2R_BF16 ? 8 : 4;
   D2R_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D % VEC == 0, "d2r_route_aggregate_fwd: bad shape B=%d L=%d D=%d", B, L, D);
   Ptrs8 e{}, r{};
   MPtrs8 o{};
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < ncell; ++j) {
     e.p[j] = h_embs[j];
     D2R_REQUIRE(e.p[j] && d2r_aligned16(e.p[j]), "d2r_route_aggregate_fwd: emb %d null or unaligned", j);
     if (P == 1) {
@@ -263,12 +275,12 @@ extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, con
   }
   dim3 grid(agg_chunks(L, D, VEC), B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (P == 6) {
-    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd6_kernel<bf16_t>), grid, block, 0, st, e, gates, B, L, D, o, probs);
-    else hipLaunchKernelGGL((agg_fwd6_kernel<float>), grid, block, 0, st, e, gates, B, L, D, o, probs);
+  if (P != 1) {
+    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd6_kernel<bf16_t>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs);
+    else hipLaunchKernelGGL((agg_fwd6_kernel<float>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs);
   } else {
-    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd1_kernel<bf16_t>), grid, block, 0, st, e, r, gates, B, L, D, (bf16_t*)o.p[0], probs);
-    else hipLaunchKernelGGL((agg_fwd1_kernel<float>), grid, block, 0, st, e, r, gates, B, L, D, (float*)o.p[0], probs);
+    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd1_kernel<bf16_t>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (bf16_t*)o.p[0], probs);
+    else hipLaunchKernelGGL((agg_fwd1_kernel<float>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (float*)o.p[0], probs);
   }
   return d2r_check_launch("d2r_route_aggregate_fwd");
 }
@@ -295,7 +307,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[N], float* sh /*
 
 template <typename T>
 __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* __restrict__ gates, Ptrs8 douts, int B,
-                                                       int L, int D, MPtrs8 dembs, float* __restrict__ ws_dots,
+                                                       int L, int D, int nc, MPtrs8 dembs, float* __restrict__ ws_dots,
                                                        float* __restrict__ ws_bc) {
   constexpr int VEC = PackOf<T>::N;
   extern __shared__ float dsh[];  // [RG][2][D] broadcast partials, then reused for the dot reduction
@@ -306,13 +318,13 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
     float g[6], S = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = gates[((int64_t)j * B + b) * 6 + i];
+      g[j] = (j < nc && i < nc) ? gates[((int64_t)j * B + b) * nc + i] : 0.f;
       S += g[j];
     }
-    const float skip = S < TH_GATE ? 1.f : 0.f;
+    const float skip = (i < nc && S < TH_GATE) ? 1.f : 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      c[i][j] = g[j] / (S + EPS_NORM) + (j == 0 ? skip : 0.f);
+      c[i][j] = g[j] / (S + EPS_NORM) + (j == 0 ? skip : 0.f);  // (absent output i >= nc: all zero)
     }
   }
   __syncthreads();
@@ -330,12 +342,19 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
   if (active) {
     const int64_t boff = (int64_t)b * D + pk * VEC;
     ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[1]) + boff, e1);
-    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
+    if (nc > 5) ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
     for (int l = l0 + rg; l < l1; l += RG) {
       const int64_t off = ((int64_t)b * L + l) * D + pk * VEC;
       float dv[6][VEC], x0[VEC], e[VEC], o[VEC];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) ld_f<T, VEC>(reinterpret_cast<const T*>(douts.p[i]) + off, dv[i]);
+      for (int i = 0; i < 6; ++i) {
+        if (i < nc) {
+          ld_f<T, VEC>(reinterpret_cast<const T*>(douts.p[i]) + off, dv[i]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dv[i][j] = 0.f;
+        }
+      }
       // cell 0 (RIC): emb = relu(x0)
       ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, x0);
 #pragma unroll
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
       // full cells 2,3,4
 #pragma unroll
       for (int k = 2; k <= 4; ++k) {
+        if (k >= nc) break;
         ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, e);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -404,23 +424,24 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
                                                               const float* __restrict__ dprobs,
                                                               const float* __restrict__ ws_dots,
                                                               const float* __restrict__ ws_bc, int B, int D, int nchunk,
-                                                              T* __restrict__ demb1, T* __restrict__ demb5,
+                                                              int nc, T* __restrict__ demb1, T* __restrict__ demb5,
                                                               float* __restrict__ d_gates) {
   __shared__ float dph[36];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (blockIdx.y == 0) {  // block-uniform: only the first column block finishes the 36 dot products
   if (tid < 36) {
-    float t = dprobs ? dprobs[(int64_t)b * 36 + tid] : 0.f;
+    const int i = tid / 6, j = tid - i * 6;
+    float t = (dprobs && i < nc && j < nc) ? dprobs[((int64_t)b * nc + i) * nc + j] : 0.f;
     for (int cidx = 0; cidx < nchunk; ++cidx) t += ws_dots[((int64_t)b * nchunk + cidx) * 36 + tid];
     dph[tid] = t;
   }
   __syncthreads();
-  if (tid < 6) {
+  if (tid < nc) {
     const int i = tid;
     float g[6], S = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = gates[((int64_t)j * B + b) * 6 + i];
+      g[j] = j < nc ? gates[((int64_t)j * B + b) * nc + i] : 0.f;
       S += g[j];
     }
     const float inv = 1.f / (S + EPS_NORM);
@@ -428,7 +449,8 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 6; ++j) dotp += dph[i * 6 + j] * (g[j] * inv);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) d_gates[((int64_t)j * B + b) * 6 + i] = (dph[i * 6 + j] - dotp) * inv;
+    for (int j = 0; j < 6; ++j)
+      if (j < nc) d_gates[((int64_t)j * B + b) * nc + i] = (dph[i * 6 + j] - dotp) * inv;
   }
   }
   const int cidx = blockIdx.y * 256 + tid;  // one column of [demb1 | demb5] per thread, grid.y column blocks
@@ -445,7 +467,7 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
     for (; k < nchunk; ++k) t0 += w[(int64_t)k * 2 * D];
     const float t = (t0 + t1) + (t2 + t3);
     if (cidx < D) demb1[(int64_t)b * D + cidx] = from_f<T>(t);
-    else demb5[(int64_t)b * D + cidx - D] = from_f<T>(t);
+    else if (demb5) demb5[(int64_t)b * D + cidx - D] = from_f<T>(t);
   }
 }
 
@@ -453,7 +475,7 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
 template <typename T>
 __global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, const float* __restrict__ gates,
                                                        const T* __restrict__ dout, const T* __restrict__ out, int B,
-                                                       int L, int D, MPtrs8 dembs, MPtrs8 drefs,
+                                                       int L, int D, int nc, MPtrs8 dembs, MPtrs8 drefs,
                                                        float* __restrict__ ws_dots, float* __restrict__ ws_bc) {
   constexpr int VEC = PackOf<T>::N;
   extern __shared__ float dsh[];  // [RG][D]
@@ -461,10 +483,11 @@ __global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, tid = threadIdx.x;
   if (tid == 0) {
     float g[6], s[6], sg = 0.f, ss = 0.f;
+    const float thf = th_gate_final(nc);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = gates[(int64_t)j * B + b];
-      s[j] = g[j] < TH_GATE_FINAL ? 1.f : 0.f;
+      g[j] = j < nc ? gates[(int64_t)j * B + b] : 0.f;
+      s[j] = (j < nc && g[j] < thf) ? 1.f : 0.f;
       sg += g[j];
       ss += s[j];
     }
@@ -490,7 +513,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
   if (active) {
     const int64_t boff = (int64_t)b * D + pk * VEC;
     ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[1]) + boff, e1);
-    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
+    if (nc > 5) ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
     for (int l = l0 + rg; l < l1; l += RG) {
       const int64_t off = ((int64_t)b * L + l) * D + pk * VEC;
       float dv[VEC], e[VEC], o[VEC];
@@ -512,6 +535,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
       st_f<T, VEC>(reinterpret_cast<T*>(dembs.p[0]) + off, o);
 #pragma unroll
       for (int k = 2; k <= 4; ++k) {
+        if (k >= nc) break;
         ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, e);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -522,6 +546,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
+        if (k >= nc) break;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = cs[k] * dv[j];
         st_f<T, VEC>(reinterpret_cast<T*>(drefs.p[k]) + off, o);
@@ -546,7 +571,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
                                                               const float* __restrict__ dprobs,
                                                               const float* __restrict__ ws_dots,
                                                               const float* __restrict__ ws_bc, int B, int D, int nchunk,
-                                                              T* __restrict__ demb1, T* __restrict__ demb5,
+                                                              int nc, T* __restrict__ demb1, T* __restrict__ demb5,
                                                               float* __restrict__ d_gates) {
   __shared__ float dt[8], cgs[6];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -558,17 +583,18 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
   __syncthreads();
   if (tid == 0) {  // every column block recomputes the coefficients; only block y==0 stores d_gates
     float g[6], sg = 0.f, ss = 0.f;
+    const float thf = th_gate_final(nc);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = gates[(int64_t)j * B + b];
-      ss += g[j] < TH_GATE_FINAL ? 1.f : 0.f;
+      g[j] = j < nc ? gates[(int64_t)j * B + b] : 0.f;
+      ss += (j < nc && g[j] < thf) ? 1.f : 0.f;
       sg += g[j];
     }
     const float inv = 1.f / (ss + sg);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       cgs[j] = g[j] * inv;
-      if (blockIdx.y == 0) d_gates[(int64_t)j * B + b] = (dt[j] - dt[6]) * inv + (dprobs ? dprobs[(int64_t)b * 6 + j] : 0.f);
+      if (blockIdx.y == 0 && j < nc) d_gates[(int64_t)j * B + b] = (dt[j] - dt[6]) * inv + (dprobs ? dprobs[(int64_t)b * nc + j] : 0.f);
     }
   }
   __syncthreads();
@@ -586,25 +612,26 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
     for (; k < nchunk; ++k) t0 += w[(int64_t)k * D];
     const float t = (t0 + t1) + (t2 + t3);
     demb1[(int64_t)b * D + cidx] = from_f<T>(cgs[1] * t);
-    demb5[(int64_t)b * D + cidx] = from_f<T>(cgs[5] * t);
+    if (demb5) demb5[(int64_t)b * D + cidx] = from_f<T>(cgs[5] * t);
   }
 }
 
 extern "C" size_t d2r_route_aggregate_bwd_workspace(int B, int L, int D, int P) {
   const size_t nchunk = (size_t)((L + AGG_LC - 1) / AGG_LC);
-  return (size_t)B * nchunk * ((P == 6 ? 36 : 8) + (size_t)(P == 6 ? 2 : 1) * D) * sizeof(float);
+  return (size_t)B * nchunk * ((P != 1 ? 36 : 8) + (size_t)(P != 1 ? 2 : 1) * D) * sizeof(float);
 }
 
 // d_probs: gradient flowing into the returned path probabilities (sim_paths -> JS loss), may be NULL;
 // h_outs: the forward outputs (only outs[0] of the final layer is read).
 extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, const void* const* h_refs,
                                           const float* gates, const void* const* h_douts, const void* const* h_outs,
-                                          const float* d_probs, int B, int L, int D, int P, void* const* h_dembs,
-                                          void* const* h_drefs, float* d_gates, void* workspace,
+                                          const float* d_probs, int B, int L, int D, int ncell, int P,
+                                          void* const* h_dembs, void* const* h_drefs, float* d_gates, void* workspace,
                                           size_t workspace_bytes, void* stream) {
   D2R_REQUIRE(h_embs && gates && h_douts && h_dembs && d_gates, "d2r_route_aggregate_bwd: null pointer");
-  D2R_REQUIRE(P == 6 || P == 1, "d2r_route_aggregate_bwd: P=%d (must be 6 or 1)", P);
-  D2R_REQUIRE(P == 6 || (h_refs && h_drefs && h_outs), "d2r_route_aggregate_bwd: the final layer needs refs, d_refs and outs");
+  D2R_REQUIRE(ncell >= 2 && ncell <= 6, "d2r_route_aggregate_bwd: ncell=%d (2..6)", ncell);
+  D2R_REQUIRE(P == ncell || P == 1, "d2r_route_aggregate_bwd: P=%d (must be ncell=%d or 1)", P, ncell);
+  D2R_REQUIRE(P != 1 || (h_refs && h_drefs && h_outs), "d2r_route_aggregate_bwd: the final layer needs refs, d_refs and outs");
   D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_route_aggregate_bwd: bad dtype %d", dtype);
   const int VEC = dtype == D2R_BF16 ? 8 : 4;
   D2R_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D % VEC == 0 && D / VEC <= 256, "d2r_route_aggregate_bwd: bad shape B=%d L=%d D=%d", B, L, D);
@@ -612,7 +639,7 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     return d2r_fail(D2R_ERR_WORKSPACE, "d2r_route_aggregate_bwd: workspace %zu < %zu", workspace_bytes, d2r_route_aggregate_bwd_workspace(B, L, D, P));
   Ptrs8 e{}, r{}, dv{};
   MPtrs8 de{}, dr{};
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < ncell; ++j) {
     e.p[j] = h_embs[j];
     de.p[j] = h_dembs[j];
     D2R_REQUIRE(e.p[j] && de.p[j] && d2r_aligned16(e.p[j]) && d2r_aligned16(de.p[j]), "d2r_route_aggregate_bwd: emb/d_emb %d null or unaligned", j);
@@ -629,18 +656,18 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
   const int nchunk = (L + AGG_LC - 1) / AGG_LC;
   const int RG = 256 / (D / VEC);
   float* ws_dots = (float*)workspace;
-  float* ws_bc = ws_dots + (size_t)B * nchunk * (P == 6 ? 36 : 8);
+  float* ws_bc = ws_dots + (size_t)B * nchunk * (P != 1 ? 36 : 8);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nchunk, B), block(256);
-  if (P == 6) {
+  if (P != 1) {
     size_t shmem = (size_t)RG * 2 * D * sizeof(float);
     if (shmem < 4 * 36 * sizeof(float)) shmem = 4 * 36 * sizeof(float);
     if (dtype == D2R_BF16) {
-      hipLaunchKernelGGL((agg_bwd6_kernel<bf16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, de, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd6_kernel<bf16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
     } else {
-      hipLaunchKernelGGL((agg_bwd6_kernel<float>), grid, block, shmem, st, e, gates, dv, B, L, D, de, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (float*)de.p[1], (float*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd6_kernel<float>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, (float*)de.p[1], (float*)de.p[5], d_gates);
     }
   } else {
     const void* outp = h_outs[0];
@@ -648,11 +675,11 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     size_t shmem = (size_t)RG * D * sizeof(float);
     if (shmem < 4 * 8 * sizeof(float)) shmem = 4 * 8 * sizeof(float);
     if (dtype == D2R_BF16) {
-      hipLaunchKernelGGL((agg_bwd1_kernel<bf16_t>), grid, block, shmem, st, e, r, gates, (const bf16_t*)dv.p[0], (const bf16_t*)outp, B, L, D, de, dr, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd1_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd1_kernel<bf16_t>), grid, block, shmem, st, e, r, gates, (const bf16_t*)dv.p[0], (const bf16_t*)outp, B, L, D, ncell, de, dr, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
     } else {
-      hipLaunchKernelGGL((agg_bwd1_kernel<float>), grid, block, shmem, st, e, r, gates, (const float*)dv.p[0], (const float*)outp, B, L, D, de, dr, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd1_finish_kernel<float>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, (float*)de.p[1], (float*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd1_kernel<float>), grid, block, shmem, st, e, r, gates, (const float*)dv.p[0], (const float*)outp, B, L, D, ncell, de, dr, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<float>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, (float*)de.p[1], (float*)de.p[5], d_gates);
     }
   }
   return d2r_check_launch("d2r_route_aggregate_bwd");

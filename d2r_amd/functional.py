@@ -1131,62 +1131,66 @@ def mean_pool(xs: Sequence[torch.Tensor]) -> torch.Tensor:
 
 
 class _RouteAggregate(torch.autograd.Function):
-    """K8: outs_i = sum_j p_hat[i,j] emb_j + gate_i relu(x0)  (P=6), or the final-layer rule (P=1)."""
+    """K8: outs_i = sum_j p_hat[i,j] emb_j + gate_i relu(x0)  (P = ncell), or the final-layer rule (P = 1).
+    ncell cells = the first ncell of [RIC, GLAC, IMRC, CMRC, CRCMC, GESC] (6 in the reference)."""
 
     @staticmethod
-    def forward(ctx, gates, x0, e1, e2, e3, e4, e5, *refs):
-        embs = [t.contiguous() for t in (x0, e1, e2, e3, e4, e5)]
+    def forward(ctx, gates, nc, *tensors):
+        embs = [t.contiguous() for t in tensors[:nc]]
+        refs = [r.contiguous() for r in tensors[nc:]]
         gates = gates.contiguous()
         B, L, D = embs[0].shape
         P = gates.shape[2]
+        assert gates.shape[0] == nc and P in (nc, 1)
         final = P == 1
-        refs = [r.contiguous() for r in refs]
         if final:
-            assert len(refs) == 5, "the final layer takes ref_1..ref_5 (ref_0 is x0)"
+            assert len(refs) == nc - 1, "the final layer takes ref_1..ref_{ncell-1} (ref_0 is x0)"
             all_refs = [embs[0]] + refs
         outs = [torch.empty(B, L, D, dtype=embs[0].dtype, device=embs[0].device) for _ in range(P)]
-        probs = torch.empty(B, P, 6, dtype=torch.float32, device=gates.device)
+        probs = torch.empty(B, P, nc, dtype=torch.float32, device=gates.device)
+        nfull = nc - 1 - (1 if nc > 5 else 0)  # cells with a [B,L,D] output (1 and 5 are per-sample broadcasts)
         _lib.call("d2r_route_aggregate_fwd", _dt(embs[0]), _parr(embs), _parr(all_refs) if final else None,
-                  gates.data_ptr(), B, L, D, P, _parr(outs), probs.data_ptr(), _stream(),
+                  gates.data_ptr(), B, L, D, nc, P, _parr(outs), probs.data_ptr(), _stream(),
                   meta=dict(group=f"route_aggregate_fwd_P{P}",
-                            bytes=float(((4 + P) * B * L * D + 2 * B * D) * embs[0].element_size() + 4 * B * P * 12)))
-        ctx.meta = (B, L, D, P)
+                            bytes=float(((nfull + P) * B * L * D + (nc - nfull) * B * D) * embs[0].element_size() + 4 * B * P * 2 * nc)))
+        ctx.meta = (B, L, D, P, nc)
         ctx.save_for_backward(gates, *embs, *refs, *(outs if final else []))
         ctx.mark_non_differentiable()
         return (probs, *outs)
 
     @staticmethod
     def backward(ctx, dprobs, *douts):
-        B, L, D, P = ctx.meta
+        B, L, D, P, nc = ctx.meta
         final = P == 1
         saved = ctx.saved_tensors
-        gates, embs = saved[0], list(saved[1:7])
-        refs = list(saved[7:12]) if final else []
-        out_saved = [saved[12]] if final else []
+        gates, embs = saved[0], list(saved[1:1 + nc])
+        refs = list(saved[1 + nc:2 * nc]) if final else []
+        out_saved = [saved[2 * nc]] if final else []
         dev, dtype = embs[0].device, embs[0].dtype
         douts = [(d if d is not None else torch.zeros(B, L, D, dtype=dtype, device=dev)).contiguous() for d in douts]
         dprobs = None if dprobs is None else dprobs.contiguous()
         dembs = [torch.empty_like(e) for e in embs]
-        drefs = [torch.empty(B, L, D, dtype=dtype, device=dev) for _ in range(6)] if final else None
+        drefs = [torch.empty(B, L, D, dtype=dtype, device=dev) for _ in range(nc)] if final else None
         dgates = torch.empty_like(gates)
         nbytes = _lib.load().d2r_route_aggregate_bwd_workspace(B, L, D, P)
         ws = _workspace(nbytes, dev)
+        nfull = nc - 1 - (1 if nc > 5 else 0)
         _lib.call("d2r_route_aggregate_bwd", _dt(embs[0]), _parr(embs), _parr([embs[0]] + refs) if final else None,
-                  gates.data_ptr(), _parr(douts), _parr(out_saved) if final else None, _ptr(dprobs), B, L, D, P,
+                  gates.data_ptr(), _parr(douts), _parr(out_saved) if final else None, _ptr(dprobs), B, L, D, nc, P,
                   _parr(dembs), _parr(drefs) if final else None, dgates.data_ptr(), ws.data_ptr(), ws.numel(),
                   _stream(), meta=dict(group=f"route_aggregate_bwd_P{P}",
-                                       bytes=float(((P + 4 + 4 + (6 if final else 0) + (1 if final else 0)) * B * L * D
-                                                    + 4 * B * D) * embs[0].element_size())))
+                                       bytes=float(((P + 2 * nfull + (nc if final else 0) + (1 if final else 0)) * B * L * D
+                                                    + 2 * (nc - nfull) * B * D) * embs[0].element_size())))
         if final:
             # ref_0 is x0 itself: relu path + skip path
             dx0 = add(dembs[0], drefs[0])
-            return (dgates, dx0, *dembs[1:], *drefs[1:])
-        return (dgates, *dembs)
+            return (dgates, None, dx0, *dembs[1:], *drefs[1:])
+        return (dgates, None, *dembs)
 
 
-def route_aggregate(gates, x0, e1, e2, e3, e4, e5, refs: Optional[Sequence[torch.Tensor]] = None):
-    """gates fp32 [6,B,P]; returns (probs [B,P,6], [outs])."""
-    res = _RouteAggregate.apply(gates, x0, e1, e2, e3, e4, e5, *(refs or ()))
+def route_aggregate(gates, *embs, refs: Optional[Sequence[torch.Tensor]] = None):
+    """gates fp32 [ncell,B,P]; embs: the ncell cell outputs (embs[0] = the RIC input); returns (probs [B,P,ncell], [outs])."""
+    res = _RouteAggregate.apply(gates, len(embs), *embs, *(refs or ()))
     return res[0], list(res[1:])
 
 

@@ -338,18 +338,23 @@ class _RoutingLayer(D2RModule):
 
     def __init__(self, args, num_cell, num_out_path):
         super().__init__()
-        assert num_cell == 6, "the reference hard-indexes six cells (models/DynamicInteraction.py:39-48)"
+        # The reference hard-indexes six cells (models/DynamicInteraction.py:39-48: any other num_cell crashes there).
+        # num_cell in 2..5 is the declared-subset EXTENSION of SURVEY.md section 8c (BASELINE configs[4]: 4 cells): the
+        # layer owns the first num_cell cells of CELL_ORDER (and only their parameters), normalises the path
+        # probabilities over them, and the final layer gates at self.threshold / self.num_cell.
+        if not 2 <= num_cell <= 6:
+            raise ValueError(f"num_cell={num_cell}: a routing layer has 2..6 cells ({', '.join(CELL_ORDER)} in this order)")
         self.num_cell, self.num_out_path = num_cell, num_out_path
         self.threshold, self.eps = 1e-4, 1e-8
-        self.ric = RectifiedIdentityCell(args, num_out_path)
-        self.imrc = IntraModelReasoningCell(args, num_out_path)
-        self.glac = GlobalLocalAlignmentCell(args, num_out_path)
-        self.cmrc = CrossModalRefinementCell(args, num_out_path)
-        self.crcmc = ContextRichCrossModalCell(args, num_out_path)
-        self.gesc = GlobalEnhancedSemanticCell(args, num_out_path)
+        self.cell_names = CELL_ORDER[:num_cell]
+        classes = dict(ric=RectifiedIdentityCell, imrc=IntraModelReasoningCell, glac=GlobalLocalAlignmentCell,
+                       cmrc=CrossModalRefinementCell, crcmc=ContextRichCrossModalCell, gesc=GlobalEnhancedSemanticCell)
+        for name in ("ric", "imrc", "glac", "cmrc", "crcmc", "gesc"):  # registration order of the reference (:28-35)
+            if name in self.cell_names:
+                setattr(self, name, classes[name](args, num_out_path))
 
     def _cells(self):
-        return [getattr(self, n) for n in CELL_ORDER]
+        return [getattr(self, n) for n in self.cell_names]
 
     def _fusion_members(self):
         return {"r0": [c.router.mlp[0] for c in self._cells()], "r2": [c.router.mlp[2] for c in self._cells()]}
@@ -364,7 +369,7 @@ class _RoutingLayer(D2RModule):
                 h = r0.grouped(F.mean_pool(refs), torch.float32, act=ACT_RELU, x_gm=True)
             gb = r2.grouped(h, torch.float32, act=ACT_TANH_RELU)  # [B, 6*P]
             B = gb.shape[0]
-            G = gb.view(B, 6, self.num_out_path).transpose(0, 1).contiguous()  # [6,B,P] (tiny copy)
+            G = gb.view(B, self.num_cell, self.num_out_path).transpose(0, 1).contiguous()  # [ncell,B,P] (tiny copy)
         else:
             if self.first_layer:  # six routers read the same tensor: pool once
                 pooled = F.mean_pool([refs[0]])[0]
@@ -386,7 +391,7 @@ class DynamicInteraction_Layer0(_RoutingLayer):
 
     def forward(self, text, image):
         own, other = (image, text) if self.swap else (text, image)
-        return self._route([own] * 6, other)
+        return self._route([own] * self.num_cell, other)
 
 
 class DynamicInteraction_Layer(_RoutingLayer):
@@ -729,8 +734,9 @@ class UnimoModel(D2RModule):
         self.vision_cls_pool = BertPooler()
         self.block_fusion = Block([E, E], E)
         self.text_pool, self.vision_pool = BertPooler(), BertPooler()
-        self.itr_module = InteractionModule(args, num_layer_routing=args.DR_step, num_cells=6, path_hid=128)
-        self.Reversed_itr_module = Reversed_InteractionModule(args, num_layer_routing=args.DR_step, num_cells=6,
+        num_cells = int(getattr(args, "num_cells", 6))  # 6 = the reference (models/modeling_unimo.py:781-782); 2..5: extension
+        self.itr_module = InteractionModule(args, num_layer_routing=args.DR_step, num_cells=num_cells, path_hid=128)
+        self.Reversed_itr_module = Reversed_InteractionModule(args, num_layer_routing=args.DR_step, num_cells=num_cells,
                                                               path_hid=128)
         self.text_pooler = BertPooler() if add_pooling_layer else None  # dead (ingest assert needs it)
         self.use_streams = os.environ.get("D2R_STREAMS", "1") != "0"

@@ -67,6 +67,8 @@ def build_parser():
     # --- extensions
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--num_classes", default=3, type=int)
+    p.add_argument("--num_cells", default=6, type=int, help="cells per routing layer: the first n of ric, glac, imrc, cmrc, "
+                   "crcmc, gesc (6 = the reference; 2..5 = declared-subset extension, BASELINE configs[4] uses 4)")
     p.add_argument("--image_size", default=224, type=int)
     p.add_argument("--patch_size", default=32, type=int)
     p.add_argument("--encoder_layers", default=12, type=int)

@@ -182,27 +182,30 @@ int d2r_meanpool_fwd(int dtype, const void* const* h_srcs, int nsrc, int B, int 
 int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, int D, void* dX, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * K8  route_aggregate — path normalisation, threshold gate and aggregation of the six cell outputs.
+ * K8  route_aggregate — path normalisation, threshold gate and aggregation of the cell outputs of one routing layer.
  * Replaces models/DynamicInteraction.py:50-67 (=:119-132, :170-187, :239-252) and the final-layer rule
  * :104-117 (=:224-237).  Cell order [RIC, GLAC, IMRC, CMRC, CRCMC, GESC] (:41-48).
- *   embs[j]  : cell outputs; j=1 (GLAC) and j=5 (GESC) are per-sample [B,D] broadcasts, the rest [B,L,D];
+ *   ncell    : number of cells of the layer = the first ncell of that list.  The reference hard-indexes six
+ *              (ncell = 6); 2..5 is the declared-subset extension of SURVEY.md section 8c (BASELINE configs[4]: 4 cells):
+ *              path normalisation over the ncell cells, final-layer threshold 1e-4/ncell (self.threshold/self.num_cell).
+ *   embs[j]  : ncell cell outputs; j=1 (GLAC) and j=5 (GESC) are per-sample [B,D] broadcasts, the rest [B,L,D];
  *              embs[0] is the RIC *input* x0 — relu (models/Cells.py:38) is applied in-kernel.
- *   gates    : fp32 [6, B, P] raw router outputs g_j (P = 6, or 1 for the final layer)
- *   refs     : (final layer only) the six layer inputs ref_j [B,L,D] used by the skip term
- *   outs[i]  : P output tensors [B,L,D];  probs: fp32 [B, P, 6] (normalised for P=6, raw for P=1)
+ *   gates    : fp32 [ncell, B, P] raw router outputs g_j (P = ncell, or 1 for the final layer)
+ *   refs     : (final layer only) the ncell layer inputs ref_j [B,L,D] used by the skip term
+ *   outs[i]  : P output tensors [B,L,D];  probs: fp32 [B, P, ncell] (normalised for P=ncell, raw for P=1)
  * ------------------------------------------------------------------------------------------------ */
-int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs /*6*/, const void* const* h_refs /*6 or NULL*/,
-                            const float* gates, int B, int L, int D, int P, void* const* h_outs /*P*/,
+int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs /*ncell*/, const void* const* h_refs /*ncell or NULL*/,
+                            const float* gates, int B, int L, int D, int ncell, int P, void* const* h_outs /*P*/,
                             float* probs, void* stream);
 size_t d2r_route_aggregate_bwd_workspace(int B, int L, int D, int P);
 /* d_embs[j] are OVERWRITTEN (d_embs[0] is w.r.t. the RIC input x0, relu' applied; broadcast ones are [B,D]);
- * d_refs[j] (final layer: gradient of the skip term) OVERWRITTEN, d_gates fp32 [6,B,P] OVERWRITTEN.
- * d_probs: fp32 [B,P,6] gradient flowing into the returned `probs` (sim_paths -> JS loss) or NULL;
- * h_outs: forward outputs (only outs[0] of the final layer is read; may be NULL for P=6). */
+ * d_refs[j] (final layer: gradient of the skip term) OVERWRITTEN, d_gates fp32 [ncell,B,P] OVERWRITTEN.
+ * d_probs: fp32 [B,P,ncell] gradient flowing into the returned `probs` (sim_paths -> JS loss) or NULL;
+ * h_outs: forward outputs (only outs[0] of the final layer is read; may be NULL for P=ncell). */
 int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, const void* const* h_refs, const float* gates,
                             const void* const* h_douts /*P*/, const void* const* h_outs, const float* d_probs,
-                            int B, int L, int D, int P, void* const* h_dembs /*6*/,
-                            void* const* h_drefs /*6 or NULL*/, float* d_gates, void* workspace,
+                            int B, int L, int D, int ncell, int P, void* const* h_dembs /*ncell*/,
+                            void* const* h_drefs /*ncell or NULL*/, float* d_gates, void* workspace,
                             size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

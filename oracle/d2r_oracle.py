@@ -72,6 +72,11 @@ class OracleConfig:
     weight_js_1: float = 0.1
     weight_js_2: float = 0.1
     num_classes: int = 3
+    # number of cells per routing layer = the first num_cells of CELL_ORDER.  The reference hard-indexes six
+    # (models/DynamicInteraction.py:39-48: any other value crashes); 2..5 is the declared-subset EXTENSION of SURVEY.md
+    # section 8c (BASELINE configs[4]: 4 cells) whose only oracle is this restatement: path normalisation over the
+    # existing cells, num_cells outputs per first / middle layer, final-layer threshold self.threshold / self.num_cell.
+    num_cells: int = 6
     # Block fusion (models/XModules.py:478-522 defaults)
     mm_dim: int = 1600
     chunks: int = 20
@@ -126,6 +131,15 @@ def _xalign_spec(spec, p):
 
 
 def _routing_layer_spec(spec, p, n_out, cfg: OracleConfig):
+    full: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    _routing_layer_spec_all(full, p, n_out, cfg)
+    cells = CELL_ORDER[:cfg.num_cells]
+    for k, v in full.items():  # a declared subset owns only the parameters of its cells
+        if k[len(p) + 1:].split(".", 1)[0] in cells:
+            spec[k] = v
+
+
+def _routing_layer_spec_all(spec, p, n_out, cfg: OracleConfig):
     for c in CELL_ORDER:
         _router_spec(spec, f"{p}.{c}", n_out, cfg)
     # IMRC
@@ -157,11 +171,12 @@ def _routing_layer_spec(spec, p, n_out, cfg: OracleConfig):
 
 
 def _interaction_module_spec(spec, p, cfg: OracleConfig):
-    _routing_layer_spec(spec, f"{p}.dynamic_itr_l0", 6, cfg)
+    nc = cfg.num_cells
+    _routing_layer_spec(spec, f"{p}.dynamic_itr_l0", nc, cfg)
     for i in range(cfg.DR_step - 2):
-        _routing_layer_spec(spec, f"{p}.dynamic_itr_l1.{i}", 6, cfg)
+        _routing_layer_spec(spec, f"{p}.dynamic_itr_l1.{i}", nc, cfg)
     _routing_layer_spec(spec, f"{p}.dynamic_itr_l2", 1, cfg)
-    total_paths = 36 * (cfg.DR_step - 1) + 6
+    total_paths = nc * nc * (cfg.DR_step - 1) + nc  # models/InteractionModule.py:18
     _lin(spec, f"{p}.path_mapping", 128, total_paths)  # dead
     _ln(spec, f"{p}.bn")  # dead BatchNorm1d(768)
     spec[f"{p}.bn.running_mean"] = (E,)
@@ -363,15 +378,16 @@ def routing_layer(sd, p, refs: List[Tensor], other: Tensor, n_out: int, st: BNSt
     """One DynamicInteraction layer.  ``refs`` holds 6 own-modality inputs (layer 0: the same tensor six
     times).  Returns (list of n_out tensors, path probs [B, n_out, 6])."""
     L = refs[0].shape[1]
+    nc = len(refs)  # number of cells (6 in the reference)
     embs, gates = [], []
-    for j, c in enumerate(CELL_ORDER):
+    for j, c in enumerate(CELL_ORDER[:nc]):
         e, g = CELLS[c](sd, f"{p}.{c}", refs[j], other, st)
         embs.append(_full(e, L))
         gates.append(g)  # [B, n_out]
-    G = torch.stack(gates, dim=2)  # [B, n_out, 6]
+    G = torch.stack(gates, dim=2)  # [B, n_out, nc]
     if n_out == 1:  # final layer (models/DynamicInteraction.py:104-117)
-        skip = (G < 1e-4 / 6).float()  # [B,1,6]
-        num = sum(G[:, 0, j, None, None] * embs[j] + skip[:, 0, j, None, None] * refs[j] for j in range(6))
+        skip = (G < 1e-4 / nc).float()  # [B,1,nc]  (self.threshold / self.num_cell, :109)
+        num = sum(G[:, 0, j, None, None] * embs[j] + skip[:, 0, j, None, None] * refs[j] for j in range(nc))
         den = (skip.sum(-1) + G.sum(-1))[:, :, None]  # [B,1,1]
         out, probs = [num / den], G
         if trace is not None:
@@ -379,7 +395,7 @@ def routing_layer(sd, p, refs: List[Tensor], other: Tensor, n_out: int, st: BNSt
     else:  # models/DynamicInteraction.py:50-67
         skip = (G.sum(-1) < 1e-4).float()  # [B, n_out]
         probs = G / (G.sum(-1, keepdim=True) + 1e-8)
-        out = [sum(probs[:, i, j, None, None] * embs[j] for j in range(6)) + skip[:, i, None, None] * embs[0]
+        out = [sum(probs[:, i, j, None, None] * embs[j] for j in range(nc)) + skip[:, i, None, None] * embs[0]
                for i in range(n_out)]
         if trace is not None:
             trace[p + ".gate_mask"] = skip
@@ -389,13 +405,13 @@ def routing_layer(sd, p, refs: List[Tensor], other: Tensor, n_out: int, st: BNSt
     return out, probs
 
 
-def interaction_module(sd, p, own, other, dr_step, st: BNState, trace: Optional[dict] = None):
+def interaction_module(sd, p, own, other, dr_step, st: BNState, trace: Optional[dict] = None, num_cells: int = 6):
     """InteractionModule.forward (models/InteractionModule.py:22-55); the reversed module is the same
     function called with the modalities swapped (models/DynamicInteraction.py:157-189,210-254)."""
-    refs, p0 = routing_layer(sd, p + ".dynamic_itr_l0", [own] * 6, other, 6, st, trace)
+    refs, p0 = routing_layer(sd, p + ".dynamic_itr_l0", [own] * num_cells, other, num_cells, st, trace)
     plist = [p0.reshape(own.shape[0], -1)]
     for i in range(dr_step - 2):
-        refs, pm = routing_layer(sd, f"{p}.dynamic_itr_l1.{i}", refs, other, 6, st, trace)
+        refs, pm = routing_layer(sd, f"{p}.dynamic_itr_l1.{i}", refs, other, num_cells, st, trace)
         plist.append(pm.reshape(own.shape[0], -1))
     out, pf = routing_layer(sd, p + ".dynamic_itr_l2", refs, other, 1, st, trace)
     plist.append(pf.reshape(own.shape[0], -1))
@@ -499,8 +515,8 @@ def forward(sd: Dict[str, Tensor], cfg: OracleConfig, input_ids, attention_mask,
     t_enc, v_enc, ext = encode(sd, cfg, input_ids, attention_mask, token_type_ids, images)
     t_cls = cls_pool(sd, "model.text_cls_pool", bert_layer(sd, "model.self_text.0", t_enc, ext, cfg))
     v_cls = cls_pool(sd, "model.vision_cls_pool", clip_layer(sd, "model.self_vision.0", v_enc, cfg))
-    out_t, sim_p = interaction_module(sd, "model.itr_module", t_enc, v_enc, cfg.DR_step, st, trace)
-    out_v, sim_pr = interaction_module(sd, "model.Reversed_itr_module", v_enc, t_enc, cfg.DR_step, st, trace)
+    out_t, sim_p = interaction_module(sd, "model.itr_module", t_enc, v_enc, cfg.DR_step, st, trace, cfg.num_cells)
+    out_v, sim_pr = interaction_module(sd, "model.Reversed_itr_module", v_enc, t_enc, cfg.DR_step, st, trace, cfg.num_cells)
     js = -cfg.weight_js_1 * js_div(sim_p, t_cls @ t_cls.t()) - cfg.weight_js_2 * js_div(sim_pr, v_cls @ v_cls.t())
     pooled = block_fusion(sd, "model.block_fusion", cls_pool(sd, "model.text_pool", out_t),
                           cls_pool(sd, "model.vision_pool", out_v), cfg)

@@ -100,7 +100,8 @@ def test_gemm_nn_dx_with_activation_backward_and_accumulate(gpu, shape):
     _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, dx, dtype=_lib.BF16, c_dtype=_lib.BF16, grad_ref=preg, grad_act=_lib.ACT_GELU))
     p = pre.double()
     gelu_grad = 0.5 * (1 + torch.erf(p / math.sqrt(2))) + p * torch.exp(-0.5 * p * p) / math.sqrt(2 * math.pi)
-    assert _max_rel(dx, ref * gelu_grad) <= 6e-3
+    # TWO bf16 roundings here (the vectorised epilogue stages the product in LDS as bf16 before the gelu' factor): 2 x 2^-8
+    assert _max_rel(dx, ref * gelu_grad) <= 1e-2
     acc = old.to(gpu).clone()
     _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, acc, dtype=_lib.BF16, c_dtype=_lib.BF16, beta=1.0))
     assert _max_rel(acc, ref + old.double()) <= 6e-3

@@ -207,51 +207,57 @@ def test_meanpool_and_router(gpu, dtype):
     run_both(lambda x: F.mean_pool([x])[0], lambda x: x.mean(1), [xs[0]], dtype, gpu, name="meanpool1")
 
 
-def _agg_ref(gates, x0, e1, e2, e3, e4, e5, *refs):
+def _agg_ref(nc, gates, *tensors):
+    embs_in, refs = list(tensors[:nc]), list(tensors[nc:])
+    x0 = embs_in[0]
     B, L, D = x0.shape
     P = gates.shape[2]
-    embs = [torch.relu(x0), e1[:, None].expand(B, L, D), e2, e3, e4, e5[:, None].expand(B, L, D)]
-    G = gates.permute(1, 2, 0)  # [B,P,6]
-    thr, thr_f = float(torch.tensor(1e-4, dtype=torch.float32)), float(torch.tensor(1e-4 / 6, dtype=torch.float32))
+    embs = [torch.relu(x0)] + [e[:, None].expand(B, L, D) if j in (1, 5) else e for j, e in enumerate(embs_in) if j > 0]
+    G = gates.permute(1, 2, 0)  # [B,P,nc]
+    thr, thr_f = float(torch.tensor(1e-4, dtype=torch.float32)), float(torch.tensor(1e-4 / nc, dtype=torch.float32))
     if P == 1:
-        rr = [x0] + list(refs)
+        rr = [x0] + refs
         skip = (G < thr_f).double()
-        num = sum(G[:, 0, j, None, None] * embs[j] + skip[:, 0, j, None, None] * rr[j] for j in range(6))
+        num = sum(G[:, 0, j, None, None] * embs[j] + skip[:, 0, j, None, None] * rr[j] for j in range(nc))
         den = (skip.sum(-1) + G.sum(-1))[:, :, None]
         return (G, num / den)
     skip = (G.sum(-1) < thr).double()
     probs = G / (G.sum(-1, keepdim=True) + float(torch.tensor(1e-8, dtype=torch.float32)))
-    outs = [sum(probs[:, i, j, None, None] * embs[j] for j in range(6)) + skip[:, i, None, None] * embs[0] for i in range(6)]
+    outs = [sum(probs[:, i, j, None, None] * embs[j] for j in range(nc)) + skip[:, i, None, None] * embs[0] for i in range(P)]
     return (probs, *outs)
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("P,regime", [(6, "open"), (6, "mixed"), (6, "closed"), (1, "open"), (1, "mixed"), (1, "closed")])
-def test_route_aggregate(gpu, dtype, P, regime):
+@pytest.mark.parametrize("nc,final,regime", [(6, False, "open"), (6, False, "mixed"), (6, False, "closed"), (6, True, "open"),
+                                             (6, True, "mixed"), (6, True, "closed"), (4, False, "mixed"), (4, True, "mixed"),
+                                             (4, True, "closed"), (5, False, "open")])
+def test_route_aggregate(gpu, dtype, nc, final, regime):
+    """K8 for the reference's six cells and for declared subsets (first nc cells; BASELINE configs[4] uses 4): path
+    normalisation / threshold gates over the existing cells, final-layer threshold 1e-4/nc."""
     from d2r_amd import functional as F
     B, L, D = 4, 19, 768
+    P = 1 if final else nc
     g = torch.Generator().manual_seed(5)
-    gates = torch.rand(6, B, P, generator=g)
+    gates = torch.rand(nc, B, P, generator=g)
     if regime == "mixed":
-        gates = gates * (torch.rand(6, B, P, generator=g) > 0.5)
+        gates = gates * (torch.rand(nc, B, P, generator=g) > 0.5)
         gates[:, 0, :] = 0.0  # one sample with every path closed -> skip connection
     elif regime == "closed":
         gates.zero_()
     gates = keep32(gates.float())
-    x0, e2, e3, e4 = (rnd(B, L, D, seed=i) for i in range(4))
-    e1, e5 = rnd(B, D, seed=7), rnd(B, D, seed=8)
-    refs = [rnd(B, L, D, seed=10 + i) for i in range(5)] if P == 1 else []
-    inputs = [gates, x0, e1, e2, e3, e4, e5] + refs
+    embs = [rnd(B, D, seed=7 + j) if j in (1, 5) else rnd(B, L, D, seed=j) for j in range(nc)]
+    refs = [rnd(B, L, D, seed=10 + i) for i in range(nc - 1)] if final else []
+    inputs = [gates] + embs + refs
 
-    def f(gates, x0, e1, e2, e3, e4, e5, *refs):
-        probs, outs = F.route_aggregate(gates, x0, e1, e2, e3, e4, e5, refs=list(refs) if refs else None)
+    def f(gates, *ts):
+        probs, outs = F.route_aggregate(gates, *ts[:nc], refs=list(ts[nc:]) if final else None)
         return (probs, *outs)
 
-    if P == 1 and regime == "closed":
+    if final and regime == "closed":
         wrt = list(range(1, len(inputs)))  # d/dgate at g=0 with every path closed is well defined but huge
     else:
         wrt = None
-    run_both(f, _agg_ref, inputs, dtype, gpu, wrt=wrt, name=f"aggregate P={P} {regime}")
+    run_both(f, lambda gates, *ts: _agg_ref(nc, gates, *ts), inputs, dtype, gpu, wrt=wrt, name=f"aggregate nc={nc} final={final} {regime}")
 
 
 @pytest.mark.parametrize("train", [True, False])

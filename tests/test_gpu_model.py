@@ -467,3 +467,51 @@ def test_degenerate_shapes_vs_oracle(gpu, shape, dtype):
         dot, ng, nr = dot + float((got * ref).sum()), ng + float(got.pow(2).sum()), nr + float(ref.pow(2).sum())
     cos = dot / max((ng * nr) ** 0.5, 1e-300)
     assert cos >= (0.9999 if dtype == torch.float32 else 0.9), cos
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_four_cells_seven_classes_vs_oracle(gpu, dtype):
+    """BASELINE configs[3] / [4] name a 7-class head and 4 cells per routing layer: both are extensions the reference cannot
+    run (models/unimo_model.py:145 hard-wires 3 classes; num_cells != 6 crashes, models/DynamicInteraction.py:39-48), so
+    the oracle is the restatement with `num_cells` / `num_classes`, itself pinned to the 6-cell oracle by
+    tests/test_oracle_golden.py::test_declared_cell_subset_extension_is_consistent_with_the_six_cell_oracle.  DR_step 4
+    (two middle layers) with about half of the paths pruned; forward + backward, fp32 tight, bf16 by the default-init rule."""
+    O, _ = _oracle()
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    cfg = O.OracleConfig(text_layers=2, vision_layers=2, image_size=64, patch_size=32, DR_step=4, num_cells=4, num_classes=7)
+    sd = O.seeded_state_dict(cfg, seed=21, router_bias="normal")
+    tc = TextConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vc = VisionConfig(num_hidden_layers=2, image_size=64, patch_size=32)
+    model = M.UnimoModelF(default_args(DR_step=4, num_cells=4), vc, tc, num_classes=7)
+    assert set(model.state_dict()) == set(sd), set(model.state_dict()) ^ set(sd)
+    model.load_state_dict(sd, strict=True)
+    model.to(gpu).set_compute_dtype(dtype).train()
+    ParamStore(model, dtype)
+    ids, mask, tt, labels, images = O.synthetic_batch(cfg, 3, 10, seed=4)
+    loss, logits = model(ids.to(gpu), mask.to(gpu), tt.to(gpu), labels.to(gpu), images.to(gpu))
+    loss.backward()
+    torch.cuda.synchronize()
+    osd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    trace = {}
+    lo, logits_o, aux = O.forward(osd, cfg, ids, mask, tt, labels, images.double(), train=True, trace=trace)
+    lo.backward()
+    assert logits.shape == (3, 7)
+    pr = model.last_aux["sim_paths"]
+    assert pr.shape == (3, 3)
+    lim = 2e-5 if dtype == torch.float32 else 5e-3
+    assert _err(logits, logits_o.detach()) <= lim and _err(loss, lo.detach()) <= lim, (_err(logits, logits_o.detach()), _err(loss, lo.detach()))
+    assert _err(pr, aux["sim_paths"].detach()) <= (1e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(aux["sim_paths"].abs().max()))
+    dot = ng = nr = 0.0
+    for name, p in model.named_parameters():
+        ref = osd[name].grad
+        if ref is None:
+            continue
+        got = p.grad.detach().double().cpu()
+        assert torch.isfinite(got).all(), name
+        dot, ng, nr = dot + float((got * ref).sum()), ng + float(got.pow(2).sum()), nr + float(ref.pow(2).sum())
+    cos = dot / max((ng * nr) ** 0.5, 1e-300)
+    print(f"[4 cells / 7 classes {str(dtype)[6:]}] logits err {_err(logits, logits_o.detach()):.2e} gradient cosine {cos:.6f}")
+    assert cos >= (0.9999 if dtype == torch.float32 else 0.9), cos

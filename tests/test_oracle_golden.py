@@ -104,3 +104,54 @@ def test_dr_step_2_extension_runs():
     own, other = torch.randn(2, 6, 768), torch.randn(2, 4, 768)
     emb, sim = O.interaction_module({"M." + k: v for k, v in sd.items()}, "M", own, other, 2, O.BNState(False))
     assert emb.shape == (2, 6, 768) and sim.shape == (2, 2) and torch.isfinite(emb).all()
+
+
+def test_declared_cell_subset_extension_is_consistent_with_the_six_cell_oracle():
+    """num_cells != 6 crashes in the reference (models/DynamicInteraction.py:39-48), so the declared-subset extension
+    (BASELINE configs[4]: 4 cells) has no external oracle.  It is pinned to the 6-cell oracle — which
+    IS pinned by the reference's fixtures — through two properties that fix its definition:
+      (1) first / middle layers: a 6-cell layer whose cells 4 and 5 have CLOSED routers (gate 0) computes, for its outputs
+          0..3, exactly what the 4-cell layer computes on the same weights (absent cell == cell with zero path probability);
+      (2) the final layer divides by (#closed + sum of gates) over the EXISTING cells and gates at threshold / num_cells."""
+    torch.manual_seed(0)
+    cfg6, cfg4 = O.OracleConfig(DR_step=3), O.OracleConfig(DR_step=3, num_cells=4)
+    sd6 = O.seeded_state_dict(cfg6, seed=4, router_bias="normal", spec=O.interaction_spec(cfg6))
+    sd4 = O.seeded_state_dict(cfg4, seed=4, router_bias="normal", spec=O.interaction_spec(cfg4))
+    assert set(sd4) < set(sd6) and not [k for k in sd4 if ".crcmc." in k or ".gesc." in k]
+    assert sd4["path_mapping.weight"].shape[1] == 16 * 2 + 4
+    own, other = torch.randn(3, 7, 768).double(), torch.randn(3, 5, 768).double()
+    d6 = {"M." + k: (v.double() if v.is_floating_point() else v) for k, v in sd6.items()}
+    d4 = {"M." + k: (v.double() if v.is_floating_point() else v) for k, v in sd4.items()}
+    # (1) layer 0: same weights for the four shared cells (name-keyed seeds), cells 4/5 of the 6-cell layer closed
+    p = "M.dynamic_itr_l0"
+    for c in ("ric", "glac", "imrc", "cmrc"):
+        for leaf in ("weight", "bias"):  # the 6-cell routers have 6 outputs: keep the first four rows
+            d4[f"{p}.{c}.router.mlp.2.{leaf}"] = d6[f"{p}.{c}.router.mlp.2.{leaf}"][:4].clone()
+    for c in ("crcmc", "gesc"):
+        d6[f"{p}.{c}.router.mlp.2.bias"] = torch.full_like(d6[f"{p}.{c}.router.mlp.2.bias"], -5.0)
+    for k in d4:
+        if k.startswith(p) and "router.mlp.2" not in k:
+            assert torch.equal(d4[k], d6[k]), k
+    st = O.BNState(False)
+    out6, pr6 = O.routing_layer(d6, p, [own] * 6, other, 6, st)
+    out4, pr4 = O.routing_layer(d4, p, [own] * 4, other, 4, st)
+    assert float(pr6[:, :4, 4:].abs().max()) == 0.0
+    for i in range(4):
+        assert float((out6[i] - out4[i]).abs().max()) < 1e-12
+    assert float((pr6[:, :4, :4] - pr4).abs().max()) < 1e-12
+    # (2) final layer, every router closed: out = mean of the EXISTING refs (4 of them), not of six
+    pf = "M.dynamic_itr_l2"
+    for c in ("ric", "glac", "imrc", "cmrc"):
+        d4[f"{pf}.{c}.router.mlp.2.bias"] = torch.full_like(d4[f"{pf}.{c}.router.mlp.2.bias"], -5.0)
+    refs = [torch.randn(3, 7, 768).double() for _ in range(4)]
+    outf, prf = O.routing_layer(d4, pf, refs, other, 1, st)
+    assert float(prf.abs().max()) == 0.0
+    assert float((outf[0] - sum(refs) / 4).abs().max()) < 1e-12
+    # whole module + full model run end to end with 4 cells and 7 classes (BASELINE configs[3] / [4])
+    emb, sim = O.interaction_module(d4, "M", own, other, 3, st, num_cells=4)
+    assert emb.shape == own.shape and sim.shape == (3, 3) and torch.isfinite(emb).all()
+    cfg = O.OracleConfig(text_layers=1, vision_layers=1, image_size=64, patch_size=32, num_cells=4, num_classes=7)
+    sd = O.seeded_state_dict(cfg, seed=1)
+    assert sd["fc.weight"].shape == (7, 768)
+    loss, logits, _ = O.forward(sd, cfg, *O.synthetic_batch(cfg, 2, 6, seed=0), train=True)
+    assert logits.shape == (2, 7) and torch.isfinite(loss)
