@@ -47,6 +47,29 @@ class EncoderLayerDesc(C.Structure):
                    ("defer_wgrad", i32), ("o_dy", vp * 4)])
 
 
+RL_NAMES = ("R0", "R2", "IMRC_QKV", "IMRC_FC1", "IMRC_FC2", "GLAC_Q", "GLAC_KV", "GLAC_LOC", "GLAC_FC1", "GLAC_TPOOL", "GLAC_IPOOL",
+            "GLAC_GLO", "GLAC_FC2", "GLAC_SAFW", "CMRC_Q", "CMRC_KV", "CMRC_SCALE", "CMRC_SHIFT", "CMRC_FC1", "CMRC_FC2", "CRCMC_Q",
+            "CRCMC_KV", "CRCMC_MLP1", "CRCMC_MLP2", "CRCMC_FC1", "CRCMC_FC2", "GESC_TPOOL", "GESC_IPOOL", "GESC_MLP0", "GESC_MLP2")
+RL = {n: i for i, n in enumerate(RL_NAMES)}  # D2R_RL_* of include/d2r_hip.h
+
+
+class LinearParams(C.Structure):
+    _fields_ = [("w", vp), ("b", vp), ("gw", vp), ("gb", vp)]
+
+
+class RoutingLayerParams(C.Structure):
+    _fields_ = [("lin", LinearParams * len(RL_NAMES)), ("bn_weight", vp), ("bn_bias", vp), ("bn_running_mean", vp),
+                ("bn_running_var", vp), ("g_bn_weight", vp), ("g_bn_bias", vp)]
+
+
+class InteractionDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("Lq", i32), ("Lk", i32), ("ncell", i32), ("nlayer", i32), ("hid_router", i32),
+                ("heads_imrc", i32), ("hid_imrc", i32), ("train", i32), ("layers", C.POINTER(RoutingLayerParams)),
+                ("own", vp), ("other", vp), ("out", vp), ("paths", vp), ("arena", vp), ("arena_bytes", sz),
+                ("splitk_ws", vp), ("splitk_bytes", sz), ("d_out", vp), ("d_paths", vp), ("d_own", vp), ("d_other", vp),
+                ("scratch", vp), ("scratch_bytes", sz)]
+
+
 # name -> (restype, argtypes); every symbol include/d2r_hip.h declares
 SIGNATURES = {
     "d2r_version": (C.c_char_p, []),
@@ -74,6 +97,11 @@ SIGNATURES = {
     "d2r_encoder_layer_bwd_scratch": (sz, [i32, i32, i32, i32]),
     "d2r_encoder_layer_fwd": (i32, [C.POINTER(EncoderLayerDesc), vp]),
     "d2r_encoder_layer_bwd": (i32, [C.POINTER(EncoderLayerDesc), vp]),
+    "d2r_interaction_supported": (i32, [i32, i32, i32, i32, i32]),
+    "d2r_interaction_arena_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
+    "d2r_interaction_bwd_scratch": (sz, [i32, i32, i32, i32, i32, i32, i32]),
+    "d2r_interaction_fwd": (i32, [C.POINTER(InteractionDesc), vp]),
+    "d2r_interaction_bwd": (i32, [C.POINTER(InteractionDesc), vp]),
     "d2r_l2norm_fwd": (i32, [i32, vp, vp, vp, i64, i32, vp]),
     "d2r_l2norm_bwd": (i32, [i32, vp, vp, vp, vp, i64, i32, vp]),
     "d2r_act_bwd": (i32, [i32, i32, vp, vp, vp, i64, vp]),
@@ -93,9 +121,9 @@ SIGNATURES = {
     "d2r_colsum": (i32, [i32, vp, i64, i64, i32, vp, vp, sz, vp]),
     "d2r_meanpool_fwd": (i32, [i32, C.POINTER(vp), i32, i32, i32, i32, vp, vp]),
     "d2r_meanpool_bwd": (i32, [i32, vp, i32, i32, i32, vp, i32, vp]),
-    "d2r_route_aggregate_fwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), vp, i32, i32, i32, i32, i32, C.POINTER(vp), vp, vp]),
+    "d2r_route_aggregate_fwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), vp, i32, i32, i32, i32, i32, C.POINTER(vp), vp, i64, vp]),
     "d2r_route_aggregate_bwd_workspace": (sz, [i32, i32, i32, i32]),
-    "d2r_route_aggregate_bwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), vp,
+    "d2r_route_aggregate_bwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), vp, i64,
                                       i32, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), vp, vp, sz, vp]),
     "d2r_saf_gate_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
     "d2r_saf_gate_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),

@@ -1,0 +1,684 @@
+// interaction.hip — K16: one whole (Reversed_)InteractionModule per C call, forward or backward (host code only: it
+// sequences the kernels of gemm*.hip / attention.hip / routing.hip / rowops.hip / elementwise.hip / misc.hip).
+//
+// Replaces (reference file:line): InteractionModule.forward models/InteractionModule.py:22-55 (=:75-108) with the routing
+// layers models/DynamicInteraction.py:37-69, 90-134 (=:157-189, 210-254), the routers models/Router.py:22-26 and the six
+// cells models/Cells.py:30-255 (+ SelfAttention.py:11-70, Refinement.py:86-154, XModules.py:277-394), and their autograd
+// backward.  What this file removes is HOST work: ~45 forward / ~110 backward launches per layer are issued from C++
+// instead of one Python autograd node and one foreign call each (the step was host-bound: 27 of 30 ms), every
+// multi-consumer gradient is accumulated in a GEMM epilogue (beta = 1 / residual operand) instead of a separate add
+// launch, and the 768x768-class weight gradients are queued and launched grouped at the end of the call.
+//
+// Notation: T = B*Lq own-modality rows, S = B*Lk other-modality rows, E = 768, n = Lq + 1 (SAF rows per sample).
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int E = 768;
+const float XSCALE = 100.0f / sqrtf(768.0f);  // softmax(100 q k^T / sqrt(768)), models/XModules.py:305-309
+
+#define TRY(expr)                     \
+  do {                                \
+    if (int rc_ = (expr)) return rc_; \
+  } while (0)
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Arena {
+  char* base;
+  size_t off = 0;
+  explicit Arena(void* b) : base((char*)b) {}
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += al(bytes);
+    return p;
+  }
+};
+
+struct Dims {
+  int B, Lq, Lk, nc, nl, hid, hidi, heads;
+  int T, S, n, lkp, lqp;
+  size_t es;
+};
+
+Dims make_dims(int B, int Lq, int Lk, int nc, int nl, int hid, int hidi, int heads) {
+  Dims d;
+  d.B = B, d.Lq = Lq, d.Lk = Lk, d.nc = nc, d.nl = nl, d.hid = hid, d.hidi = hidi, d.heads = heads;
+  d.T = B * Lq, d.S = B * Lk, d.n = Lq + 1, d.lkp = (Lk + 7) / 8 * 8, d.lqp = (Lq + 7) / 8 * 8;
+  d.es = 2;
+  return d;
+}
+
+// ---- saved forward activations of one layer ---------------------------------------------------------------
+struct LayerF {
+  float *pooled, *h, *gates;
+  void *qkv, *y, *f1, *e2;
+  float* lse_i;
+  void *g_q, *g_kv, *g_c, *g_sq, *g_loc, *g_l2, *g_sl, *g_pt, *g_pi, *g_dg, *g_glo, *g_l2g, *g_sg, *g_S, *g_w16, *g_wsum, *e1;
+  float *g_lse, *g_nloc, *g_nglo, *g_a, *g_w, *g_saved, *g_ne1;
+  void *c_q, *c_kv, *c_c, *c_s, *c_h, *c_mod, *c_f, *e3;
+  float* c_lse;
+  void *r_q, *r_kv, *r_c, *r_Qs, *r_Ks, *r_a, *r_b, *e4;
+  float *r_lse, *r_lse2;
+  void *s_a, *s_b, *s_ab, *s_z1, *s_z, *s_g, *e5;
+  void* outs[6];
+};
+
+void plan_fwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerF& L) {
+  const size_t TE = (size_t)d.T * E * d.es, SE = (size_t)d.S * E * d.es, BE = (size_t)d.B * E * d.es;
+  memset(&L, 0, sizeof(L));
+  L.pooled = (float*)A.take((size_t)(first ? 1 : d.nc) * d.B * E * 4);
+  L.h = (float*)A.take((size_t)d.B * d.nc * d.hid * 4);
+  L.gates = (float*)A.take((size_t)d.B * d.nc * P * 4);
+  if (d.nc > 1) {  // GLAC
+    L.g_q = A.take(TE), L.g_kv = A.take(2 * SE), L.g_c = A.take(TE), L.g_sq = A.take(TE), L.g_loc = A.take(TE);
+    L.g_l2 = A.take(TE), L.g_sl = A.take(TE);
+    L.g_pt = A.take(BE), L.g_pi = A.take(BE), L.g_dg = A.take(BE), L.g_glo = A.take(BE), L.g_l2g = A.take(BE), L.g_sg = A.take(BE);
+    L.g_S = A.take((size_t)d.B * d.n * E * d.es);
+    L.g_w16 = A.take((size_t)d.B * d.n * d.es + 16), L.g_wsum = A.take(BE), L.e1 = A.take(BE);
+    L.g_lse = (float*)A.take((size_t)d.T * 4), L.g_nloc = (float*)A.take((size_t)d.T * 4), L.g_nglo = (float*)A.take((size_t)d.B * 4);
+    L.g_a = (float*)A.take((size_t)d.B * d.n * 4), L.g_w = (float*)A.take((size_t)d.B * d.n * 4);
+    L.g_saved = (float*)A.take(16), L.g_ne1 = (float*)A.take((size_t)d.B * 4);
+  }
+  if (d.nc > 2) {  // IMRC
+    L.qkv = A.take(3 * TE), L.y = A.take(TE), L.f1 = A.take((size_t)d.T * d.hidi * d.es), L.e2 = A.take(TE);
+    L.lse_i = (float*)A.take((size_t)d.B * 64 * d.Lq * 4);  // up to 64 heads (the size queries do not know the head count)
+  }
+  if (d.nc > 3) {  // CMRC
+    L.c_q = A.take(TE), L.c_kv = A.take(2 * SE), L.c_c = A.take(TE), L.c_s = A.take(TE), L.c_h = A.take(TE);
+    L.c_mod = A.take(TE), L.c_f = A.take(TE), L.e3 = A.take(TE);
+    L.c_lse = (float*)A.take((size_t)d.T * 4);
+  }
+  if (d.nc > 4) {  // CRCMC
+    L.r_q = A.take(TE), L.r_kv = A.take(2 * SE), L.r_c = A.take(TE), L.r_Qs = A.take(TE), L.r_Ks = A.take(TE);
+    L.r_a = A.take(TE), L.r_b = A.take(TE), L.e4 = A.take(TE);
+    L.r_lse = (float*)A.take((size_t)d.T * 4), L.r_lse2 = (float*)A.take((size_t)d.T * 4);
+  }
+  if (d.nc > 5) {  // GESC
+    L.s_a = A.take(BE), L.s_b = A.take(BE), L.s_ab = A.take(BE), L.s_z1 = A.take(BE), L.s_z = A.take(BE), L.s_g = A.take(BE);
+    L.e5 = A.take(BE);
+  }
+  if (!final)
+    for (int i = 0; i < P; ++i) L.outs[i] = A.take(TE);
+}
+
+// ---- launch helpers ------------------------------------------------------------------------------------------
+struct Ctx {
+  int dt;
+  void* st;
+  void* ws;
+  size_t wsb;
+};
+
+struct G {
+  d2r_gemm_desc d;
+  G(int dtype, int cdtype, int layout, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+    int64_t ldc) {
+    memset(&d, 0, sizeof(d));
+    d.dtype = dtype, d.c_dtype = cdtype, d.layout = layout, d.act = D2R_ACT_NONE;
+    d.M = M, d.N = N, d.K = K, d.nb = 1, d.nh = 1, d.alpha = 1.f, d.beta = 0.f;
+    d.A = A, d.lda = lda, d.B = B, d.ldb = ldb, d.C = C, d.ldc = ldc;
+  }
+  G& batch(int nb, int64_t sA, int64_t sB, int64_t sC) {
+    d.nb = nb, d.sAb = sA, d.sBb = sB, d.sCb = sC;
+    return *this;
+  }
+  G& ws(const Ctx& c) {
+    d.workspace = c.ws, d.workspace_bytes = c.wsb;
+    return *this;
+  }
+};
+
+// y[M,N] = act(x[M,K] W^T + b) (+ residual); x rows at stride ldx; the split-K scratch goes with M <= 64 (pooled vectors)
+int lin(const Ctx& c, int M, int N, int K, const void* x, int64_t ldx, const d2r_linear_params& p, void* y, int act = D2R_ACT_NONE,
+        const void* res = nullptr, int dt = -1, int cdt = -1) {
+  if (dt < 0) dt = c.dt;
+  if (cdt < 0) cdt = dt;
+  G g(dt, cdt, D2R_GEMM_NT, M, N, K, x, ldx, p.w, K, y, N);
+  g.d.bias = p.b, g.d.act = act, g.d.residual = res, g.d.ldr = N;
+  if (M <= 64) g.ws(c);
+  return d2r_gemm(&g.d, c.st);
+}
+
+// dx[M,Kf] (ldc) = beta*dx + dy[M,Nf] (ldy) W[Nf,Kf] (+ residual [M,Kf]) (* act'(grad_ref))
+int dxg(const Ctx& c, int M, int Kf, int Nf, const void* dy, int64_t ldy, const void* w, void* dx, int64_t ldc, float beta = 0.f,
+        const void* res = nullptr, const void* gref = nullptr, int gact = D2R_ACT_NONE, int dt = -1) {
+  if (dt < 0) dt = c.dt;
+  G g(dt, dt, D2R_GEMM_NN, M, Kf, Nf, dy, ldy, w, Kf, dx, ldc);
+  g.d.beta = beta, g.d.residual = res, g.d.ldr = Kf, g.d.grad_ref = gref, g.d.grad_act = gact;
+  if (M <= 64) g.ws(c);
+  return d2r_gemm(&g.d, c.st);
+}
+
+// weight gradient gw[Nf,Kf] += dy[M,Nf]^T x[M,Kf] (+ gb += colsum dy), launched on the spot (split-K inside)
+int dwg(const Ctx& c, int M, int Nf, int Kf, const void* dy, int64_t ldy, const void* x, int64_t ldx, const d2r_linear_params& p,
+        int dt = -1) {
+  if (dt < 0) dt = c.dt;
+  G g(dt, D2R_F32, D2R_GEMM_TN, Nf, Kf, M, dy, ldy, x, ldx, p.gw, Kf);
+  g.d.beta = 1.f, g.d.dbias = p.gb;
+  g.ws(c);
+  return d2r_gemm(&g.d, c.st);
+}
+
+// queued weight gradients (768x768 / 1536x768 class): nothing in the backward pass reads them
+struct WJob {
+  int M, Nf, Kf;
+  int64_t ldy, ldx;
+  const void *dy, *x;
+  float *gw, *gb;
+};
+typedef std::vector<WJob> Jobs;
+
+void defer(Jobs& jobs, int M, int Nf, int Kf, const void* dy, int64_t ldy, const void* x, int64_t ldx, const d2r_linear_params& p) {
+  jobs.push_back(WJob{M, Nf, Kf, ldy, ldx, dy, x, p.gw, p.gb});
+}
+
+int flush_jobs(const Ctx& c, Jobs& jobs) {
+  std::vector<char> done(jobs.size(), 0);
+  std::vector<const void*> A, Bp;
+  std::vector<float*> Cp, Dp;
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    if (done[i]) continue;
+    const WJob& a = jobs[i];
+    A.clear(), Bp.clear(), Cp.clear(), Dp.clear();
+    for (size_t j = i; j < jobs.size(); ++j) {
+      const WJob& b = jobs[j];
+      if (done[j] || b.M != a.M || b.Nf != a.Nf || b.Kf != a.Kf || b.ldy != a.ldy || b.ldx != a.ldx) continue;
+      bool dup = false;  // one sink twice in a launch would race: the second product waits for the next round
+      for (size_t k = 0; k < Cp.size(); ++k) dup |= (Cp[k] == b.gw);
+      if (dup) continue;
+      done[j] = 1;
+      A.push_back(b.dy), Bp.push_back(b.x), Cp.push_back(b.gw), Dp.push_back(b.gb);
+    }
+    TRY(d2r_gemm_tn_grouped(c.dt, a.Nf, a.Kf, a.M, a.ldy, a.ldx, a.Kf, A.data(), Bp.data(), Cp.data(), Dp.data(), (int)A.size(), 1.f, c.st));
+  }
+  // leftovers (duplicates of a sink within one shape class): one more pass each
+  bool left = false;
+  for (size_t i = 0; i < jobs.size(); ++i) left |= !done[i];
+  if (left) {
+    Jobs rest;
+    for (size_t i = 0; i < jobs.size(); ++i)
+      if (!done[i]) rest.push_back(jobs[i]);
+    jobs.swap(rest);
+    return flush_jobs(c, jobs);
+  }
+  jobs.clear();
+  return D2R_OK;
+}
+
+int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, void* st) {
+  hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)st);
+  if (e != hipSuccess) return d2r_fail(D2R_ERR_LAUNCH, "d2r_interaction: hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
+  return D2R_OK;
+}
+
+// single-head attention over the 768-wide feature: forward
+int xat_fwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t ldk, const void* v, int64_t ldv, int Lk, void* o,
+            const void* res, float* lse, float scale) {
+  return d2r_xattn_fwd(c.dt, q, E, (int64_t)d.Lq * E, k, ldk, (int64_t)Lk * ldk, v, ldv, (int64_t)Lk * ldv, o, E, (int64_t)d.Lq * E, res,
+                       E, (int64_t)d.Lq * E, nullptr, lse, d.B, d.Lq, Lk, E, scale, c.st);
+}
+// backward: dq [T,E]; dk / dv written at (ptr, ld) with batch stride Lk*ld; P / dS: [B,Lq,lkp] scratch
+int xat_bwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t ldk, const void* v, int64_t ldv, int Lk, const void* dO,
+            const float* lse, void* dq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* P, void* dS, float scale) {
+  const int lkp = (Lk + 7) / 8 * 8;
+  TRY(d2r_xattn_bwd(c.dt, q, E, (int64_t)d.Lq * E, k, ldk, (int64_t)Lk * ldk, v, ldv, (int64_t)Lk * ldv, dO, E, (int64_t)d.Lq * E, nullptr,
+                    lse, dq, E, (int64_t)d.Lq * E, P, dS, lkp, d.B, d.Lq, Lk, E, scale, c.st));
+  G gv(c.dt, c.dt, D2R_GEMM_TN, Lk, E, d.Lq, P, lkp, dO, E, dv, lddv);  // dV = P^T dO
+  gv.batch(d.B, (int64_t)d.Lq * lkp, (int64_t)d.Lq * E, (int64_t)Lk * lddv);
+  TRY(d2r_gemm(&gv.d, c.st));
+  G gk(c.dt, c.dt, D2R_GEMM_TN, Lk, E, d.Lq, dS, lkp, q, E, dk, lddk);  // dK = dS^T Q
+  gk.batch(d.B, (int64_t)d.Lq * lkp, (int64_t)d.Lq * E, (int64_t)Lk * lddk);
+  return d2r_gemm(&gk.d, c.st);
+}
+
+// ---- forward of one routing layer --------------------------------------------------------------------------
+int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
+              const void* const* refs, const void* other, LayerF& L, void* out_final, float* probs, int64_t ldp) {
+  const int B = d.B, T = d.T, S = d.S, nc = d.nc, hid = d.hid, n = d.n;
+  const int64_t TEe = (int64_t)d.Lq * E, SEe = (int64_t)d.Lk * E;
+  const d2r_linear_params* lp = p.lin;
+  // --- routers (fp32 end to end: routing decisions are exact) -------------------------------------------------
+  if (first) {  // the cells of layer 0 read the same tensor: pool once, ONE plain GEMM with N = ncell*hid
+    TRY(d2r_meanpool_fwd(c.dt, refs, 1, B, d.Lq, E, L.pooled, c.st));
+    TRY(lin(c, B, nc * hid, E, L.pooled, E, lp[D2R_RL_R0], L.h, D2R_ACT_RELU, nullptr, D2R_F32));
+  } else {
+    TRY(d2r_meanpool_fwd(c.dt, refs, nc, B, d.Lq, E, L.pooled, c.st));
+    G g(D2R_F32, D2R_F32, D2R_GEMM_NT, B, hid, E, L.pooled, E, lp[D2R_RL_R0].w, E, L.h, (int64_t)nc * hid);
+    g.batch(nc, (int64_t)B * E, (int64_t)hid * E, hid);
+    g.d.bias = lp[D2R_RL_R0].b, g.d.s_bias_b = hid, g.d.act = D2R_ACT_RELU;
+    TRY(d2r_gemm(&g.d, c.st));
+  }
+  {
+    G g(D2R_F32, D2R_F32, D2R_GEMM_NT, B, P, hid, L.h, (int64_t)nc * hid, lp[D2R_RL_R2].w, hid, L.gates, (int64_t)nc * P);
+    g.batch(nc, hid, (int64_t)P * hid, P);
+    g.d.bias = lp[D2R_RL_R2].b, g.d.s_bias_b = P, g.d.act = D2R_ACT_TANH_RELU;
+    TRY(d2r_gemm(&g.d, c.st));
+  }
+  // --- GLAC (cell 1) ---------------------------------------------------------------------------------------------
+  if (nc > 1) {
+    const void* x = refs[1];
+    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_GLAC_Q], L.g_q));
+    TRY(lin(c, S, 2 * E, E, other, E, lp[D2R_RL_GLAC_KV], L.g_kv));
+    TRY(xat_fwd(c, d, L.g_q, L.g_kv, 2 * E, (const char*)L.g_kv + E * d.es, 2 * E, d.Lk, L.g_c, nullptr, L.g_lse, XSCALE));
+    TRY(d2r_sqdiff_fwd(c.dt, x, L.g_c, L.g_sq, (int64_t)T * E, c.st));
+    TRY(lin(c, T, E, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC], L.g_loc));
+    TRY(d2r_l2norm_fwd(c.dt, L.g_loc, L.g_l2, L.g_nloc, T, E, c.st));
+    TRY(lin(c, T, E, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1], L.g_sl));
+    TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GLAC_TPOOL], L.g_pt, D2R_ACT_TANH));
+    TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GLAC_IPOOL], L.g_pi, D2R_ACT_TANH));
+    TRY(d2r_sqdiff_fwd(c.dt, L.g_pt, L.g_pi, L.g_dg, (int64_t)B * E, c.st));
+    TRY(lin(c, B, E, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO], L.g_glo));
+    TRY(d2r_l2norm_fwd(c.dt, L.g_glo, L.g_l2g, L.g_nglo, B, E, c.st));
+    TRY(lin(c, B, E, E, L.g_l2g, E, lp[D2R_RL_GLAC_FC2], L.g_sg));
+    // S = cat([sg[:,None], sl], 1)  [B, n, E]
+    const size_t row = (size_t)E * d.es;
+    TRY(copy2d(L.g_S, (size_t)n * row, L.g_sg, row, row, B, c.st));
+    TRY(copy2d((char*)L.g_S + row, (size_t)n * row, L.g_sl, (size_t)d.Lq * row, (size_t)d.Lq * row, B, c.st));
+    TRY(lin(c, B * n, 1, E, L.g_S, E, lp[D2R_RL_GLAC_SAFW], L.g_a, D2R_ACT_NONE, nullptr, -1, D2R_F32));
+    TRY(d2r_saf_gate_fwd(L.g_a, B, n, p.bn_weight, p.bn_bias, p.bn_running_mean, p.bn_running_var, train, L.g_w, L.g_saved, c.st));
+    TRY(d2r_cast(D2R_F32, L.g_w, c.dt, L.g_w16, (int64_t)B * n, c.st));
+    G g(c.dt, c.dt, D2R_GEMM_NN, 1, E, n, L.g_w16, n, L.g_S, E, L.g_wsum, E);  // wsum[b] = w[b] @ S[b]
+    g.batch(B, n, (int64_t)n * E, E);
+    TRY(d2r_gemm(&g.d, c.st));
+    TRY(d2r_l2norm_fwd(c.dt, L.g_wsum, L.e1, L.g_ne1, B, E, c.st));
+  }
+  // --- IMRC (cell 2) -----------------------------------------------------------------------------------------------
+  if (nc > 2) {
+    const void* x = refs[2];
+    const int dh = E / d.heads;
+    const char* qkv = (const char*)L.qkv;
+    TRY(lin(c, T, 3 * E, E, x, E, lp[D2R_RL_IMRC_QKV], L.qkv));
+    TRY(d2r_mha_fwd(c.dt, qkv, 3 * E, (int64_t)d.Lq * 3 * E, qkv + E * d.es, 3 * E, (int64_t)d.Lq * 3 * E, qkv + 2 * E * d.es, 3 * E,
+                    (int64_t)d.Lq * 3 * E, L.y, E, TEe, x, E, TEe, nullptr, L.lse_i, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), c.st));
+    TRY(lin(c, T, d.hidi, E, L.y, E, lp[D2R_RL_IMRC_FC1], L.f1, D2R_ACT_RELU));
+    TRY(lin(c, T, E, d.hidi, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2], L.e2, D2R_ACT_NONE, L.y));
+  }
+  // --- CMRC (cell 3) -----------------------------------------------------------------------------------------------
+  if (nc > 3) {
+    const void* x = refs[3];
+    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CMRC_Q], L.c_q));
+    TRY(lin(c, S, 2 * E, E, other, E, lp[D2R_RL_CMRC_KV], L.c_kv));
+    TRY(xat_fwd(c, d, L.c_q, L.c_kv, 2 * E, (const char*)L.c_kv + E * d.es, 2 * E, d.Lk, L.c_c, nullptr, L.c_lse, XSCALE));
+    TRY(lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE], L.c_s, D2R_ACT_TANH));
+    TRY(lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT], L.c_h));
+    TRY(d2r_muladd_fwd(c.dt, x, L.c_s, L.c_h, L.c_mod, (int64_t)T * E, c.st));
+    TRY(lin(c, T, E, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1], L.c_f, D2R_ACT_RELU));
+    TRY(lin(c, T, E, E, L.c_f, E, lp[D2R_RL_CMRC_FC2], L.e3, D2R_ACT_NONE, x));
+  }
+  // --- CRCMC (cell 4) ----------------------------------------------------------------------------------------------
+  if (nc > 4) {
+    const void* x = refs[4];
+    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CRCMC_Q], L.r_q));
+    TRY(lin(c, S, 2 * E, E, other, E, lp[D2R_RL_CRCMC_KV], L.r_kv));
+    TRY(xat_fwd(c, d, L.r_q, L.r_kv, 2 * E, (const char*)L.r_kv + E * d.es, 2 * E, d.Lk, L.r_c, nullptr, L.r_lse, XSCALE));
+    TRY(lin(c, T, E, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1], L.r_Qs, D2R_ACT_TANH));
+    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CRCMC_MLP2], L.r_Ks, D2R_ACT_TANH));
+    TRY(lin(c, T, E, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1], L.r_a));
+    TRY(lin(c, T, E, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2], L.r_b));
+    TRY(xat_fwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, L.e4, L.r_Qs, L.r_lse2, 1.0f));  // unscaled softmax(Q K^T), + Qs
+  }
+  // --- GESC (cell 5) -----------------------------------------------------------------------------------------------
+  if (nc > 5) {
+    const void* x = refs[5];
+    TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GESC_TPOOL], L.s_a, D2R_ACT_TANH));
+    TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GESC_IPOOL], L.s_b, D2R_ACT_TANH));
+    TRY(d2r_add(c.dt, L.s_a, L.s_b, L.s_ab, (int64_t)B * E, c.st));
+    TRY(lin(c, B, E, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0], L.s_z1, D2R_ACT_TANH));
+    TRY(lin(c, B, E, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2], L.s_z));
+    TRY(d2r_softmax_fwd(c.dt, c.dt, L.s_z, L.s_g, E, B, E, 1.0f, nullptr, 1, c.st));
+    TRY(d2r_lerp_fwd(c.dt, L.s_g, L.s_a, L.s_b, L.e5, (int64_t)B * E, c.st));
+  }
+  // --- K8: path normalisation, gates, aggregation ------------------------------------------------------------------
+  const void* embs[6] = {refs[0], L.e1, L.e2, L.e3, L.e4, L.e5};
+  void* outs[6];
+  for (int i = 0; i < 6; ++i) outs[i] = final ? (i == 0 ? out_final : nullptr) : L.outs[i];
+  return d2r_route_aggregate_fwd(c.dt, embs, final ? refs : nullptr, L.gates, B, d.Lq, E, nc, P, outs, probs, ldp, c.st);
+}
+
+// ---- backward scratch of one layer -----------------------------------------------------------------------------
+struct LayerB {
+  float *dgates, *dG, *dh, *dhp, *dpooled, *cs0, *cs2, *bn2;
+  void *cws;
+  size_t cws_bytes;
+  void *agg_ws;
+  size_t agg_bytes;
+  void* de[6];
+  void* dx[6];
+  void *i_df1, *i_dy, *i_dqkv;
+  void *g_dwsum, *g_dw16, *g_dS, *g_dsl, *g_dl2, *g_dloc, *g_dsq, *g_da, *g_dc, *g_dq, *g_P, *g_dSa, *g_dkv, *g_dl2g, *g_dglo, *g_ddg,
+      *g_dpt, *g_dpi, *g_dptp, *g_dpip, *g_da16;
+  float *g_dwf, *g_daf;
+  void *c_dfp, *c_dmod, *c_da, *c_ds, *c_dsp, *c_dc, *c_dq, *c_P, *c_dSa, *c_dkv, *c_tmp;
+  void *r_da, *r_P2, *r_dS2, *r_dKv, *r_db, *r_dQs, *r_dKs, *r_dQsp, *r_dKsp, *r_dc, *r_dq, *r_P, *r_dSa, *r_dkv;
+  void *s_dg, *s_da1, *s_db1, *s_dz, *s_dz1p, *s_dab, *s_dat, *s_dbt, *s_dap, *s_dbp;
+};
+
+void plan_bwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerB& K) {
+  const size_t TE = (size_t)d.T * E * d.es, SE = (size_t)d.S * E * d.es, BE = (size_t)d.B * E * d.es;
+  memset(&K, 0, sizeof(K));
+  K.dgates = (float*)A.take((size_t)d.B * d.nc * P * 4), K.dG = (float*)A.take((size_t)d.B * d.nc * P * 4);
+  K.dh = (float*)A.take((size_t)d.B * d.nc * d.hid * 4), K.dhp = (float*)A.take((size_t)d.B * d.nc * d.hid * 4);
+  K.dpooled = (float*)A.take((size_t)(first ? 1 : d.nc) * d.B * E * 4);
+  K.cs0 = (float*)A.take((size_t)d.nc * d.hid * 4), K.cs2 = (float*)A.take((size_t)d.nc * P * 4), K.bn2 = (float*)A.take(16);
+  K.cws_bytes = d2r_colsum_workspace(d.B, d.nc * d.hid) + d2r_colsum_workspace(d.B, d.nc * P) + 256;
+  K.cws = A.take(K.cws_bytes);
+  K.agg_bytes = d2r_route_aggregate_bwd_workspace(d.B, d.Lq, E, P);
+  K.agg_ws = A.take(K.agg_bytes);
+  K.de[1] = A.take(BE), K.de[5] = A.take(BE);
+  for (int j : {2, 3, 4}) K.de[j] = A.take(TE);
+  if (first) K.de[0] = nullptr;  // written straight into d_own
+  if (!first)
+    for (int j = 0; j < d.nc; ++j) K.dx[j] = A.take(TE);  // gradients w.r.t. this layer's six inputs
+  if (final) K.de[0] = A.take(TE);  // final layer: relu-path gradient of x0 (the skip-path gradient goes to dx[0])
+  if (d.nc > 2) K.i_df1 = A.take((size_t)d.T * d.hidi * d.es), K.i_dy = A.take(TE), K.i_dqkv = A.take(3 * TE);
+  if (d.nc > 1) {
+    K.g_dwsum = A.take(BE), K.g_dw16 = A.take((size_t)d.B * d.n * d.es + 16), K.g_dS = A.take((size_t)d.B * d.n * E * d.es);
+    K.g_dsl = A.take(TE), K.g_dl2 = A.take(TE), K.g_dloc = A.take(TE), K.g_dsq = A.take(TE), K.g_da = A.take(TE), K.g_dc = A.take(TE);
+    K.g_dq = A.take(TE), K.g_P = A.take((size_t)d.T * d.lkp * d.es), K.g_dSa = A.take((size_t)d.T * d.lkp * d.es), K.g_dkv = A.take(2 * SE);
+    K.g_dl2g = A.take(BE), K.g_dglo = A.take(BE), K.g_ddg = A.take(BE), K.g_dpt = A.take(BE), K.g_dpi = A.take(BE);
+    K.g_dptp = A.take(BE), K.g_dpip = A.take(BE), K.g_da16 = A.take((size_t)d.B * d.n * d.es + 16);
+    K.g_dwf = (float*)A.take((size_t)d.B * d.n * 4), K.g_daf = (float*)A.take((size_t)d.B * d.n * 4);
+  }
+  if (d.nc > 3) {
+    K.c_dfp = A.take(TE), K.c_dmod = A.take(TE), K.c_da = A.take(TE), K.c_ds = A.take(TE), K.c_dsp = A.take(TE), K.c_dc = A.take(TE);
+    K.c_dq = A.take(TE), K.c_P = A.take((size_t)d.T * d.lkp * d.es), K.c_dSa = A.take((size_t)d.T * d.lkp * d.es), K.c_dkv = A.take(2 * SE);
+    K.c_tmp = A.take(TE);
+  }
+  if (d.nc > 4) {
+    K.r_da = A.take(TE), K.r_P2 = A.take((size_t)d.T * d.lqp * d.es), K.r_dS2 = A.take((size_t)d.T * d.lqp * d.es), K.r_dKv = A.take(TE);
+    K.r_db = A.take(TE), K.r_dQs = A.take(TE), K.r_dKs = A.take(TE), K.r_dQsp = A.take(TE), K.r_dKsp = A.take(TE), K.r_dc = A.take(TE);
+    K.r_dq = A.take(TE), K.r_P = A.take((size_t)d.T * d.lkp * d.es), K.r_dSa = A.take((size_t)d.T * d.lkp * d.es), K.r_dkv = A.take(2 * SE);
+  }
+  if (d.nc > 5) {
+    K.s_dg = A.take(BE), K.s_da1 = A.take(BE), K.s_db1 = A.take(BE), K.s_dz = A.take(BE), K.s_dz1p = A.take(BE), K.s_dab = A.take(BE);
+    K.s_dat = A.take(BE), K.s_dbt = A.take(BE), K.s_dap = A.take(BE), K.s_dbp = A.take(BE);
+  }
+}
+
+// fp32 sink += fp32 temp
+int acc32(const Ctx& c, const float* tmp, float* sink, int64_t nel) { return d2r_axpby(D2R_F32, 1.f, tmp, 1.f, sink, nel, c.st); }
+
+// ---- backward of one routing layer --------------------------------------------------------------------------------
+// douts[i]: gradient of output i (NULL = zero; only legal for the final layer's single output);  dx[j]: gradient w.r.t.
+// input j, OVERWRITTEN (layer 0: all six alias d_own);  d_other: ACCUMULATED (zeroed by the caller).
+int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
+              const void* const* refs, const void* other, const LayerF& L, LayerB& K, const void* const* douts, const void* out_final,
+              const float* dprobs, int64_t ldp, void* const* dx, void* d_other, Jobs& jobs) {
+  const int B = d.B, T = d.T, S = d.S, nc = d.nc, hid = d.hid, n = d.n;
+  const int64_t TEe = (int64_t)d.Lq * E, SEe = (int64_t)d.Lk * E, TEn = (int64_t)T * E, BEn = (int64_t)B * E;
+  const d2r_linear_params* lp = p.lin;
+  // --- K8 backward ---------------------------------------------------------------------------------------------------
+  {
+    const void* embs[6] = {refs[0], L.e1, L.e2, L.e3, L.e4, L.e5};
+    void* dembs[6];
+    void* drefs[6];
+    for (int j = 0; j < 6; ++j) dembs[j] = K.de[j], drefs[j] = nullptr;
+    if (final) {
+      for (int j = 0; j < nc; ++j) drefs[j] = dx[j];  // skip-path gradients initialise dx[j]; de[0] holds the relu path
+    } else {
+      dembs[0] = dx[0];  // the relu-path gradient of x0 initialises dx[0] (layer 0: d_own)
+    }
+    const void* outs[1] = {out_final};
+    TRY(d2r_route_aggregate_bwd(c.dt, embs, final ? refs : nullptr, L.gates, douts, final ? outs : nullptr, dprobs, ldp, B, d.Lq, E, nc, P,
+                                dembs, final ? drefs : nullptr, K.dgates, K.agg_ws, K.agg_bytes, c.st));
+    if (final) TRY(d2r_axpby(c.dt, 1.f, K.de[0], 1.f, dx[0], TEn, c.st));  // x0 is ref_0: relu path + skip path
+  }
+  // --- routers ---------------------------------------------------------------------------------------------------------
+  {
+    TRY(d2r_act_bwd(D2R_F32, D2R_ACT_TANH_RELU, K.dgates, L.gates, K.dG, (int64_t)B * nc * P, c.st));
+    G gx(D2R_F32, D2R_F32, D2R_GEMM_NN, B, hid, P, K.dG, (int64_t)nc * P, lp[D2R_RL_R2].w, hid, K.dh, (int64_t)nc * hid);
+    gx.batch(nc, P, (int64_t)P * hid, hid);
+    TRY(d2r_gemm(&gx.d, c.st));
+    G gw(D2R_F32, D2R_F32, D2R_GEMM_TN, P, hid, B, K.dG, (int64_t)nc * P, L.h, (int64_t)nc * hid, lp[D2R_RL_R2].gw, hid);
+    gw.batch(nc, P, hid, (int64_t)P * hid);
+    gw.d.beta = 1.f;
+    TRY(d2r_gemm(&gw.d, c.st));
+    TRY(d2r_colsum(D2R_F32, K.dG, (int64_t)nc * P, B, nc * P, K.cs2, K.cws, K.cws_bytes, c.st));
+    TRY(acc32(c, K.cs2, lp[D2R_RL_R2].gb, (int64_t)nc * P));
+    TRY(d2r_act_bwd(D2R_F32, D2R_ACT_RELU, K.dh, L.h, K.dhp, (int64_t)B * nc * hid, c.st));
+    if (first) {
+      TRY(dxg(c, B, E, nc * hid, K.dhp, (int64_t)nc * hid, lp[D2R_RL_R0].w, K.dpooled, E, 0.f, nullptr, nullptr, D2R_ACT_NONE, D2R_F32));
+      TRY(dwg(c, B, nc * hid, E, K.dhp, (int64_t)nc * hid, L.pooled, E, lp[D2R_RL_R0], D2R_F32));
+      TRY(d2r_meanpool_bwd(c.dt, K.dpooled, B, d.Lq, E, dx[0], 1, c.st));
+    } else {
+      G g0(D2R_F32, D2R_F32, D2R_GEMM_NN, B, E, hid, K.dhp, (int64_t)nc * hid, lp[D2R_RL_R0].w, E, K.dpooled, E);
+      g0.batch(nc, hid, (int64_t)hid * E, (int64_t)B * E);
+      TRY(d2r_gemm(&g0.d, c.st));
+      G gw0(D2R_F32, D2R_F32, D2R_GEMM_TN, hid, E, B, K.dhp, (int64_t)nc * hid, L.pooled, E, lp[D2R_RL_R0].gw, E);
+      gw0.batch(nc, hid, (int64_t)B * E, (int64_t)hid * E);
+      gw0.d.beta = 1.f;
+      TRY(d2r_gemm(&gw0.d, c.st));
+      TRY(d2r_colsum(D2R_F32, K.dhp, (int64_t)nc * hid, B, nc * hid, K.cs0, K.cws, K.cws_bytes, c.st));
+      TRY(acc32(c, K.cs0, lp[D2R_RL_R0].gb, (int64_t)nc * hid));
+      // dx[0] already holds the aggregation's gradient (and, in the final layer, every dx[j] the skip-path gradient)
+      for (int j = 0; j < nc; ++j)
+        TRY(d2r_meanpool_bwd(c.dt, K.dpooled + (size_t)j * B * E, B, d.Lq, E, dx[j], (j == 0 || final) ? 1 : 0, c.st));
+    }
+  }
+  // from here on every dx[j] is initialised: the cells ACCUMULATE into it (GEMM epilogues, beta = 1)
+  // --- GLAC ------------------------------------------------------------------------------------------------------------
+  if (nc > 1) {
+    const void* x = refs[1];
+    void* dxj = dx[1];
+    TRY(d2r_l2norm_bwd(c.dt, K.de[1], L.g_wsum, L.g_ne1, K.g_dwsum, B, E, c.st));
+    G gw(c.dt, c.dt, D2R_GEMM_NT, 1, n, E, K.g_dwsum, E, L.g_S, E, K.g_dw16, n);  // d w[b] = d wsum[b] S[b]^T
+    gw.batch(B, E, (int64_t)n * E, n);
+    TRY(d2r_gemm(&gw.d, c.st));
+    G gs(c.dt, c.dt, D2R_GEMM_TN, n, E, 1, L.g_w16, n, K.g_dwsum, E, K.g_dS, E);  // d S[b] = w[b]^T d wsum[b]
+    gs.batch(B, n, E, (int64_t)n * E);
+    TRY(d2r_gemm(&gs.d, c.st));
+    TRY(d2r_cast(c.dt, K.g_dw16, D2R_F32, K.g_dwf, (int64_t)B * n, c.st));
+    TRY(d2r_saf_gate_bwd(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, K.bn2, K.bn2 + 1, c.st));
+    TRY(acc32(c, K.bn2, p.g_bn_weight, 1));
+    TRY(acc32(c, K.bn2 + 1, p.g_bn_bias, 1));
+    TRY(d2r_cast(D2R_F32, K.g_daf, c.dt, K.g_da16, (int64_t)B * n, c.st));
+    TRY(dxg(c, B * n, E, 1, K.g_da16, 1, lp[D2R_RL_GLAC_SAFW].w, K.g_dS, E, 1.f));  // + d a w_saf
+    TRY(dwg(c, B * n, 1, E, K.g_da16, 1, L.g_S, E, lp[D2R_RL_GLAC_SAFW]));
+    // split dS: row 0 of every sample = d sg (used in place, row stride n*E), rows 1.. = d sl (made contiguous)
+    const size_t row = (size_t)E * d.es;
+    TRY(copy2d(K.g_dsl, (size_t)d.Lq * row, (char*)K.g_dS + row, (size_t)n * row, (size_t)d.Lq * row, B, c.st));
+    const int64_t ldsg = (int64_t)n * E;
+    // local path
+    TRY(dxg(c, T, E, E, K.g_dsl, E, lp[D2R_RL_GLAC_FC1].w, K.g_dl2, E));
+    defer(jobs, T, E, E, K.g_dsl, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1]);
+    TRY(d2r_l2norm_bwd(c.dt, K.g_dl2, L.g_loc, L.g_nloc, K.g_dloc, T, E, c.st));
+    TRY(dxg(c, T, E, E, K.g_dloc, E, lp[D2R_RL_GLAC_LOC].w, K.g_dsq, E));
+    defer(jobs, T, E, E, K.g_dloc, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC]);
+    TRY(d2r_sqdiff_bwd(c.dt, x, L.g_c, K.g_dsq, K.g_da, K.g_dc, TEn, c.st));
+    TRY(xat_bwd(c, d, L.g_q, L.g_kv, 2 * E, (const char*)L.g_kv + E * d.es, 2 * E, d.Lk, K.g_dc, L.g_lse, K.g_dq, K.g_dkv, 2 * E,
+                (char*)K.g_dkv + E * d.es, 2 * E, K.g_P, K.g_dSa, XSCALE));
+    TRY(dxg(c, T, E, E, K.g_dq, E, lp[D2R_RL_GLAC_Q].w, dxj, E, 1.f, K.g_da));  // += dq Wq + d(sqdiff)/dx
+    defer(jobs, T, E, E, K.g_dq, E, x, E, lp[D2R_RL_GLAC_Q]);
+    TRY(dxg(c, S, E, 2 * E, K.g_dkv, 2 * E, lp[D2R_RL_GLAC_KV].w, d_other, E, 1.f));
+    defer(jobs, S, 2 * E, E, K.g_dkv, 2 * E, other, E, lp[D2R_RL_GLAC_KV]);
+    // global path
+    TRY(dxg(c, B, E, E, K.g_dS, ldsg, lp[D2R_RL_GLAC_FC2].w, K.g_dl2g, E));
+    defer(jobs, B, E, E, K.g_dS, ldsg, L.g_l2g, E, lp[D2R_RL_GLAC_FC2]);
+    TRY(d2r_l2norm_bwd(c.dt, K.g_dl2g, L.g_glo, L.g_nglo, K.g_dglo, B, E, c.st));
+    TRY(dxg(c, B, E, E, K.g_dglo, E, lp[D2R_RL_GLAC_GLO].w, K.g_ddg, E));
+    defer(jobs, B, E, E, K.g_dglo, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO]);
+    TRY(d2r_sqdiff_bwd(c.dt, L.g_pt, L.g_pi, K.g_ddg, K.g_dpt, K.g_dpi, BEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.g_dpt, L.g_pt, K.g_dptp, BEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.g_dpi, L.g_pi, K.g_dpip, BEn, c.st));
+    TRY(dxg(c, B, E, E, K.g_dptp, E, lp[D2R_RL_GLAC_TPOOL].w, dxj, TEe, 1.f));      // token 0 of every sample
+    defer(jobs, B, E, E, K.g_dptp, E, x, TEe, lp[D2R_RL_GLAC_TPOOL]);
+    TRY(dxg(c, B, E, E, K.g_dpip, E, lp[D2R_RL_GLAC_IPOOL].w, d_other, SEe, 1.f));
+    defer(jobs, B, E, E, K.g_dpip, E, other, SEe, lp[D2R_RL_GLAC_IPOOL]);
+  }
+  // --- IMRC ------------------------------------------------------------------------------------------------------------
+  if (nc > 2) {
+    const void* x = refs[2];
+    const int dh = E / d.heads;
+    const char* qkv = (const char*)L.qkv;
+    char* dqkv = (char*)K.i_dqkv;
+    const int64_t E3 = 3 * E, sb3 = (int64_t)d.Lq * 3 * E;
+    TRY(dxg(c, T, d.hidi, E, K.de[2], E, lp[D2R_RL_IMRC_FC2].w, K.i_df1, d.hidi, 0.f, nullptr, L.f1, D2R_ACT_RELU));  // d f1_pre
+    defer(jobs, T, E, d.hidi, K.de[2], E, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2]);
+    TRY(dxg(c, T, E, d.hidi, K.i_df1, d.hidi, lp[D2R_RL_IMRC_FC1].w, K.i_dy, E, 0.f, K.de[2]));  // + skip y -> e2
+    defer(jobs, T, d.hidi, E, K.i_df1, d.hidi, L.y, E, lp[D2R_RL_IMRC_FC1]);
+    TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, dqkv, E3, sb3,
+                    dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), c.st));
+    TRY(dxg(c, T, E, 3 * E, dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
+    TRY(dwg(c, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]));
+  }
+  // --- CMRC ------------------------------------------------------------------------------------------------------------
+  if (nc > 3) {
+    const void* x = refs[3];
+    TRY(dxg(c, T, E, E, K.de[3], E, lp[D2R_RL_CMRC_FC2].w, K.c_dfp, E, 0.f, nullptr, L.c_f, D2R_ACT_RELU));
+    defer(jobs, T, E, E, K.de[3], E, L.c_f, E, lp[D2R_RL_CMRC_FC2]);
+    TRY(dxg(c, T, E, E, K.c_dfp, E, lp[D2R_RL_CMRC_FC1].w, K.c_dmod, E));
+    defer(jobs, T, E, E, K.c_dfp, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1]);
+    TRY(d2r_muladd_bwd(c.dt, x, L.c_s, K.c_dmod, K.c_da, K.c_ds, TEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.c_ds, L.c_s, K.c_dsp, TEn, c.st));
+    TRY(dxg(c, T, E, E, K.c_dsp, E, lp[D2R_RL_CMRC_SCALE].w, K.c_dc, E));
+    defer(jobs, T, E, E, K.c_dsp, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE]);
+    TRY(dxg(c, T, E, E, K.c_dmod, E, lp[D2R_RL_CMRC_SHIFT].w, K.c_dc, E, 1.f));
+    defer(jobs, T, E, E, K.c_dmod, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT]);
+    TRY(xat_bwd(c, d, L.c_q, L.c_kv, 2 * E, (const char*)L.c_kv + E * d.es, 2 * E, d.Lk, K.c_dc, L.c_lse, K.c_dq, K.c_dkv, 2 * E,
+                (char*)K.c_dkv + E * d.es, 2 * E, K.c_P, K.c_dSa, XSCALE));
+    TRY(d2r_add(c.dt, K.c_da, K.de[3], K.c_tmp, TEn, c.st));  // FiLM path + skip x -> e3
+    TRY(dxg(c, T, E, E, K.c_dq, E, lp[D2R_RL_CMRC_Q].w, dx[3], E, 1.f, K.c_tmp));
+    defer(jobs, T, E, E, K.c_dq, E, x, E, lp[D2R_RL_CMRC_Q]);
+    TRY(dxg(c, S, E, 2 * E, K.c_dkv, 2 * E, lp[D2R_RL_CMRC_KV].w, d_other, E, 1.f));
+    defer(jobs, S, 2 * E, E, K.c_dkv, 2 * E, other, E, lp[D2R_RL_CMRC_KV]);
+  }
+  // --- CRCMC -----------------------------------------------------------------------------------------------------------
+  if (nc > 4) {
+    const void* x = refs[4];
+    TRY(xat_bwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, K.de[4], L.r_lse2, K.r_da, K.r_db, E, K.r_dKv, E, K.r_P2, K.r_dS2, 1.0f));
+    TRY(dxg(c, T, E, E, K.r_da, E, lp[D2R_RL_CRCMC_FC1].w, K.r_dQs, E, 0.f, K.de[4]));  // + residual Qs -> e4
+    defer(jobs, T, E, E, K.r_da, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1]);
+    TRY(dxg(c, T, E, E, K.r_db, E, lp[D2R_RL_CRCMC_FC2].w, K.r_dKs, E, 0.f, K.r_dKv));  // + Ks as the attention's value
+    defer(jobs, T, E, E, K.r_db, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2]);
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dQs, L.r_Qs, K.r_dQsp, TEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dKs, L.r_Ks, K.r_dKsp, TEn, c.st));
+    TRY(dxg(c, T, E, E, K.r_dQsp, E, lp[D2R_RL_CRCMC_MLP1].w, K.r_dc, E));
+    defer(jobs, T, E, E, K.r_dQsp, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1]);
+    TRY(xat_bwd(c, d, L.r_q, L.r_kv, 2 * E, (const char*)L.r_kv + E * d.es, 2 * E, d.Lk, K.r_dc, L.r_lse, K.r_dq, K.r_dkv, 2 * E,
+                (char*)K.r_dkv + E * d.es, 2 * E, K.r_P, K.r_dSa, XSCALE));
+    TRY(dxg(c, T, E, E, K.r_dq, E, lp[D2R_RL_CRCMC_Q].w, dx[4], E, 1.f));
+    defer(jobs, T, E, E, K.r_dq, E, x, E, lp[D2R_RL_CRCMC_Q]);
+    TRY(dxg(c, T, E, E, K.r_dKsp, E, lp[D2R_RL_CRCMC_MLP2].w, dx[4], E, 1.f));
+    defer(jobs, T, E, E, K.r_dKsp, E, x, E, lp[D2R_RL_CRCMC_MLP2]);
+    TRY(dxg(c, S, E, 2 * E, K.r_dkv, 2 * E, lp[D2R_RL_CRCMC_KV].w, d_other, E, 1.f));
+    defer(jobs, S, 2 * E, E, K.r_dkv, 2 * E, other, E, lp[D2R_RL_CRCMC_KV]);
+  }
+  // --- GESC ------------------------------------------------------------------------------------------------------------
+  if (nc > 5) {
+    const void* x = refs[5];
+    TRY(d2r_lerp_bwd(c.dt, L.s_g, L.s_a, L.s_b, K.de[5], K.s_dg, K.s_da1, K.s_db1, BEn, c.st));
+    TRY(d2r_softmax_bwd(c.dt, c.dt, L.s_g, K.s_dg, K.s_dz, E, B, E, 1.0f, c.st));
+    TRY(dxg(c, B, E, E, K.s_dz, E, lp[D2R_RL_GESC_MLP2].w, K.s_dz1p, E, 0.f, nullptr, L.s_z1, D2R_ACT_TANH));
+    defer(jobs, B, E, E, K.s_dz, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2]);
+    TRY(dxg(c, B, E, E, K.s_dz1p, E, lp[D2R_RL_GESC_MLP0].w, K.s_dab, E));
+    defer(jobs, B, E, E, K.s_dz1p, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0]);
+    TRY(d2r_add(c.dt, K.s_da1, K.s_dab, K.s_dat, BEn, c.st));
+    TRY(d2r_add(c.dt, K.s_db1, K.s_dab, K.s_dbt, BEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dat, L.s_a, K.s_dap, BEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dbt, L.s_b, K.s_dbp, BEn, c.st));
+    TRY(dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f));
+    defer(jobs, B, E, E, K.s_dap, E, x, TEe, lp[D2R_RL_GESC_TPOOL]);
+    TRY(dxg(c, B, E, E, K.s_dbp, E, lp[D2R_RL_GESC_IPOOL].w, d_other, SEe, 1.f));
+    defer(jobs, B, E, E, K.s_dbp, E, other, SEe, lp[D2R_RL_GESC_IPOOL]);
+  }
+  return D2R_OK;
+}
+
+int check(const d2r_interaction_desc* D, const char* fn, bool bwd) {
+  D2R_REQUIRE(D != nullptr, "%s: null descriptor", fn);
+  D2R_REQUIRE(D->B >= 1 && D->Lq >= 1 && D->Lk >= 1 && D->nlayer >= 2 && D->hid_router >= 1 && D->hid_imrc >= 8 && D->heads_imrc >= 1,
+              "%s: bad shape", fn);
+  D2R_REQUIRE(d2r_interaction_supported(D->dtype, D->Lq, D->Lk, D->ncell, D->heads_imrc),
+              "%s: unsupported (bf16, 2..6 cells, token counts within the fused attention cores' limits)", fn);
+  D2R_REQUIRE(D->layers && D->own && D->other && D->out && D->paths && D->arena && d2r_aligned16(D->arena), "%s: null / unaligned pointer", fn);
+  D2R_REQUIRE(D->arena_bytes >= d2r_interaction_arena_bytes(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc),
+              "%s: arena too small", fn);
+  if (bwd) {
+    D2R_REQUIRE(D->d_own && D->d_other && D->scratch && d2r_aligned16(D->scratch), "%s: null / unaligned gradient pointer", fn);
+    D2R_REQUIRE(D->scratch_bytes >= d2r_interaction_bwd_scratch(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc),
+                "%s: scratch too small", fn);
+  }
+  return D2R_OK;
+}
+
+}  // namespace
+
+extern "C" int d2r_interaction_supported(int dtype, int Lq, int Lk, int ncell, int heads_imrc) {
+  if (dtype != D2R_BF16 || ncell < 2 || ncell > 6 || heads_imrc < 1 || heads_imrc > 64 || E % heads_imrc) return 0;
+  if (!d2r_xattn_supported(dtype, Lq, Lk, E)) return 0;
+  if (ncell > 4 && !d2r_xattn_supported(dtype, Lq, Lq, E)) return 0;
+  if (ncell > 2 && !d2r_mha_supported(dtype, Lq, Lq, E / heads_imrc)) return 0;
+  return 1;
+}
+
+extern "C" size_t d2r_interaction_arena_bytes(int B, int Lq, int Lk, int ncell, int nlayer, int hid_router, int hid_imrc) {
+  const Dims d = make_dims(B, Lq, Lk, ncell, nlayer, hid_router, hid_imrc, 16);
+  Arena A(nullptr);
+  LayerF L;
+  for (int l = 0; l < nlayer; ++l) plan_fwd(A, d, l == nlayer - 1 ? 1 : ncell, l == 0, l == nlayer - 1, L);
+  return A.off + 256;
+}
+
+extern "C" size_t d2r_interaction_bwd_scratch(int B, int Lq, int Lk, int ncell, int nlayer, int hid_router, int hid_imrc) {
+  const Dims d = make_dims(B, Lq, Lk, ncell, nlayer, hid_router, hid_imrc, 16);
+  Arena A(nullptr);
+  LayerB K;
+  for (int l = 0; l < nlayer; ++l) plan_bwd(A, d, l == nlayer - 1 ? 1 : ncell, l == 0, l == nlayer - 1, K);
+  A.take((size_t)d.T * E * d.es);  // zero gradient standing in for a missing d_out
+  return A.off + 256;
+}
+
+extern "C" int d2r_interaction_fwd(const d2r_interaction_desc* D, void* stream) {
+  TRY(check(D, "d2r_interaction_fwd", false));
+  const Dims d = make_dims(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc, D->heads_imrc);
+  const Ctx c{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
+  Arena A(D->arena);
+  const int nc = d.nc, total = nc * nc * (d.nl - 1) + nc;
+  const void* refs[6];
+  for (int j = 0; j < 6; ++j) refs[j] = D->own;
+  LayerF L;
+  for (int l = 0; l < d.nl; ++l) {
+    const bool first = l == 0, final = l == d.nl - 1;
+    const int P = final ? 1 : nc;
+    plan_fwd(A, d, P, first, final, L);
+    TRY(layer_fwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, L, D->out, D->paths + (size_t)l * nc * nc, total));
+    for (int j = 0; j < nc && !final; ++j) refs[j] = L.outs[j];
+  }
+  return D2R_OK;
+}
+
+extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) {
+  TRY(check(D, "d2r_interaction_bwd", true));
+  const Dims d = make_dims(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc, D->heads_imrc);
+  const Ctx c{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
+  const int nc = d.nc, nl = d.nl, total = nc * nc * (nl - 1) + nc;
+  const size_t TE = (size_t)d.T * E * d.es;
+  std::vector<LayerF> F(nl);
+  std::vector<LayerB> K(nl);
+  Arena A(D->arena), Z(D->scratch);
+  for (int l = 0; l < nl; ++l) plan_fwd(A, d, l == nl - 1 ? 1 : nc, l == 0, l == nl - 1, F[l]);
+  for (int l = 0; l < nl; ++l) plan_bwd(Z, d, l == nl - 1 ? 1 : nc, l == 0, l == nl - 1, K[l]);
+  void* zero_out = Z.take(TE);
+  hipError_t e = hipMemsetAsync(D->d_other, 0, (size_t)d.S * E * d.es, (hipStream_t)stream);
+  if (e == hipSuccess && !D->d_out) e = hipMemsetAsync(zero_out, 0, TE, (hipStream_t)stream);
+  if (e != hipSuccess) return d2r_fail(D2R_ERR_LAUNCH, "d2r_interaction_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+  Jobs jobs;
+  for (int l = nl - 1; l >= 0; --l) {
+    const bool first = l == 0, final = l == nl - 1;
+    const int P = final ? 1 : nc;
+    const void* refs[6];
+    void* dx[6];
+    const void* douts[6];
+    for (int j = 0; j < 6; ++j) {
+      refs[j] = first ? D->own : (j < nc ? F[l - 1].outs[j] : nullptr);
+      dx[j] = first ? D->d_own : K[l].dx[j];
+      douts[j] = final ? (j == 0 ? (D->d_out ? D->d_out : zero_out) : nullptr) : K[l + 1].dx[j];
+    }
+    const float* dprobs = D->d_paths ? D->d_paths + (size_t)l * nc * nc : nullptr;
+    TRY(layer_bwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, F[l], K[l], douts, D->out, dprobs, total, dx, D->d_other, jobs));
+  }
+  return flush_jobs(c, jobs);
+}

@@ -115,7 +115,7 @@ extern "C" int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, i
 }
 
 // =====================================================================================================
-// K8 forward.  gates: fp32 [nc, B, P] (cell-major).  Cells 1 (GLAC) and 5 (GESC) are [B,D] broadcasts.
+// K8 forward.  gates: fp32 [B, nc, P] (sample-major: the layout the routers' grouped GEMM writes).  Cells 1 (GLAC) and 5 (GESC) are [B,D] broadcasts.
 // nc = number of cells of the layer: the first nc of [RIC, GLAC, IMRC, CMRC, CRCMC, GESC] (6 in the reference, which
 // hard-indexes them, models/DynamicInteraction.py:41-48; 2..5 = the declared-subset extension of SURVEY.md section 8c);
 // P = nc outputs (first / middle layers) or 1 (final layer).  probs: [B, P, nc].
@@ -136,7 +136,7 @@ __device__ __forceinline__ void st_f(T* p, const float (&o)[VEC]) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* __restrict__ gates, int B, int L, int D,
-                                                       int nc, MPtrs8 outs, float* __restrict__ probs) {
+                                                       int nc, MPtrs8 outs, float* __restrict__ probs, int64_t ldp) {
   constexpr int VEC = PackOf<T>::N;
   __shared__ float c[6][6];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* 
     float g[6], S = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = (j < nc && i < nc) ? gates[((int64_t)j * B + b) * nc + i] : 0.f;
+      g[j] = (j < nc && i < nc) ? gates[((int64_t)b * nc + j) * nc + i] : 0.f;
       S += g[j];
     }
     const float skip = S < TH_GATE ? 1.f : 0.f;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* 
     for (int j = 0; j < 6; ++j) {
       const float ph = g[j] / (S + EPS_NORM);
       c[i][j] = ph + (j == 0 ? skip : 0.f);
-      if (blockIdx.x == 0 && i < nc && j < nc) probs[((int64_t)b * nc + i) * nc + j] = ph;
+      if (blockIdx.x == 0 && i < nc && j < nc) probs[(int64_t)b * ldp + i * nc + j] = ph;
     }
   }
   __syncthreads();
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* 
 // final layer (P = 1): out = sum_j (g_j emb_j + s_j ref_j) / (sum s + sum g)
 template <typename T>
 __global__ __launch_bounds__(256) void agg_fwd1_kernel(Ptrs8 embs, Ptrs8 refs, const float* __restrict__ gates, int B,
-                                                       int L, int D, int nc, T* __restrict__ out, float* __restrict__ probs) {
+                                                       int L, int D, int nc, T* __restrict__ out, float* __restrict__ probs, int64_t ldp) {
   constexpr int VEC = PackOf<T>::N;
   __shared__ float cg[6], cs[6];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void agg_fwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
     const float thf = th_gate_final(nc);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = j < nc ? gates[(int64_t)j * B + b] : 0.f;
+      g[j] = j < nc ? gates[(int64_t)b * nc + j] : 0.f;
       s[j] = (j < nc && g[j] < thf) ? 1.f : 0.f;
       sg += g[j];
       ss += s[j];
-      if (blockIdx.x == 0 && j < nc) probs[(int64_t)b * nc + j] = g[j];
+      if (blockIdx.x == 0 && j < nc) probs[(int64_t)b * ldp + j] = g[j];
     }
     const float inv = 1.f / (ss + sg);
 #pragma unroll
@@ -251,11 +251,12 @@ static int agg_chunks(int L, int D, int VEC) {
 
 extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, const void* const* h_refs,
                                        const float* gates, int B, int L, int D, int ncell, int P, void* const* h_outs,
-                                       float* probs, void* stream) {
+                                       float* probs, int64_t ld_probs, void* stream) {
   D2R_REQUIRE(h_embs && gates && h_outs && probs, "d2r_route_aggregate_fwd: null pointer");
   D2R_REQUIRE(ncell >= 2 && ncell <= 6, "d2r_route_aggregate_fwd: ncell=%d (2..6)", ncell);
   D2R_REQUIRE(P == ncell || P == 1, "d2r_route_aggregate_fwd: P=%d (must be ncell=%d or 1)", P, ncell);
   D2R_REQUIRE(P != 1 || h_refs, "d2r_route_aggregate_fwd: the final layer needs refs");
+  D2R_REQUIRE(ld_probs >= (int64_t)P * ncell, "d2r_route_aggregate_fwd: ld_probs %lld < P*ncell", (long long)ld_probs);
   D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_route_aggregate_fwd: bad dtype %d", dtype);
   const int VEC = dtype == D2R_BF16 ? 8 : 4;
   D2R_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D % VEC == 0, "d2r_route_aggregate_fwd: bad shape B=%d L=%d D=%d", B, L, D);
@@ -276,11 +277,11 @@ extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, con
   dim3 grid(agg_chunks(L, D, VEC), B), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (P != 1) {
-    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd6_kernel<bf16_t>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs);
-    else hipLaunchKernelGGL((agg_fwd6_kernel<float>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs);
+    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd6_kernel<bf16_t>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs, ld_probs);
+    else hipLaunchKernelGGL((agg_fwd6_kernel<float>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs, ld_probs);
   } else {
-    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd1_kernel<bf16_t>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (bf16_t*)o.p[0], probs);
-    else hipLaunchKernelGGL((agg_fwd1_kernel<float>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (float*)o.p[0], probs);
+    if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd1_kernel<bf16_t>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (bf16_t*)o.p[0], probs, ld_probs);
+    else hipLaunchKernelGGL((agg_fwd1_kernel<float>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (float*)o.p[0], probs, ld_probs);
   }
   return d2r_check_launch("d2r_route_aggregate_fwd");
 }
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
     float g[6], S = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = (j < nc && i < nc) ? gates[((int64_t)j * B + b) * nc + i] : 0.f;
+      g[j] = (j < nc && i < nc) ? gates[((int64_t)b * nc + j) * nc + i] : 0.f;
       S += g[j];
     }
     const float skip = (i < nc && S < TH_GATE) ? 1.f : 0.f;
@@ -424,14 +425,14 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
                                                               const float* __restrict__ dprobs,
                                                               const float* __restrict__ ws_dots,
                                                               const float* __restrict__ ws_bc, int B, int D, int nchunk,
-                                                              int nc, T* __restrict__ demb1, T* __restrict__ demb5,
+                                                              int nc, int64_t ldp, T* __restrict__ demb1, T* __restrict__ demb5,
                                                               float* __restrict__ d_gates) {
   __shared__ float dph[36];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (blockIdx.y == 0) {  // block-uniform: only the first column block finishes the 36 dot products
   if (tid < 36) {
     const int i = tid / 6, j = tid - i * 6;
-    float t = (dprobs && i < nc && j < nc) ? dprobs[((int64_t)b * nc + i) * nc + j] : 0.f;
+    float t = (dprobs && i < nc && j < nc) ? dprobs[(int64_t)b * ldp + i * nc + j] : 0.f;
     for (int cidx = 0; cidx < nchunk; ++cidx) t += ws_dots[((int64_t)b * nchunk + cidx) * 36 + tid];
     dph[tid] = t;
   }
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
     float g[6], S = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = j < nc ? gates[((int64_t)j * B + b) * nc + i] : 0.f;
+      g[j] = j < nc ? gates[((int64_t)b * nc + j) * nc + i] : 0.f;
       S += g[j];
     }
     const float inv = 1.f / (S + EPS_NORM);
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
     for (int j = 0; j < 6; ++j) dotp += dph[i * 6 + j] * (g[j] * inv);
 #pragma unroll
     for (int j = 0; j < 6; ++j)
-      if (j < nc) d_gates[((int64_t)j * B + b) * nc + i] = (dph[i * 6 + j] - dotp) * inv;
+      if (j < nc) d_gates[((int64_t)b * nc + j) * nc + i] = (dph[i * 6 + j] - dotp) * inv;
   }
   }
   const int cidx = blockIdx.y * 256 + tid;  // one column of [demb1 | demb5] per thread, grid.y column blocks
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
     const float thf = th_gate_final(nc);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = j < nc ? gates[(int64_t)j * B + b] : 0.f;
+      g[j] = j < nc ? gates[(int64_t)b * nc + j] : 0.f;
       s[j] = (j < nc && g[j] < thf) ? 1.f : 0.f;
       sg += g[j];
       ss += s[j];
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
                                                               const float* __restrict__ dprobs,
                                                               const float* __restrict__ ws_dots,
                                                               const float* __restrict__ ws_bc, int B, int D, int nchunk,
-                                                              int nc, T* __restrict__ demb1, T* __restrict__ demb5,
+                                                              int nc, int64_t ldp, T* __restrict__ demb1, T* __restrict__ demb5,
                                                               float* __restrict__ d_gates) {
   __shared__ float dt[8], cgs[6];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
     const float thf = th_gate_final(nc);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      g[j] = j < nc ? gates[(int64_t)j * B + b] : 0.f;
+      g[j] = j < nc ? gates[(int64_t)b * nc + j] : 0.f;
       ss += (j < nc && g[j] < thf) ? 1.f : 0.f;
       sg += g[j];
     }
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       cgs[j] = g[j] * inv;
-      if (blockIdx.y == 0 && j < nc) d_gates[(int64_t)j * B + b] = (dt[j] - dt[6]) * inv + (dprobs ? dprobs[(int64_t)b * nc + j] : 0.f);
+      if (blockIdx.y == 0 && j < nc) d_gates[(int64_t)b * nc + j] = (dt[j] - dt[6]) * inv + (dprobs ? dprobs[(int64_t)b * ldp + j] : 0.f);
     }
   }
   __syncthreads();
@@ -625,7 +626,7 @@ extern "C" size_t d2r_route_aggregate_bwd_workspace(int B, int L, int D, int P) 
 // h_outs: the forward outputs (only outs[0] of the final layer is read).
 extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, const void* const* h_refs,
                                           const float* gates, const void* const* h_douts, const void* const* h_outs,
-                                          const float* d_probs, int B, int L, int D, int ncell, int P,
+                                          const float* d_probs, int64_t ld_dprobs, int B, int L, int D, int ncell, int P,
                                           void* const* h_dembs, void* const* h_drefs, float* d_gates, void* workspace,
                                           size_t workspace_bytes, void* stream) {
   D2R_REQUIRE(h_embs && gates && h_douts && h_dembs && d_gates, "d2r_route_aggregate_bwd: null pointer");
@@ -664,10 +665,10 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     if (shmem < 4 * 36 * sizeof(float)) shmem = 4 * 36 * sizeof(float);
     if (dtype == D2R_BF16) {
       hipLaunchKernelGGL((agg_bwd6_kernel<bf16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
     } else {
       hipLaunchKernelGGL((agg_bwd6_kernel<float>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, (float*)de.p[1], (float*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (float*)de.p[1], (float*)de.p[5], d_gates);
     }
   } else {
     const void* outp = h_outs[0];
@@ -676,10 +677,10 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     if (shmem < 4 * 8 * sizeof(float)) shmem = 4 * 8 * sizeof(float);
     if (dtype == D2R_BF16) {
       hipLaunchKernelGGL((agg_bwd1_kernel<bf16_t>), grid, block, shmem, st, e, r, gates, (const bf16_t*)dv.p[0], (const bf16_t*)outp, B, L, D, ncell, de, dr, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd1_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
     } else {
       hipLaunchKernelGGL((agg_bwd1_kernel<float>), grid, block, shmem, st, e, r, gates, (const float*)dv.p[0], (const float*)outp, B, L, D, ncell, de, dr, ws_dots, ws_bc);
-      hipLaunchKernelGGL((agg_bwd1_finish_kernel<float>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, (float*)de.p[1], (float*)de.p[5], d_gates);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<float>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (float*)de.p[1], (float*)de.p[5], d_gates);
     }
   }
   return d2r_check_launch("d2r_route_aggregate_bwd");

@@ -851,6 +851,108 @@ def encoder_layer(x, bundle: LayerBundle, mask=None):
 
 
 # ------------------------------------------------------------------------------------------------------
+# K16 whole (Reversed_)InteractionModule (16-bit compute): one C call forward, one backward
+# ------------------------------------------------------------------------------------------------------
+class InteractionBundle:
+    """Parameter / gradient-sink pointers of one interaction module (stable across steps: views of the flat buffers of
+    d2r_amd.params.ParamStore), packed as the d2r_routing_layer_params table of include/d2r_hip.h.
+
+    ``layers``: one dict per routing layer {RL name: (weight leaf, bias leaf)} plus 'bn': (weight, bias, running_mean,
+    running_var); weight leaves carry ._d2r_grad (fp32 sink) and, for the compute-dtype linears, ._d2r_lp (16-bit shadow);
+    the router linears (R0, R2) are multiplied as fp32 masters."""
+
+    def __init__(self, layers, ncell, hid_router, heads_imrc, hid_imrc):
+        self.ncell, self.nlayer = ncell, len(layers)
+        self.hid_router, self.heads_imrc, self.hid_imrc = hid_router, heads_imrc, hid_imrc
+        self.table = (_lib.RoutingLayerParams * self.nlayer)()
+        self.params = []  # every leaf whose gradient sink the backward call writes (data-parallel readiness)
+        key = []
+        for l, spec in enumerate(layers):
+            t = self.table[l]
+            for name, (w, b) in spec.items():
+                if name == "bn":
+                    continue
+                for leaf in (w, b):
+                    if getattr(leaf, "_d2r_grad", None) is None:
+                        raise _lib.D2RError("InteractionBundle needs a model prepared by ParamStore")
+                fp32 = name in ("R0", "R2")
+                wc = w if fp32 else getattr(w, "_d2r_lp", None)
+                if wc is None:
+                    raise _lib.D2RError("InteractionBundle needs the 16-bit weight shadow of ParamStore")
+                e = t.lin[_lib.RL[name]]
+                e.w, e.b, e.gw, e.gb = wc.data_ptr(), b.data_ptr(), w._d2r_grad.data_ptr(), b._d2r_grad.data_ptr()
+                self.params += [w, b]
+                key += [e.w, e.gw]
+            if "bn" in spec:
+                bw, bb, rm, rv = spec["bn"]
+                t.bn_weight, t.bn_bias, t.bn_running_mean, t.bn_running_var = bw.data_ptr(), bb.data_ptr(), rm.data_ptr(), rv.data_ptr()
+                t.g_bn_weight, t.g_bn_bias = bw._d2r_grad.data_ptr(), bb._d2r_grad.data_ptr()
+                self.params += [bw, bb]
+                key += [t.bn_running_mean]
+        self.key = tuple(key)
+        self.total_paths = ncell * ncell * (self.nlayer - 1) + ncell
+
+    def supports(self, own, other) -> bool:
+        return (own.dtype == torch.bfloat16 and other.dtype == torch.bfloat16 and own.is_cuda and own.dim() == 3 and own.shape[-1] == 768
+                and other.shape[-1] == 768
+                and bool(_lib.load().d2r_interaction_supported(BF16, own.shape[1], other.shape[1], self.ncell, self.heads_imrc)))
+
+
+class _Interaction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, own, other, anchor, bundle, train):
+        own, other = own.contiguous(), other.contiguous()
+        B, Lq, _ = own.shape
+        Lk = other.shape[1]
+        lib = _lib.load()
+        d = _lib.InteractionDesc()
+        d.dtype, d.B, d.Lq, d.Lk, d.ncell, d.nlayer = BF16, B, Lq, Lk, bundle.ncell, bundle.nlayer
+        d.hid_router, d.heads_imrc, d.hid_imrc, d.train = bundle.hid_router, bundle.heads_imrc, bundle.hid_imrc, int(train)
+        d.layers = bundle.table
+        out = torch.empty_like(own)
+        paths = torch.empty(B, bundle.total_paths, dtype=torch.float32, device=own.device)
+        nbytes = lib.d2r_interaction_arena_bytes(B, Lq, Lk, bundle.ncell, bundle.nlayer, bundle.hid_router, bundle.hid_imrc)
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=own.device)
+        ws = _workspace(64 << 20, own.device)
+        d.own, d.other, d.out, d.paths = own.data_ptr(), other.data_ptr(), out.data_ptr(), paths.data_ptr()
+        d.arena, d.arena_bytes, d.splitk_ws, d.splitk_bytes = arena.data_ptr(), arena.numel(), ws.data_ptr(), ws.numel()
+        _lib.call("d2r_interaction_fwd", C.byref(d), _stream(), meta=dict(group="interaction_fwd"))
+        ctx.save_for_backward(own, other, out)
+        ctx.d, ctx.keep, ctx.bundle = d, arena, bundle
+        return out, paths
+
+    @staticmethod
+    def backward(ctx, d_out, d_paths):
+        _ensure_backward_join()
+        own, other, out = ctx.saved_tensors
+        d, bundle = ctx.d, ctx.bundle
+        lib = _lib.load()
+        d_own, d_other = torch.empty_like(own), torch.empty_like(other)
+        if d_out is not None:
+            d_out = d_out.contiguous()
+        if d_paths is not None:
+            d_paths = d_paths.contiguous()
+        nbytes = lib.d2r_interaction_bwd_scratch(d.B, d.Lq, d.Lk, d.ncell, d.nlayer, d.hid_router, d.hid_imrc)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=own.device)
+        ws = _workspace(64 << 20, own.device)
+        d.splitk_ws, d.splitk_bytes = ws.data_ptr(), ws.numel()
+        d.d_out, d.d_paths, d.d_own, d.d_other = _ptr(d_out), _ptr(d_paths), d_own.data_ptr(), d_other.data_ptr()
+        d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
+        _lib.call("d2r_interaction_bwd", C.byref(d), _stream(), meta=dict(group="interaction_bwd"))
+        ctx.keep = None
+        for p in bundle.params:  # data-parallel bucket readiness (d2r_amd.dp): every sink of the module is written now
+            cb = getattr(p, "_d2r_ready_cb", None)
+            if cb is not None:
+                cb(p)
+        return d_own, d_other, None, None, None
+
+
+def interaction(own, other, bundle: InteractionBundle, train: bool):
+    """One whole (Reversed_)InteractionModule as a single autograd node: -> (emb [B,Lq,768], paths fp32 [B,total_paths])."""
+    return _Interaction.apply(own, other, bundle.params[0], bundle, bool(train))
+
+
+# ------------------------------------------------------------------------------------------------------
 # row kernels
 # ------------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
@@ -1141,7 +1243,7 @@ class _RouteAggregate(torch.autograd.Function):
         gates = gates.contiguous()
         B, L, D = embs[0].shape
         P = gates.shape[2]
-        assert gates.shape[0] == nc and P in (nc, 1)
+        assert gates.shape[1] == nc and P in (nc, 1), "gates: fp32 [B, ncell, P]"
         final = P == 1
         if final:
             assert len(refs) == nc - 1, "the final layer takes ref_1..ref_{ncell-1} (ref_0 is x0)"
@@ -1150,7 +1252,7 @@ class _RouteAggregate(torch.autograd.Function):
         probs = torch.empty(B, P, nc, dtype=torch.float32, device=gates.device)
         nfull = nc - 1 - (1 if nc > 5 else 0)  # cells with a [B,L,D] output (1 and 5 are per-sample broadcasts)
         _lib.call("d2r_route_aggregate_fwd", _dt(embs[0]), _parr(embs), _parr(all_refs) if final else None,
-                  gates.data_ptr(), B, L, D, nc, P, _parr(outs), probs.data_ptr(), _stream(),
+                  gates.data_ptr(), B, L, D, nc, P, _parr(outs), probs.data_ptr(), P * nc, _stream(),
                   meta=dict(group=f"route_aggregate_fwd_P{P}",
                             bytes=float(((nfull + P) * B * L * D + (nc - nfull) * B * D) * embs[0].element_size() + 4 * B * P * 2 * nc)))
         ctx.meta = (B, L, D, P, nc)
@@ -1176,7 +1278,7 @@ class _RouteAggregate(torch.autograd.Function):
         ws = _workspace(nbytes, dev)
         nfull = nc - 1 - (1 if nc > 5 else 0)
         _lib.call("d2r_route_aggregate_bwd", _dt(embs[0]), _parr(embs), _parr([embs[0]] + refs) if final else None,
-                  gates.data_ptr(), _parr(douts), _parr(out_saved) if final else None, _ptr(dprobs), B, L, D, nc, P,
+                  gates.data_ptr(), _parr(douts), _parr(out_saved) if final else None, _ptr(dprobs), P * nc, B, L, D, nc, P,
                   _parr(dembs), _parr(drefs) if final else None, dgates.data_ptr(), ws.data_ptr(), ws.numel(),
                   _stream(), meta=dict(group=f"route_aggregate_bwd_P{P}",
                                        bytes=float(((P + 2 * nfull + (nc if final else 0) + (1 if final else 0)) * B * L * D
@@ -1189,7 +1291,7 @@ class _RouteAggregate(torch.autograd.Function):
 
 
 def route_aggregate(gates, *embs, refs: Optional[Sequence[torch.Tensor]] = None):
-    """gates fp32 [ncell,B,P]; embs: the ncell cell outputs (embs[0] = the RIC input); returns (probs [B,P,ncell], [outs])."""
+    """gates fp32 [B,ncell,P]; embs: the ncell cell outputs (embs[0] = the RIC input); returns (probs [B,P,ncell], [outs])."""
     res = _RouteAggregate.apply(gates, len(embs), *embs, *(refs or ()))
     return res[0], list(res[1:])
 

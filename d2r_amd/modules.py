@@ -368,8 +368,7 @@ class _RoutingLayer(D2RModule):
             else:
                 h = r0.grouped(F.mean_pool(refs), torch.float32, act=ACT_RELU, x_gm=True)
             gb = r2.grouped(h, torch.float32, act=ACT_TANH_RELU)  # [B, 6*P]
-            B = gb.shape[0]
-            G = gb.view(B, self.num_cell, self.num_out_path).transpose(0, 1).contiguous()  # [ncell,B,P] (tiny copy)
+            G = gb.view(gb.shape[0], self.num_cell, self.num_out_path)  # [B,ncell,P]: the layout K8 reads (no copy)
         else:
             if self.first_layer:  # six routers read the same tensor: pool once
                 pooled = F.mean_pool([refs[0]])[0]
@@ -377,7 +376,7 @@ class _RoutingLayer(D2RModule):
             else:
                 pooled = F.mean_pool(refs)  # [6,B,768] in one launch
                 gates = [c.router.gate_from_pooled(pooled[j]) for j, c in enumerate(cells)]
-            G = torch.stack(gates, dim=0)  # fp32 [6,B,P]
+            G = torch.stack(gates, dim=1)  # fp32 [B,ncell,P]
         embs = [c(refs[j], other) for j, c in enumerate(cells)]
         if self.num_out_path == 1:
             probs, outs = F.route_aggregate(G, *embs, refs=refs[1:])
@@ -424,7 +423,78 @@ class _InteractionBase(D2RModule):
         self.path_mapping = Linear(total_paths, path_hid)  # dead parameter (models/InteractionModule.py:19)
         self.bn = nn.BatchNorm1d(args.embed_size)  # dead module (:20)
 
+    def _bundle_spec(self):
+        """{RL name: (weight leaf, bias leaf)} per routing layer for functional.InteractionBundle (None: not prepared)."""
+        def wb(lin):
+            return (lin.weight, lin.bias)
+
+        def fused(owner, key=None):
+            fz = owner._fused_linear(key)
+            if fz is None:
+                raise LookupError
+            return (fz.weight, fz.bias)
+
+        layers = []
+        for layer in [self.dynamic_itr_l0, *self.dynamic_itr_l1, self.dynamic_itr_l2]:
+            s = {"R0": fused(layer, "r0"), "R2": fused(layer, "r2")}
+            names = layer.cell_names
+            if "glac" in names:
+                g = layer.glac
+                s.update(GLAC_Q=wb(g.CrossModalAlignment.query), GLAC_KV=fused(g.CrossModalAlignment), GLAC_LOC=wb(g.fc_sim_tranloc),
+                         GLAC_FC1=wb(g.fc_1), GLAC_TPOOL=wb(g.text_cls_pool.dense), GLAC_IPOOL=wb(g.image_cls_pool.dense),
+                         GLAC_GLO=wb(g.fc_sim_tranglo), GLAC_FC2=wb(g.fc_2), GLAC_SAFW=wb(g.SAF_module.attn_sim_w))
+                bn = g.SAF_module.bn
+                s["bn"] = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            if "imrc" in names:
+                sa = layer.imrc.sa
+                s.update(IMRC_QKV=fused(sa.att_layer), IMRC_FC1=wb(sa.feed_forward_layer.fc1), IMRC_FC2=wb(sa.feed_forward_layer.fc2))
+            if "cmrc" in names:
+                r = layer.cmrc.refine
+                s.update(CMRC_Q=wb(r.CrossModalAlignment.query), CMRC_KV=fused(r.CrossModalAlignment), CMRC_SCALE=wb(r.fc_scale),
+                         CMRC_SHIFT=wb(r.fc_shift), CMRC_FC1=wb(r.fc_1), CMRC_FC2=wb(r.fc_2))
+            if "crcmc" in names:
+                c = layer.crcmc
+                s.update(CRCMC_Q=wb(c.CrossModalAlignment.query), CRCMC_KV=fused(c.CrossModalAlignment), CRCMC_MLP1=wb(c.fc_mlp_1[0]),
+                         CRCMC_MLP2=wb(c.fc_mlp_2[0]), CRCMC_FC1=wb(c.fc_1), CRCMC_FC2=wb(c.fc_2))
+            if "gesc" in names:
+                e = layer.gesc
+                s.update(GESC_TPOOL=wb(e.text_cls_pool.dense), GESC_IPOOL=wb(e.image_cls_pool.dense), GESC_MLP0=wb(e.fc_mlp[0]),
+                         GESC_MLP2=wb(e.fc_mlp[2]))
+            layers.append(s)
+        return layers
+
+    def _bundle(self, own, other):
+        """The cached InteractionBundle when the one-call path applies (bf16 model prepared by ParamStore, token counts the
+        fused attention cores support), else None -> the layers run op by op."""
+        if not COMPOSITE_ROUTING or self.cdtype != torch.bfloat16 or own.dtype != torch.bfloat16 or not own.is_cuda:
+            return None
+        b = getattr(self, "_bundle_cache", None)
+        l0 = self.dynamic_itr_l0
+        probe = l0._fused_linear("r0")
+        if probe is None or getattr(l0.ric.router.mlp[0].weight, "_d2r_grad", None) is None:
+            return None
+        if b is None or b.key[:2] != (probe.weight.data_ptr(), probe.weight._d2r_grad.data_ptr()):
+            try:
+                spec = self._bundle_spec()
+                imrc = getattr(l0, "imrc", None)
+                b = F.InteractionBundle(spec, self.num_cells, l0.ric.router.mlp[0].out_features,
+                                        imrc.sa.h if imrc is not None else 16,
+                                        imrc.sa.feed_forward_layer.fc1.out_features if imrc is not None else E)
+            except (LookupError, F._lib.D2RError):
+                return None
+            self._bundle_cache = b
+        return b if b.supports(own, other) else None
+
     def forward(self, text, image):
+        own, other = (image, text) if self.dynamic_itr_l0.swap else (text, image)
+        bundle = self._bundle(own, other)
+        if bundle is not None:  # K16: the whole module as one C call per direction
+            out, paths = F.interaction(own, other, bundle, self.training)
+            if self.training:  # BatchNorm1d bookkeeping of the GLAC cells (the running statistics are updated in the call)
+                for layer in [self.dynamic_itr_l0, *self.dynamic_itr_l1, self.dynamic_itr_l2]:
+                    if "glac" in layer.cell_names:
+                        layer.glac.SAF_module.bn.num_batches_tracked += 1
+            return [out], F.matmul_nt(paths, paths)
         B = text.shape[0]
         refs, p0 = self.dynamic_itr_l0(text, image)
         plist = [p0.reshape(B, -1)]
@@ -450,6 +520,7 @@ class Reversed_InteractionModule(_InteractionBase):
 # encoders
 # ------------------------------------------------------------------------------------------------------
 COMPOSITE_LAYERS = os.environ.get("D2R_COMPOSITE", "1") != "0"  # whole encoder layers as one C call (bf16 only)
+COMPOSITE_ROUTING = os.environ.get("D2R_COMPOSITE_ROUTING", "1") != "0"  # whole interaction modules as one C call (bf16 only)
 
 
 def _layer_bundle(layer, x):

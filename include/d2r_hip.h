@@ -190,21 +190,22 @@ int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, int D, void*
  *              path normalisation over the ncell cells, final-layer threshold 1e-4/ncell (self.threshold/self.num_cell).
  *   embs[j]  : ncell cell outputs; j=1 (GLAC) and j=5 (GESC) are per-sample [B,D] broadcasts, the rest [B,L,D];
  *              embs[0] is the RIC *input* x0 — relu (models/Cells.py:38) is applied in-kernel.
- *   gates    : fp32 [ncell, B, P] raw router outputs g_j (P = ncell, or 1 for the final layer)
+ *   gates    : fp32 [B, ncell, P] raw router outputs g_j (P = ncell, or 1 for the final layer)
  *   refs     : (final layer only) the ncell layer inputs ref_j [B,L,D] used by the skip term
- *   outs[i]  : P output tensors [B,L,D];  probs: fp32 [B, P, ncell] (normalised for P=ncell, raw for P=1)
+ *   outs[i]  : P output tensors [B,L,D];  probs: fp32 [B, P, ncell] (normalised for P=ncell, raw for P=1), sample b at
+ *              probs + b*ld_probs (ld_probs >= P*ncell: the layers of a module write slices of one [B, total_paths] row)
  * ------------------------------------------------------------------------------------------------ */
 int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs /*ncell*/, const void* const* h_refs /*ncell or NULL*/,
                             const float* gates, int B, int L, int D, int ncell, int P, void* const* h_outs /*P*/,
-                            float* probs, void* stream);
+                            float* probs, int64_t ld_probs, void* stream);
 size_t d2r_route_aggregate_bwd_workspace(int B, int L, int D, int P);
 /* d_embs[j] are OVERWRITTEN (d_embs[0] is w.r.t. the RIC input x0, relu' applied; broadcast ones are [B,D]);
- * d_refs[j] (final layer: gradient of the skip term) OVERWRITTEN, d_gates fp32 [ncell,B,P] OVERWRITTEN.
- * d_probs: fp32 [B,P,ncell] gradient flowing into the returned `probs` (sim_paths -> JS loss) or NULL;
+ * d_refs[j] (final layer: gradient of the skip term) OVERWRITTEN, d_gates fp32 [B,ncell,P] OVERWRITTEN.
+ * d_probs: fp32 [B,P,ncell] (sample stride ld_dprobs) gradient flowing into the returned `probs` (sim_paths -> JS loss) or NULL;
  * h_outs: forward outputs (only outs[0] of the final layer is read; may be NULL for P=ncell). */
 int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, const void* const* h_refs, const float* gates,
                             const void* const* h_douts /*P*/, const void* const* h_outs, const float* d_probs,
-                            int B, int L, int D, int ncell, int P, void* const* h_dembs /*ncell*/,
+                            int64_t ld_dprobs, int B, int L, int D, int ncell, int P, void* const* h_dembs /*ncell*/,
                             void* const* h_drefs /*ncell or NULL*/, float* d_gates, void* workspace,
                             size_t workspace_bytes, void* stream);
 
@@ -328,6 +329,70 @@ typedef struct {
 size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F);
 int d2r_encoder_layer_fwd(const d2r_encoder_layer_desc* d, void* stream);
 int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K16 one whole (Reversed_)InteractionModule per call (16-bit compute dtype): the DR_step routing layers of
+ * models/InteractionModule.py:22-55 (=:75-108) — every router (models/Router.py:22-26), the up to six cells of each layer
+ * (models/Cells.py:30-255 with SelfAttention.py / Refinement.py / XModules.py:277-394), the path normalisation, threshold
+ * gates and aggregation (models/DynamicInteraction.py:37-69, 90-134) and the concatenated path probabilities
+ * (InteractionModule.py:33-53) — forward, or backward, issued from C++ in ONE call: the same kernels as the single-op
+ * entry points above, without one Python autograd node and one foreign call per launch.  In the backward pass every
+ * multi-consumer gradient (the module's two inputs, a layer's aggregated outputs) is accumulated in GEMM epilogues
+ * (beta = 1 / residual operand) instead of separate add launches, and the 768x768-class weight gradients are queued and
+ * launched grouped (d2r_gemm_tn_grouped) at the end of the call.  Parameter gradients ACCUMULATE into the caller's fp32
+ * sinks.  `own` is the branch's own modality (text for InteractionModule, image tokens for the reversed module).
+ * Requires the fused attention cores for the shapes: d2r_xattn_supported(Lq,Lk), (Lq,Lq) and d2r_mha_supported(Lq,Lq,48).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* w;   /* [N,K] weight in the compute dtype (router linears: fp32 masters) */
+  const float* b;  /* fp32 [N] */
+  float* gw;       /* fp32 [N,K] gradient sink, accumulated */
+  float* gb;       /* fp32 [N] gradient sink, accumulated */
+} d2r_linear_params;
+/* linears of one routing layer, in this order (same-input projections are ONE fused linear: rows back to back) */
+enum {
+  D2R_RL_R0 = 0,      /* the ncell routers' mlp.0, fused [ncell*hid, 768] fp32 */
+  D2R_RL_R2,          /* the ncell routers' mlp.2, fused [ncell*P, hid] fp32 (one group per cell) */
+  D2R_RL_IMRC_QKV,    /* sa.att_layer.linears.0|1|2  [2304,768] */
+  D2R_RL_IMRC_FC1, D2R_RL_IMRC_FC2,
+  D2R_RL_GLAC_Q, D2R_RL_GLAC_KV /* key|value [1536,768] */, D2R_RL_GLAC_LOC /* fc_sim_tranloc */, D2R_RL_GLAC_FC1,
+  D2R_RL_GLAC_TPOOL /* text_cls_pool.dense (applied to OWN tokens) */, D2R_RL_GLAC_IPOOL /* image_cls_pool.dense (OTHER) */,
+  D2R_RL_GLAC_GLO /* fc_sim_tranglo */, D2R_RL_GLAC_FC2, D2R_RL_GLAC_SAFW /* SAF_module.attn_sim_w [1,768] */,
+  D2R_RL_CMRC_Q, D2R_RL_CMRC_KV, D2R_RL_CMRC_SCALE, D2R_RL_CMRC_SHIFT, D2R_RL_CMRC_FC1, D2R_RL_CMRC_FC2,
+  D2R_RL_CRCMC_Q, D2R_RL_CRCMC_KV, D2R_RL_CRCMC_MLP1, D2R_RL_CRCMC_MLP2, D2R_RL_CRCMC_FC1, D2R_RL_CRCMC_FC2,
+  D2R_RL_GESC_TPOOL, D2R_RL_GESC_IPOOL, D2R_RL_GESC_MLP0, D2R_RL_GESC_MLP2,
+  D2R_RL_NLIN
+};
+typedef struct {
+  d2r_linear_params lin[D2R_RL_NLIN];   /* entries of absent cells (declared subset) are ignored */
+  const float *bn_weight, *bn_bias;     /* GLAC SAF BatchNorm1d(1) */
+  float *bn_running_mean, *bn_running_var;
+  float *g_bn_weight, *g_bn_bias;       /* fp32 [1] sinks, accumulated */
+} d2r_routing_layer_params;
+typedef struct {
+  int dtype;                 /* D2R_BF16 */
+  int B, Lq, Lk;             /* batch, own tokens, other tokens (hidden size is 768: models/Cells.py:140-143) */
+  int ncell, nlayer;         /* cells per layer (2..6), routing layers = DR_step (>= 2): layer 0, middle layers, final layer */
+  int hid_router, heads_imrc, hid_imrc;
+  int train;                 /* BatchNorm: batch statistics + running-stat update (1) or running statistics (0) */
+  const d2r_routing_layer_params* layers;  /* HOST array [nlayer] */
+  const void* own;           /* [B,Lq,768] */
+  const void* other;         /* [B,Lk,768] */
+  void* out;                 /* [B,Lq,768]  fwd: written; bwd: read (final-layer aggregation backward) */
+  float* paths;              /* fp32 [B, ncell*ncell*(nlayer-1) + ncell]  fwd: written */
+  void* arena; size_t arena_bytes;        /* saved activations: fwd writes, bwd reads; >= d2r_interaction_arena_bytes() */
+  void* splitk_ws; size_t splitk_bytes;   /* split-K scratch of small-M / weight-gradient GEMMs (may be NULL) */
+  /* backward only */
+  const void* d_out;         /* [B,Lq,768] or NULL (= zero) */
+  const float* d_paths;      /* fp32 [B, total_paths] or NULL */
+  void* d_own; void* d_other;             /* [B,Lq,768], [B,Lk,768]  OVERWRITTEN */
+  void* scratch; size_t scratch_bytes;    /* >= d2r_interaction_bwd_scratch() */
+} d2r_interaction_desc;
+int d2r_interaction_supported(int dtype, int Lq, int Lk, int ncell, int heads_imrc);
+size_t d2r_interaction_arena_bytes(int B, int Lq, int Lk, int ncell, int nlayer, int hid_router, int hid_imrc);
+size_t d2r_interaction_bwd_scratch(int B, int Lq, int Lk, int ncell, int nlayer, int hid_router, int hid_imrc);
+int d2r_interaction_fwd(const d2r_interaction_desc* d, void* stream);
+int d2r_interaction_bwd(const d2r_interaction_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K12 embeddings (models/modeling_unimo.py:87-118, 272-331)

@@ -65,11 +65,14 @@ w = results[True][1].to(dev)
 other = w.clone()
 dist.broadcast(other, src=0)
 same_ranks = bool(torch.equal(other, w))
-diff = (results[False][1] != results[True][1]).nonzero().flatten()[:4096]
-bad = sorted({n for n, o, k in entries if ((diff >= o) & (diff < o + k)).any()})
+ne = results[False][1] != results[True][1]
+csum = torch.cat([torch.zeros(1, dtype=torch.int64), ne.to(torch.int64).cumsum(0)])  # differing elements before each offset
+count = lambda a, b: int(csum[b] - csum[a])
+bad = [(n, count(o, o + k)) for n, o, k in entries if count(o, o + k)]
 torch.save({"losses": results[True][0], "losses_plain": results[False][0], "same_modes": same_modes, "same_ranks": same_ranks,
-            "n_diff": int(diff.numel()), "bad": bad[:40], "n_bad": len(bad), "bounds": bounds,
-            "bad_buckets": sorted({i for i, (a, b) in enumerate(bounds) if ((diff >= a) & (diff < b)).any()}),
+            "n_diff": int(ne.sum()), "bad": bad[:40], "n_bad": len(bad), "bounds": bounds,
+            "bad_buckets": [(i, count(a, b)) for i, (a, b) in enumerate(bounds) if count(a, b)],
+            "max_abs_diff": float((results[False][1] - results[True][1]).abs().max()),
             "finite": bool(torch.isfinite(results[True][1]).all())}, os.path.join(out_dir, f"rank{rank}.pt"))
 dist.barrier()
 dist.destroy_process_group()

@@ -166,7 +166,8 @@ def test_cross_modal_attention_core_at_the_real_temperature(gpu, dtype, lq, lk):
     """softmax(100 q k^T / sqrt(768)) v on unit-variance tokens projected by default-init Linears (element std 0.58: the
     logits have a standard deviation of ~33, the softmax is near one-hot — the regime the reference runs in, SURVEY.md
     section 7), forward and backward against fp64 on identical (dtype-rounded) inputs.
-    Tolerance: 2e-5 (fp32) / 2.5e-2 (bf16: P and dS are rounded to bf16 MFMA operands) of the output / gradient scale."""
+    Tolerance: 1e-4 (fp32: logits of magnitude ~100 carry ~1e-5 of absolute fp32 rounding, i.e. ~1e-5 relative on every
+    probability, summed over the keys) / 2.5e-2 (bf16: P and dS are rounded to bf16 MFMA operands) of the output / gradient scale."""
     from d2r_amd import functional as F
     B, E = 4, 768
     scale = 100.0 / math.sqrt(E)
@@ -182,8 +183,8 @@ def test_cross_modal_attention_core_at_the_real_temperature(gpu, dtype, lq, lk):
     p = torch.softmax(scale * qr @ kr.transpose(1, 2), -1)
     orf = p @ vr
     (orf * w.double()).sum().backward()
-    assert float(p.max(-1).values.median()) > 0.9, "this test is meant to run in the near-one-hot regime"
-    tol = 2e-5 if dtype == torch.float32 else 2.5e-2
+    assert float(p.detach().max(-1).values.median()) > 0.9, "this test is meant to run in the near-one-hot regime"
+    tol = 1e-4 if dtype == torch.float32 else 2.5e-2
     for name, got, ref in (("o", o, orf), ("dq", qg.grad, qr.grad), ("dk", kg.grad, kr.grad), ("dv", vg.grad, vr.grad)):
         err = float((got.detach().double().cpu() - ref.detach()).abs().max())
         s = float(ref.detach().abs().max())

@@ -213,7 +213,7 @@ def _agg_ref(nc, gates, *tensors):
     B, L, D = x0.shape
     P = gates.shape[2]
     embs = [torch.relu(x0)] + [e[:, None].expand(B, L, D) if j in (1, 5) else e for j, e in enumerate(embs_in) if j > 0]
-    G = gates.permute(1, 2, 0)  # [B,P,nc]
+    G = gates.transpose(1, 2)  # [B,P,nc]
     thr, thr_f = float(torch.tensor(1e-4, dtype=torch.float32)), float(torch.tensor(1e-4 / nc, dtype=torch.float32))
     if P == 1:
         rr = [x0] + refs
@@ -238,10 +238,10 @@ def test_route_aggregate(gpu, dtype, nc, final, regime):
     B, L, D = 4, 19, 768
     P = 1 if final else nc
     g = torch.Generator().manual_seed(5)
-    gates = torch.rand(nc, B, P, generator=g)
+    gates = torch.rand(B, nc, P, generator=g)
     if regime == "mixed":
-        gates = gates * (torch.rand(nc, B, P, generator=g) > 0.5)
-        gates[:, 0, :] = 0.0  # one sample with every path closed -> skip connection
+        gates = gates * (torch.rand(B, nc, P, generator=g) > 0.5)
+        gates[0] = 0.0  # one sample with every path closed -> skip connection
     elif regime == "closed":
         gates.zero_()
     gates = keep32(gates.float())
@@ -431,6 +431,70 @@ def test_encoder_layer_one_call_matches_op_by_op(gpu, kind):
     for n, p, o, k, _ in store.entries:
         r = float((g1[o:o + k] - g0[o:o + k]).norm() / (g0[o:o + k].norm() + 1e-3 * g0.norm()))  # floor: a key bias has a mathematically zero gradient
         assert r < 2e-2, (n, r)
+
+
+@pytest.mark.parametrize("cfg", [("text", 6, 3, 3, 24, 10, True), ("image", 6, 4, 2, 10, 24, True), ("text", 4, 3, 2, 16, 7, True),
+                                 ("image", 6, 3, 2, 12, 9, False), ("text", 6, 2, 2, 9, 5, True)],
+                         ids=lambda c: f"{c[0]}-nc{c[1]}-dr{c[2]}-{'train' if c[6] else 'eval'}")
+def test_interaction_module_one_call_matches_op_by_op(gpu, cfg):
+    """d2r_interaction_fwd/bwd (K16: one C call per module and direction) against the op-by-op path built from the same
+    kernels, on identical weights and inputs with about half of the paths pruned: the forward (aggregated embedding, path
+    similarities, BatchNorm running statistics) is bit-identical; the backward differs only in WHERE multi-consumer
+    gradients are summed (GEMM epilogues instead of separate bf16 adds) — input gradients and every parameter gradient are
+    compared per tensor."""
+    from d2r_amd import modules as M
+    from d2r_amd.config import default_args
+    from d2r_amd.params import ParamStore
+    branch, nc, dr, B, Lq, Lk, train = cfg
+    torch.manual_seed(11)
+    cls = M.InteractionModule if branch == "text" else M.Reversed_InteractionModule
+    mod = cls(default_args(DR_step=dr), num_layer_routing=dr, num_cells=nc, path_hid=128).to(gpu)
+    mod.set_compute_dtype(torch.bfloat16).train(train)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if n.endswith("router.mlp.2.bias"):
+                p.normal_()
+    store = ParamStore(mod, torch.bfloat16)
+    own0 = torch.randn(B, Lq, 768, device=gpu).bfloat16()
+    other0 = torch.randn(B, Lk, 768, device=gpu).bfloat16()
+    r_emb = torch.randn(B, Lq, 768, device=gpu)
+    r_sim = torch.randn(B, B, device=gpu)
+    buffers0 = {k: v.clone() for k, v in mod.named_buffers()}
+    res = {}
+    for composite in (False, True):
+        M.COMPOSITE_ROUTING = composite
+        try:
+            with torch.no_grad():
+                for k, v in mod.named_buffers():
+                    v.copy_(buffers0[k])
+            store.zero_grad()
+            own, other = own0.clone().requires_grad_(True), other0.clone().requires_grad_(True)
+            text, image = (own, other) if branch == "text" else (other, own)
+            (emb,), sim = mod(text, image)
+            assert ("_InteractionBackward" in repr(emb.grad_fn)) == composite, emb.grad_fn
+            ((emb.float() * r_emb).sum() + (sim * r_sim).sum()).backward()
+            torch.cuda.synchronize()
+            res[composite] = (emb.detach().clone(), sim.detach().clone(), own.grad.clone(), other.grad.clone(), store.flat_g.clone(),
+                              {k: v.clone() for k, v in mod.named_buffers()})
+        finally:
+            M.COMPOSITE_ROUTING = True
+    (e0, s0, do0, dt0, g0, b0), (e1, s1, do1, dt1, g1, b1) = res[False], res[True]
+    assert torch.equal(e0, e1), f"forward differs: max {float((e0.float() - e1.float()).abs().max()):.3e}"
+    assert torch.equal(s0, s1), "path similarities differ"
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), f"buffer {k} differs"
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+    assert rel(do1, do0) < 2e-2, ("d own", rel(do1, do0))
+    assert rel(dt1, dt0) < 2e-2, ("d other", rel(dt1, dt0))
+    gn = float(g0.norm())
+    worst = ("", 0.0)
+    for n, p, o, k, _ in store.entries:
+        a, b = g1[o:o + k], g0[o:o + k]
+        r = float((a - b).norm() / (b.norm() + 1e-3 * gn / len(store.entries) ** 0.5))
+        if r > worst[1]:
+            worst = (n, r)
+        assert r < 3e-2, (n, r, float(a.norm()), float(b.norm()))
+    print(f"[{cfg}] one-call vs op-by-op: d_own {rel(do1, do0):.2e} d_other {rel(dt1, dt0):.2e} worst parameter gradient {worst[0]} {worst[1]:.2e}")
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -203,5 +203,7 @@ def test_data_parallel_two_ranks_on_one_gpu(gpu, tmp_path):
     for rank in (0, 1):
         res = torch.load(os.path.join(str(tmp_path), f"rank{rank}.pt"))
         assert res["finite"] and all(l == l for l in res["losses"]), res
-        assert res["same_modes"], ("overlapped all-reduce changed the result", {k: res[k] for k in res if k not in ("finite",)})
+        assert res["same_modes"], ("overlapped all-reduce changed the result: %d differing elements in %d tensors, buckets %s of %d, "
+                                   "max |diff| %.3e, first tensors %s" % (res["n_diff"], res["n_bad"], res["bad_buckets"], len(res["bounds"]),
+                                                                          res["max_abs_diff"], res["bad"][:6]))
         assert res["same_ranks"], "replicas diverged"
