@@ -411,11 +411,13 @@ static int g_nbuf = env_int("D2R_GEMM_NBUF", 1);
 static int g_vepi = env_int("D2R_GEMM_VEPI", 1);
 static int g_tile = env_int("D2R_GEMM_TILE", -1);
 static int g_xcd = env_int("D2R_GEMM_XCD", 1);
+static int g_wgrad_glds = env_int("D2R_WGRAD_GLDS", 1);
 extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
   g_nbuf = nbuf & 0xff;
   g_xcd = (nbuf >> 8) & 1 ? 0 : 1;  // bit 8 of the first argument disables the XCD-aware tile order (A/B runs)
   g_vepi = vepi;
-  g_tile = tile;
+  if (tile == 100 || tile == 101) g_wgrad_glds = tile - 100;  // A/B switch of the grouped weight-gradient kernel (0: 64x64 generic)
+  else g_tile = tile;
 }
 
 template <typename T, int LAYOUT, int BM, int BN, int WM_, int WN_>
@@ -437,6 +439,9 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     if (g_tile == 4) bn = 128;
     else if (g_tile == 5) bn = 64;
     else if (g_tile == 6) bn = 129;  // 128x128 on eight waves (A/B runs)
+    else if (g_tile == 7) bn = 1128;  // software-pipelined K-loop: 128x128 on four waves
+    else if (g_tile == 8) bn = 1064;  //                             128x64
+    else if (g_tile == 9) bn = 1129;  //                             128x128 on eight waves
     // measured (profiles/gemm_ab_r01_e.log): the 128x64 LDS-DMA kernel beats the register-staged 64x64 tiles on every
     // NT / NN shape of the workload (351 vs 275, 548 vs 422, 616 vs 343 TFLOP/s ...); weight-gradient GEMMs that carry
     // the bias-gradient side product stay on the generic kernel
@@ -576,6 +581,8 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
 // fp32 slabs and a reduce launch to fill the chip (175 TFLOP/s); sixteen of them give 2304 workgroups that each
 // run the whole reduction (356 TFLOP/s, profiles/gemm_grouped_r01.log).  Nothing in the backward pass reads a weight
 // gradient, so the caller may defer these products and launch them together.
+int d2r_gemm_glds_wgrad_try(const GemmArgs& a, const GemmGroup& grp, int n, hipStream_t st);  // gemm_glds.hip
+
 template <typename T>
 static int launch_grouped_tn(const GemmArgs& base, const void* const* A, const void* const* B, float* const* C,
                              float* const* dbias, int count, hipStream_t st) {
@@ -588,6 +595,14 @@ static int launch_grouped_tn(const GemmArgs& base, const void* const* A, const v
     }
     GemmArgs a = base;
     a.dbias = dbias ? reinterpret_cast<float*>(1) : nullptr;  // per-problem pointer substituted in the kernel; non-null enables the path
+    if (sizeof(T) == 2 && g_wgrad_glds) {  // 128x128 LDS-DMA tiles (half the L2 bytes per flop of the 64x64 tiles below)
+      GemmArgs b = a;
+      b.xcd = g_xcd;
+      if (d2r_gemm_glds_wgrad_try(b, grp, n, st)) {
+        if (int rc = d2r_check_launch("d2r_gemm_tn_grouped(glds)")) return rc;
+        continue;
+      }
+    }
     dim3 grid(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 64), n);
     // Operand strips fetched past L2 per round of resident workgroups (profiles/gemm_grouped_pmc_r01.txt): with whole
     // problems per XCD a round covers (resident / grid.x) row strips + grid.x column strips - right for 12 tile columns

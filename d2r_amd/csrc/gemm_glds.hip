@@ -17,8 +17,13 @@
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
 // NWN waves along N (2: four waves, 4: eight waves per workgroup); a wave owns 64 rows x BN/NWN columns.
-template <int LAYOUT, int BN, int NWN = 2>
-__global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g) {
+// PIPE = 1: software-pipelined K-step (all fragment reads of the step issued up front behind counted lgkmcnt waits, the
+// closing barrier in the MIDDLE of the MFMA block, the DMA of tile t+2 issued right behind it: two tiles in flight).
+// WGRAD (TN only): grouped weight-gradient mode — blockIdx.z selects one of up to 16 same-shape problems (operand pointers in
+// `grp`), the output is fp32 and ACCUMULATED (C += A^T B, 16-byte loads / stores), and the workgroups of the first tile column
+// also produce the bias gradient dbias[m] += sum_k A[k,m] (their A fragments times an all-ones fragment).
+template <int LAYOUT, int BN, int NWN = 2, int PIPE = 0, bool WGRAD = false>
+__global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, GemmGroup grp) {
   constexpr int BM = 128, BK = 64, NW = 2 * NWN;
   constexpr bool A_KCONT = (LAYOUT != D2R_GEMM_TN);
   constexpr bool B_KCONT = (LAYOUT == D2R_GEMM_NT);
@@ -34,11 +39,23 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
-  int tile_m, tile_n;
-  xcd_tile(g.xcd, tile_m, tile_n);
+  int tile_m, tile_n, z = 0;
+  if constexpr (WGRAD) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
+  else xcd_tile(g.xcd, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+  if constexpr (WGRAD) {
+    static_assert(LAYOUT == D2R_GEMM_TN, "the weight-gradient mode is a TN product");
+    A = reinterpret_cast<const bf16_t*>(grp.A[z]);
+    B = reinterpret_cast<const bf16_t*>(grp.B[z]);
+    g.C = grp.C[z];
+    g.dbias = grp.dbias[z];
+  }
+  const bool do_bias = WGRAD && g.dbias != nullptr && tile_n == 0 && (wave % NWN) == 0;
+  f32x4 acc_b[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) acc_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // per-lane source offsets (elements) of this wave's DMA instructions, without the k0 term
   int64_t offA[IA], offB[IB];
@@ -73,18 +90,30 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g) {
     }
   }
 
+  // weight-gradient mode: the reduction length (token rows) need not be a multiple of 64 — the k-rows of the last tile past
+  // the end are CLAMPED to the last valid row here and the A rows are zeroed in LDS before they are read (see the K-loop)
+  const int nk_w = (g.K + BK - 1) / BK, rem_w = g.K - (nk_w - 1) * BK;
   auto issue = [&](int t, int buf) {
     const int k0 = t * BK;
     unsigned char* base = smem + buf * BUF;
+    int64_t adjA = 0, adjB = 0;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      const bf16_t* src = A + offA[i] + (A_KCONT ? (int64_t)k0 : (int64_t)k0 * g.lda);
+      if constexpr (WGRAD) {
+        const int krow = (wave + NW * i) * 4 + (lane >> 4);
+        adjA = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.lda : 0;
+      }
+      const bf16_t* src = A + offA[i] + adjA + (A_KCONT ? (int64_t)k0 : (int64_t)k0 * g.lda);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      const bf16_t* src = B + offB[i] + (B_KCONT ? (int64_t)k0 : (int64_t)k0 * g.ldb);
+      if constexpr (WGRAD) {
+        const int krow = (wave + NW * i) * 4 + (lane >> 4);
+        adjB = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.ldb : 0;
+      }
+      const bf16_t* src = B + offB[i] + adjB + (B_KCONT ? (int64_t)k0 : (int64_t)k0 * g.ldb);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
     }
@@ -97,7 +126,92 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int nk = g.K / BK;
+  const int nk = WGRAD ? nk_w : g.K / BK;
+  // fragments of K-substep kk (32 k) from the staged tile at bA / bB
+  auto read_frags = [&](const unsigned char* bA, const unsigned char* bB, int kk, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (A_KCONT) {
+        const int row = wm0 + i * 16 + fr, c = kk * 4 + fq;
+        af[i] = *reinterpret_cast<const bf16x8*>(bA + row * 128 + ((c ^ (row & 7)) << 4));
+      } else {
+        const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
+        const int c = col >> 3, h = (col & 7) >> 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8));
+        af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (B_KCONT) {
+        const int row = wn0 + j * 16 + fr, c = kk * 4 + fq;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(bB + row * 128 + ((c ^ (row & 7)) << 4));
+      } else {
+        constexpr int ROWB = BN * 2, PM = BN / 8 - 1;
+        const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
+        const int c = col >> 3, h = (col & 7) >> 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8));
+        bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  };
+  if constexpr (PIPE == 1) {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int t = 0; t < nk; ++t) {
+      const int cur = t & 1;
+      // tile t was issued at least one whole K-step ago; the newest tile (t+1) may stay in flight
+      if (t + 1 < nk) {
+        if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (IA + IB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_barrier" ::: "memory");  // tile t is visible to every wave
+      const unsigned char* bA = smem + cur * BUF;
+      const unsigned char* bB = bA + A_BYTES;
+      if constexpr (WGRAD) {
+        if (t == nk - 1 && rem_w < BK) {  // rows past the reduction length: zero A (B holds clamped, finite rows) -> no contribution
+          unsigned char* z0 = smem + cur * BUF + rem_w * (BM * 2);
+          const int zbytes = (BK - rem_w) * (BM * 2);
+          for (int off = tid * 16; off < zbytes; off += NW * 64 * 16) *reinterpret_cast<uint4*>(z0 + off) = uint4{0u, 0u, 0u, 0u};
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+      }
+      bf16x8 af0[TM], bf0[TN], af1[TM], bf1[TN];
+      read_frags(bA, bB, 0, af0, bf0);
+      read_frags(bA, bB, 1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);  // every LDS read of the step is issued before its first MFMA (counted lgkmcnt waits follow)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);
+      if constexpr (WGRAD) {
+        if (do_bias) {
+          const bf16_t one = (bf16_t)1.f;
+          const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            acc_b[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af0[i], acc_b[i], 0, 0, 0);
+            acc_b[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af1[i], acc_b[i], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // every wave has its fragments in registers: buffer `cur` is free -> refill it with tile t+2 while the second half runs
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (t + 2 < nk) issue(t + 2, cur);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[i], acc[i][j], 0, 0, 0);
+    }
+  } else {
   issue(0, 0);
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
@@ -153,6 +267,34 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading buffer `cur` before it is refilled at t+1
   }
 
+  }
+
+  if constexpr (WGRAD) {
+    // acc[i][j][r] = C[wm0 + i*16 + fr][wn0 + j*16 + fq*4 + r]: one 16-byte fp32 pack per lane and tile
+    float* Cg = reinterpret_cast<float*>(g.C);
+    const bool vec = (g.ldc & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = m0 + wm0 + i * 16 + fr;
+      if (row >= g.M) continue;
+      if (do_bias && fq == 0) g.dbias[row] += acc_b[i][0];  // every column of acc_b holds sum_k A[k,row]; this lane is the row's only writer
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 16 + fq * 4;
+        float* p = Cg + (int64_t)row * g.ldc + col;
+        if (vec && col + 4 <= g.N) {
+          f32x4 old = *reinterpret_cast<const f32x4*>(p);
+          *reinterpret_cast<f32x4*>(p) = f32x4{g.beta * old[0] + acc[i][j][0], g.beta * old[1] + acc[i][j][1],
+                                               g.beta * old[2] + acc[i][j][2], g.beta * old[3] + acc[i][j][3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col + r < g.N) p[r] = g.beta * p[r] + acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue (same semantics as the generic kernel) ------------------------------------------------
   if (g.c_dtype == D2R_BF16 && g.vecC) {
     constexpr int LDE = WN + 8;
@@ -241,24 +383,30 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g) {
 
 template <int LAYOUT>
 static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
+  static const GemmGroup no_group = {};
+  const bool pipe = bn >= 1000;  // 1064 / 1128 / 1129: the software-pipelined K-loop
+  if (pipe) bn -= 1000;
   if (bn == 129) {  // 128 x 128 tile on EIGHT waves (2 x 4): per wave as the 128x64 kernel, a third less L2 traffic per flop
     dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
-    hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128, 4>), grid, dim3(512), 0, st, a);
+    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128, 4, 1>), grid, dim3(512), 0, st, a, no_group);
+    else hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128, 4>), grid, dim3(512), 0, st, a, no_group);
     return;
   }
   if (bn == 128) {
     dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
-    hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128>), grid, dim3(256), 0, st, a);
+    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128, 2, 1>), grid, dim3(256), 0, st, a, no_group);
+    else hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128>), grid, dim3(256), 0, st, a, no_group);
   } else {
     dim3 grid(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 128));
-    hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 64>), grid, dim3(256), 0, st, a);
+    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 64, 2, 1>), grid, dim3(256), 0, st, a, no_group);
+    else hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 64>), grid, dim3(256), 0, st, a, no_group);
   }
 }
 
 // Returns 1 when the launch was taken by the LDS-DMA kernel, 0 when the shape is not eligible.
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st) {
   if (batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
-  if (bn == 129 && a.N < 128) return 0;
+  if ((bn % 1000) == 129 && a.N < 128) return 0;
   if (!a.vecA || !a.vecB) return 0;
   if (a.G && !(a.vecC && a.c_dtype == D2R_BF16)) return 0;  // the activation-gradient epilogue is in the vectorised path only
   const bool a_strided = layout == D2R_GEMM_TN, b_strided = layout != D2R_GEMM_NT;
@@ -269,5 +417,16 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
     case D2R_GEMM_TN: launch_glds<D2R_GEMM_TN>(a, bn, st); break;
     default: return 0;
   }
+  return 1;
+}
+
+
+// Grouped weight gradients on the LDS-DMA kernel: `n` (<= 16) same-shape TN problems, 128 x 128 tiles, software-pipelined
+// K-loop over the token rows, fp32 accumulate epilogue, bias gradients.  Returns 1 when taken, 0 when the shape is not
+// eligible (then the generic 64 x 64 kernel runs).
+int d2r_gemm_glds_wgrad_try(const GemmArgs& a, const GemmGroup& grp, int n, hipStream_t st) {
+  if (a.K < 128 || a.M < 128 || a.N < 128 || !a.vecA || !a.vecB || a.M % 8 != 0 || a.N % 8 != 0) return 0;
+  dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), n);
+  hipLaunchKernelGGL((gemm_glds_kernel<D2R_GEMM_TN, 128, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
   return 1;
 }

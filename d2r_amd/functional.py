@@ -869,9 +869,10 @@ class InteractionBundle:
         key = []
         for l, spec in enumerate(layers):
             t = self.table[l]
-            for name, (w, b) in spec.items():
+            for name, leaves in spec.items():
                 if name == "bn":
                     continue
+                w, b = leaves
                 for leaf in (w, b):
                     if getattr(leaf, "_d2r_grad", None) is None:
                         raise _lib.D2RError("InteractionBundle needs a model prepared by ParamStore")

@@ -490,6 +490,11 @@ def test_interaction_module_one_call_matches_op_by_op(gpu, cfg):
     worst = ("", 0.0)
     for n, p, o, k, _ in store.entries:
         a, b = g1[o:o + k], g0[o:o + k]
+        if n.endswith(("key.bias", "linears.1.bias", "crcmc.fc_2.bias")):  # (crcmc.fc_2 makes the keys of softmax(Q K^T), Cells.py:244)
+            # a key bias shifts every logit of a softmax row equally: its gradient is mathematically zero, what both paths
+            # hold is rounding noise of different summation orders
+            assert float(a.norm()) < 1e-2 * gn and float(b.norm()) < 1e-2 * gn, (n, float(a.norm()), float(b.norm()), gn)
+            continue
         r = float((a - b).norm() / (b.norm() + 1e-3 * gn / len(store.entries) ** 0.5))
         if r > worst[1]:
             worst = (n, r)
@@ -567,11 +572,13 @@ def test_bert_layer_with_dropout_backward_is_consistent(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(19, 300, 136, 72), (3, 200, 72, 1536)], ids=["19x136x72", "3x72x1536"])
+@pytest.mark.parametrize("shape", [(19, 300, 136, 72), (3, 200, 72, 1536), (3, 1576, 256, 384), (2, 200, 136, 264), (17, 192, 128, 128)],
+                         ids=["19x136x72", "3x72x1536", "3x256x384-T1576", "2x136x264-T200", "17x128x128"])
 def test_grouped_weight_gradient_gemm(gpu, dtype, shape):
     """d2r_gemm_tn_grouped: same-shape dW = dY^T X problems (19: two launches, 16 + 3; 24 tile columns: the launch order
     without the whole-problem-per-XCD remap) with bias-gradient side product and accumulation into pre-filled sinks,
-    against torch."""
+    against torch.  Outputs >= 128 x 128 in bf16 run on the 128x128 LDS-DMA weight-gradient kernel: ragged output edges
+    (136 x 264), token counts that are not a multiple of the 64-row K tile (1576 = 8 x 197, 200), 17 problems (16 + 1)."""
     from d2r_amd import _lib
     from d2r_amd.functional import _parr, _stream
     n, T, N, K = shape
