@@ -20,6 +20,7 @@
 // recompute P and dS in the other orientation (rows = queries), dV^T += dO^T P, dK^T += Q^T dS.  Fixed summation
 // order, no atomics.
 #include <math.h>
+#include <stdlib.h>
 
 #include "gemm_args.h"
 
@@ -746,6 +747,10 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(XattnArgs a) {
 
 }  // namespace
 
+int d2r_xattn2_fwd_try(const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb, const void* v, int64_t ldv,
+                       int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual, int64_t ldr, int64_t srb, const float* mask,
+                       float* lse, int B, int Lq, int Lk, float scale, hipStream_t st);  // xattn2.hip
+
 extern "C" int d2r_xattn_supported(int dtype, int Lq, int Lk, int D) {
   return dtype == D2R_BF16 && D == 768 && Lq >= 1 && Lk >= 1 && Lk <= 256;
 }
@@ -759,6 +764,10 @@ extern "C" int d2r_xattn_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb,
   D2R_REQUIRE(aligned_slice(q, ldq, sqb, 768) && aligned_slice(k, ldk, skb, 768) && aligned_slice(v, ldv, svb, 768) &&
                   aligned_slice(o, ldo, sob, 768) && (!residual || aligned_slice(residual, ldr, srb, 768)),
               "d2r_xattn_fwd: pointers must be 16-byte aligned, strides multiples of 8 elements");
+  static const int use_v2 = getenv("D2R_XATTN2") ? atoi(getenv("D2R_XATTN2")) : 1;
+  if (use_v2 && d2r_xattn2_fwd_try(q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, Lq, Lk, scale,
+                                   (hipStream_t)stream))
+    return d2r_check_launch("d2r_xattn_fwd(v2)");
   XattnArgs a = {};
   a.q = (const bf16_t*)q, a.k = (const bf16_t*)k, a.v = (const bf16_t*)v, a.res = (const bf16_t*)residual, a.o = (bf16_t*)o;
   a.mask = mask, a.lse = lse;

@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
     bf16_t* Pg = reinterpret_cast<bf16_t*>(g.P);
     const bf16_t* Rg = reinterpret_cast<const bf16_t*>(g.R);
     const bf16_t* Gg = reinterpret_cast<const bf16_t*>(g.G);
-#pragma unroll
-    for (int it = 0; it < WM * CPR / 64; ++it) {
+#pragma unroll 1
+    for (int it = 0; it < WM * CPR / 64; ++it) {  // (rolled on purpose: one copy of the epilogue arithmetic)
       const int e = it * 64 + lane;
       const int rl = e / CPR, ch = e % CPR;
       const int row = m0 + wm0 + rl, col = n0 + wn0 + ch * 8;
@@ -323,33 +323,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
       const Pack<bf16_t, 8> pv = ld_pack<bf16_t, 8>(Cs + rl * LDE + ch * 8);
       const int64_t ci = cz + (int64_t)row * g.ldc + col;
       const int64_t ri = rz + (int64_t)row * g.ldr + col;
-      if (col + 8 <= g.N) {
-        if (Pg) st_pack<bf16_t, 8>(Pg + ci, pv);
-        Pack<bf16_t, 8> rv, cv, ov, gv;
-        if (Rg) rv = ld_pack<bf16_t, 8>(Rg + ri);
-        if (g.beta != 0.f) cv = ld_pack<bf16_t, 8>(Cg + ci);
-        if (Gg) gv = ld_pack<bf16_t, 8>(Gg + ci);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          float v = act_apply(g.act, (float)pv.v[u]);
-          if (Gg) v *= act_grad(g.gact, (float)gv.v[u]);
-          if (Rg) v += (float)rv.v[u];
-          if (g.beta != 0.f) v += g.beta * (float)cv.v[u];
-          ov.v[u] = (bf16_t)v;
-        }
-        st_pack<bf16_t, 8>(Cg + ci, ov);
-      } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {  // (fully unrolled: a runtime bound would index the packs dynamically -> scratch)
-          if (col + u >= g.N) break;
-          if (Pg) Pg[ci + u] = pv.v[u];
-          float v = act_apply(g.act, (float)pv.v[u]);
-          if (Gg) v *= act_grad(g.gact, (float)Gg[ci + u]);
-          if (Rg) v += (float)Rg[ri + u];
-          if (g.beta != 0.f) v += g.beta * (float)Cg[ci + u];
-          Cg[ci + u] = (bf16_t)v;
-        }
-      }
+      epilogue_pack8(g, pv, Cg, Pg, Rg, Gg, ci, ri, g.N - col);
     }
     return;
   }
@@ -367,7 +341,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
         float v = g.alpha * acc[i][j][r] + bv;
         const int64_t ci = cz + (int64_t)row * g.ldc + col;
         if (g.P) store_c(g.P, g.c_dtype, ci, v);
-        v = act_apply(g.act, v);
+        v = act_apply_cold(g.act, v);
         if (g.R) v += load_c(g.R, g.c_dtype, rz + (int64_t)row * g.ldr + col);
         if (g.beta != 0.f) v += g.beta * load_c(g.C, g.c_dtype, ci);
         store_c(g.C, g.c_dtype, ci, v);
@@ -394,8 +368,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
     const int64_t ci = (int64_t)m * g.ldc + n;
     float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f);
     if (g.P) store_c(g.P, g.c_dtype, ci, v);
-    v = act_apply(g.act, v);
-    if (g.G) v *= act_grad(g.gact, load_c(g.G, g.c_dtype, ci));
+    v = act_apply_cold(g.act, v);
+    if (g.G) v *= act_grad_cold(g.gact, load_c(g.G, g.c_dtype, ci));
     if (g.R) v += load_c(g.R, g.c_dtype, (int64_t)m * g.ldr + n);
     if (g.beta != 0.f) v += g.beta * load_c(g.C, g.c_dtype, ci);
     store_c(g.C, g.c_dtype, ci, v);
@@ -549,6 +523,8 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh; a.sBiasB = d->s_bias_b;
   a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype;
   a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd;
+  static const int g_dbg = env_int("D2R_GEMM_DBG", 0);
+  a.dbg = g_dbg;
   D2R_REQUIRE(!d->dbias || (d->layout == D2R_GEMM_TN && d->nb * d->nh == 1), "d2r_gemm: dbias needs the TN layout and batch 1");
   a.dbias = d->dbias;
   D2R_REQUIRE(!d->grad_ref || d->nb * d->nh == 1, "d2r_gemm: grad_ref needs batch 1");
@@ -625,7 +601,7 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
   const int64_t es = (int64_t)d2r_esize(dtype);
   GemmArgs a = {};
   a.M = M, a.N = N, a.K = K, a.nh = 1, a.splits = 1, a.lda = lda, a.ldb = ldb, a.ldc = ldc;
-  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.xcd = g_xcd, a.grouped = 1;
+  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.xcd = g_xcd, a.grouped = 1, a.dbg = 0;
   a.vecA = (lda * es) % 16 == 0, a.vecB = (ldb * es) % 16 == 0, a.vecC = 0;
   for (int i = 0; i < count; ++i) {
     D2R_REQUIRE(h_A[i] && h_B[i] && h_C[i] && (!h_dbias || h_dbias[i]), "d2r_gemm_tn_grouped: null operand in problem %d", i);

@@ -34,6 +34,7 @@ struct GemmArgs {
   int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh, sBiasB;
   float alpha, beta;
   int act, c_dtype, vecA, vecB, vecC, xcd;
+  int dbg;  // timing experiments (D2R_GEMM_DBG): 1 = no MFMA, 2 = no DMA issue, 3 = no epilogue stores
 };
 
 // Loads VEC consecutive elements [c0, c0+VEC) of a row; zero outside [0, climit) or when !row_ok.
@@ -87,3 +88,144 @@ __device__ __forceinline__ float load_c(const void* C, int c_dtype, int64_t idx)
   return c_dtype == D2R_BF16 ? (float)reinterpret_cast<const bf16_t*>(C)[idx] : reinterpret_cast<const float*>(C)[idx];
 }
 
+
+
+// Hardware-transposed LDS read (ds_read_b64_tr_b16) as inline asm.  Through the builtin, hipcc cannot tell which LDS bytes the
+// read touches and drains EVERY in-flight LDS-DMA (s_waitcnt vmcnt(0)) in front of it — which serialises a DMA pipeline that
+// keeps tiles in flight across the reads.  The asm form is invisible to that pass: the caller orders DMA arrival itself
+// (counted vmcnt + barrier) and must put `lds_reads_done()` between the reads and the first MFMA that consumes them
+// (cdna_hip_programming.md 5.7 form (iii), rule 18).
+__device__ __forceinline__ bf16x4 lds_tr_read(const void* p) {
+  bf16x4 r;
+  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+__device__ __forceinline__ void lds_reads_done() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+
+// ---- compact epilogue arithmetic ---------------------------------------------------------------------------------------
+// The activation of a GEMM epilogue is a RUN-TIME choice (one kernel serves every nn.Linear).  Calling act_apply() per
+// element from fully unrolled loops expands the seven-way switch (with erff / tanhf / expf bodies) at every call site:
+// the 128x64 kernel grew to 30,000 instructions whose instruction-cache misses cost a third of a K = 768 GEMM.  These
+// helpers take the switch ONCE per 8-wide pack; the callers keep the pack loop rolled.
+template <int N>
+__device__ __forceinline__ void act_apply_vec(int act, float (&v)[N]) {
+  switch (act) {
+    case D2R_ACT_RELU:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.f);
+      break;
+    case D2R_ACT_TANH:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = tanhf(v[j]);
+      break;
+    case D2R_ACT_GELU:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+      break;
+    case D2R_ACT_QUICK_GELU:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = v[j] / (1.f + expf(-1.702f * v[j]));
+      break;
+    case D2R_ACT_TANH_RELU:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = fmaxf(tanhf(v[j]), 0.f);
+      break;
+    case D2R_ACT_SIGMOID:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = 1.f / (1.f + expf(-v[j]));
+      break;
+    default: break;
+  }
+}
+// v[j] *= d act / d x evaluated at r[j] (activation output, or pre-activation for gelu / quick_gelu: see act_grad)
+template <int N>
+__device__ __forceinline__ void act_grad_mul_vec(int act, const float (&r)[N], float (&v)[N]) {
+  switch (act) {
+    case D2R_ACT_RELU:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = r[j] > 0.f ? v[j] : 0.f;
+      break;
+    case D2R_ACT_TANH:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] *= 1.f - r[j] * r[j];
+      break;
+    case D2R_ACT_GELU:
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float cdf = 0.5f * (1.f + erff(r[j] * 0.70710678118654752f));
+        v[j] *= cdf + r[j] * 0.3989422804014327f * expf(-0.5f * r[j] * r[j]);
+      }
+      break;
+    case D2R_ACT_QUICK_GELU:
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float sg = 1.f / (1.f + expf(-1.702f * r[j]));
+        v[j] *= sg + 1.702f * r[j] * sg * (1.f - sg);
+      }
+      break;
+    case D2R_ACT_TANH_RELU:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = r[j] > 0.f ? v[j] * (1.f - r[j] * r[j]) : 0.f;
+      break;
+    case D2R_ACT_SIGMOID:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] *= r[j] * (1.f - r[j]);
+      break;
+    default: break;
+  }
+}
+// scalar forms for the rarely taken element-wise paths: ONE out-of-line copy instead of one expansion per call site
+static __device__ __attribute__((noinline)) float act_apply_cold(int act, float x) { return act_apply(act, x); }
+static __device__ __attribute__((noinline)) float act_grad_cold(int act, float r) { return act_grad(act, r); }
+
+// One 8-column pack of the LDS-staged bf16 epilogue, shared by the MFMA GEMM kernels:
+//   out = act(pv) [* act'(G)] [+ R] [+ beta * C_old],  preact <- pv;   `n_ok` = valid columns of the pack (8 = whole pack)
+__device__ __forceinline__ void epilogue_pack8(const GemmArgs& g, const Pack<bf16_t, 8>& pv, bf16_t* Cg, bf16_t* Pg, const bf16_t* Rg,
+                                               const bf16_t* Gg, int64_t ci, int64_t ri, int n_ok) {
+  float v[8], t[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = (float)pv.v[u];
+  if (n_ok >= 8) {
+    if (Pg) st_pack<bf16_t, 8>(Pg + ci, pv);
+    act_apply_vec<8>(g.act, v);
+    if (Gg) {
+      const Pack<bf16_t, 8> gv = ld_pack<bf16_t, 8>(Gg + ci);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = (float)gv.v[u];
+      act_grad_mul_vec<8>(g.gact, t, v);
+    }
+    if (Rg) {
+      const Pack<bf16_t, 8> rv = ld_pack<bf16_t, 8>(Rg + ri);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] += (float)rv.v[u];
+    }
+    if (g.beta != 0.f) {
+      const Pack<bf16_t, 8> cv = ld_pack<bf16_t, 8>(Cg + ci);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] += g.beta * (float)cv.v[u];
+    }
+    Pack<bf16_t, 8> ov;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ov.v[u] = (bf16_t)v[u];
+    st_pack<bf16_t, 8>(Cg + ci, ov);
+    return;
+  }
+  // ragged right edge: element by element (static indices only: a runtime index into the packs would go to scratch)
+  act_apply_vec<8>(g.act, v);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (u < n_ok) {
+      if (Pg) Pg[ci + u] = pv.v[u];
+      float x = v[u];
+      if (Gg) x *= act_grad_cold(g.gact, (float)Gg[ci + u]);
+      if (Rg) x += (float)Rg[ri + u];
+      if (g.beta != 0.f) x += g.beta * (float)Cg[ci + u];
+      Cg[ci + u] = (bf16_t)x;
+    }
+  }
+}

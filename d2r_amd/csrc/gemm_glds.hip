@@ -94,6 +94,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
   // the end are CLAMPED to the last valid row here and the A rows are zeroed in LDS before they are read (see the K-loop)
   const int nk_w = (g.K + BK - 1) / BK, rem_w = g.K - (nk_w - 1) * BK;
   auto issue = [&](int t, int buf) {
+    if (g.dbg == 2) return;
     const int k0 = t * BK;
     unsigned char* base = smem + buf * BUF;
     int64_t adjA = 0, adjB = 0;
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       } else {
         const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
         const int c = col >> 3, h = (col & 7) >> 2;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8));
+        const bf16x4 lo = lds_tr_read(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8);
+        const bf16x4 hi = lds_tr_read(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8);
         af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
         constexpr int ROWB = BN * 2, PM = BN / 8 - 1;
         const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
         const int c = col >> 3, h = (col & 7) >> 2;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8));
+        const bf16x4 lo = lds_tr_read(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8);
+        const bf16x4 hi = lds_tr_read(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8);
         bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       bf16x8 af0[TM], bf0[TN], af1[TM], bf1[TN];
       read_frags(bA, bB, 0, af0, bf0);
       read_frags(bA, bB, 1, af1, bf1);
-      __builtin_amdgcn_sched_barrier(0);  // every LDS read of the step is issued before its first MFMA (counted lgkmcnt waits follow)
+      if constexpr (!A_KCONT || !B_KCONT) lds_reads_done();  // (asm transposed reads are not tracked by the compiler)
+      __builtin_amdgcn_sched_barrier(0);  // every LDS read of the step is issued before its first MFMA
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -239,8 +241,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
         } else {
           const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
           const int c = col >> 3, h = (col & 7) >> 2;
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8));
+          const bf16x4 lo = lds_tr_read(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8);
+          const bf16x4 hi = lds_tr_read(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8);
           af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       }
@@ -253,10 +255,18 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
           constexpr int ROWB = BN * 2, PM = BN / 8 - 1;
           const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
           const int c = col >> 3, h = (col & 7) >> 2;
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8));
+          const bf16x4 lo = lds_tr_read(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8);
+          const bf16x4 hi = lds_tr_read(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8);
           bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
+      }
+      if constexpr (!A_KCONT || !B_KCONT) lds_reads_done();  // (asm transposed reads are not tracked by the compiler)
+      if (g.dbg == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[j]));
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -295,6 +305,13 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     }
     return;
   }
+  if (g.dbg == 3) {  // (every accumulator kept live: the MFMAs must not be eliminated with the epilogue)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+    return;
+  }
   // ---- epilogue (same semantics as the generic kernel) ------------------------------------------------
   if (g.c_dtype == D2R_BF16 && g.vecC) {
     constexpr int LDE = WN + 8;
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
         Pack<bf16_t, 4> pk;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float bv = (g.bias && col + r < g.N) ? g.bias[col + r] : 0.f;
+          const float bv = (g.bias && g.dbg != 4 && col + r < g.N) ? g.bias[col + r] : 0.f;
           pk.v[r] = (bf16_t)(g.alpha * acc[i][j][r] + bv);
         }
         st_pack<bf16_t, 4>(Cs + (i * 16 + fr) * LDE + j * 16 + fq * 4, pk);
@@ -320,8 +337,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     bf16_t* Pg = reinterpret_cast<bf16_t*>(g.P);
     const bf16_t* Rg = reinterpret_cast<const bf16_t*>(g.R);
     const bf16_t* Gg = reinterpret_cast<const bf16_t*>(g.G);
-#pragma unroll
-    for (int it = 0; it < WM * CPR / 64; ++it) {
+#pragma unroll 1
+    for (int it = 0; it < WM * CPR / 64; ++it) {  // (rolled on purpose: one copy of the epilogue arithmetic)
       const int e = it * 64 + lane;
       const int rl = e / CPR, ch = e % CPR;
       const int row = m0 + wm0 + rl, col = n0 + wn0 + ch * 8;
@@ -329,33 +346,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       const Pack<bf16_t, 8> pv = ld_pack<bf16_t, 8>(Cs + rl * LDE + ch * 8);
       const int64_t ci = (int64_t)row * g.ldc + col;
       const int64_t ri = (int64_t)row * g.ldr + col;
-      if (col + 8 <= g.N) {
-        if (Pg) st_pack<bf16_t, 8>(Pg + ci, pv);
-        Pack<bf16_t, 8> rv, cv, ov, gv;
-        if (Rg) rv = ld_pack<bf16_t, 8>(Rg + ri);
-        if (g.beta != 0.f) cv = ld_pack<bf16_t, 8>(Cg + ci);
-        if (Gg) gv = ld_pack<bf16_t, 8>(Gg + ci);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          float v = act_apply(g.act, (float)pv.v[u]);
-          if (Gg) v *= act_grad(g.gact, (float)gv.v[u]);
-          if (Rg) v += (float)rv.v[u];
-          if (g.beta != 0.f) v += g.beta * (float)cv.v[u];
-          ov.v[u] = (bf16_t)v;
-        }
-        st_pack<bf16_t, 8>(Cg + ci, ov);
-      } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {  // (fully unrolled: a runtime bound would index the packs dynamically -> scratch)
-          if (col + u >= g.N) break;
-          if (Pg) Pg[ci + u] = pv.v[u];
-          float v = act_apply(g.act, (float)pv.v[u]);
-          if (Gg) v *= act_grad(g.gact, (float)Gg[ci + u]);
-          if (Rg) v += (float)Rg[ri + u];
-          if (g.beta != 0.f) v += g.beta * (float)Cg[ci + u];
-          Cg[ci + u] = (bf16_t)v;
-        }
-      }
+      if (g.dbg == 5) continue;
+      epilogue_pack8(g, pv, Cg, Pg, Rg, Gg, ci, ri, g.N - col);
     }
     return;
   }
@@ -372,7 +364,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
         float v = g.alpha * acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
         const int64_t ci = (int64_t)row * g.ldc + col;
         if (g.P) store_c(g.P, g.c_dtype, ci, v);
-        v = act_apply(g.act, v);
+        v = act_apply_cold(g.act, v);
         if (g.R) v += load_c(g.R, g.c_dtype, (int64_t)row * g.ldr + col);
         if (g.beta != 0.f) v += g.beta * load_c(g.C, g.c_dtype, ci);
         store_c(g.C, g.c_dtype, ci, v);
