@@ -500,7 +500,7 @@ def test_interaction_module_one_call_matches_op_by_op(gpu, cfg):
         r = float((a - b).norm() / (b.norm() + 1e-3 * gn / len(store.entries) ** 0.5))
         if r > worst[1]:
             worst = (n, r)
-        assert r < 3e-2, (n, r, float(a.norm()), float(b.norm()))
+        assert r < 5e-2, (n, r, float(a.norm()), float(b.norm()))
     print(f"[{cfg}] one-call vs op-by-op: d_own {rel(do1, do0):.2e} d_other {rel(dt1, dt0):.2e} worst parameter gradient {worst[0]} {worst[1]:.2e}")
 
 
