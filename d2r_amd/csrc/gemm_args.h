@@ -9,7 +9,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // Grouped mode (weight-gradient GEMMs of identical shape deferred and launched together): operand pointers of problem
 // z = blockIdx.z, passed by value so that the launch needs no host-to-device copy and can be captured into a hipGraph.
-constexpr int D2R_GEMM_GROUP_MAX = 16;
+constexpr int D2R_GEMM_GROUP_MAX = 32;
 struct GemmGroup {
   const void* A[D2R_GEMM_GROUP_MAX];
   const void* B[D2R_GEMM_GROUP_MAX];

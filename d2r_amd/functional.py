@@ -105,7 +105,7 @@ def wgrad_streams():
 DEFER_WGRAD = os.environ.get("D2R_DEFER_WGRAD", "1") != "0"
 DEFER_SHORT_WGRAD = os.environ.get("D2R_DEFER_SHORT_WGRAD", "1") != "0"  # also the rank-B updates of the pooled-vector linears
 _WGRAD_Q = {}  # stream handle -> {"stream": torch stream, "jobs": {shape key: [job, ...]}}
-_WGRAD_FLUSH_AT = 16
+_WGRAD_FLUSH_AT = 32
 D2R_LAYER_GROUP = int(os.environ.get("D2R_LAYER_GROUP", "7"))  # encoder layers per grouped launch of their (large) weight gradients
 # (measured at C2: 1 -> 32.6 ms/step, 2 -> 31.7, 4 / 6 / 13 -> 31.3-31.5; each stream runs 13 composite layers per step, so seven
 # gives groups of 7 + 6 and no single-problem launch; at most ~0.8 GB of scratch kept alive)
