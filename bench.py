@@ -303,8 +303,8 @@ def main():
             sched.step()
             opt.zero_grad()
 
-        saved = (M.COMPOSITE_LAYERS, model.model.use_streams)
-        M.COMPOSITE_LAYERS, model.model.use_streams = False, False
+        saved = (M.COMPOSITE_LAYERS, model.model.use_streams, M.COMPOSITE_ROUTING)
+        M.COMPOSITE_LAYERS, model.model.use_streams, M.COMPOSITE_ROUTING = False, False, False
         try:
             local_step()
             torch.cuda.synchronize()
@@ -313,7 +313,7 @@ def main():
                     local_step()
             summ = kt.summary()
         finally:
-            M.COMPOSITE_LAYERS, model.model.use_streams = saved
+            M.COMPOSITE_LAYERS, model.model.use_streams, M.COMPOSITE_ROUTING = saved
         kernels = []
         for name, r in summ.items():
             calls, t_s = r["calls"], r["ms"] * 1e-3

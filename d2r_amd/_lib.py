@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd2r_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU, ACT_QUICK_GELU, ACT_TANH_RELU, ACT_SIGMOID = range(7)
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 
@@ -138,8 +138,9 @@ SIGNATURES = {
     "d2r_patchify": (i32, [i32, vp, i32, i32, i32, i32, vp, vp]),
     "d2r_clip_embed_finish": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
     "d2r_clip_embed_bwd": (i32, [i32, vp, i32, i32, i32, vp, vp, vp]),
-    "d2r_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
-    "d2r_adamw_step_dev": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]),
+    "d2r_adamw_step": (i32, [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, f32, i64, f32, vp, vp]),
+    "d2r_adamw_step_dev": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, f32, f32, f32, f32, vp, vp]),
+    "d2r_grad_nonfinite": (i32, [vp, i64, vp, vp]),
 }
 
 

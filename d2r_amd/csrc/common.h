@@ -8,6 +8,7 @@
 #include "../../include/d2r_hip.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 
 #define D2R_WAVE 64
 
@@ -22,15 +23,18 @@ int d2r_check_launch(const char* what);
   } while (0)
 
 static inline bool d2r_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-static inline size_t d2r_esize(int dtype) { return dtype == D2R_BF16 ? 2 : 4; }
+static inline size_t d2r_esize(int dtype) { return dtype == D2R_F32 ? 4 : 2; }
+static inline bool d2r_is16(int dtype) { return dtype == D2R_BF16 || dtype == D2R_F16; }
 
 // ---- scalar conversions -------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f<f16_t>(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }  // RNE, NaN-preserving
+template <> __device__ __forceinline__ f16_t from_f<f16_t>(float v) { return (f16_t)v; }     // RNE; |v| > 65504 -> inf
 
 // ---- 16-byte packs --------------------------------------------------------------------------------
 template <typename T> struct PackOf { static constexpr int N = 16 / sizeof(T); };

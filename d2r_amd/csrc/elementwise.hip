@@ -55,11 +55,12 @@ static int ew_launch(const char* name, int dtype, const EwPtrs<NIN, NOUT>& p, in
     if (!p.out[o]) return d2r_fail(D2R_ERR_INVALID, "%s: null output %d", name, o);
     vec_ok &= d2r_aligned16(p.out[o]);
   }
-  const int64_t work = n / (dtype == D2R_BF16 ? 8 : 4) + 1;
+  const int64_t work = n / (dtype != D2R_F32 ? 8 : 4) + 1;
   int blocks = (int)((work + 255) / 256);
   if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((ew_kernel<bf16_t, NIN, NOUT, F>), dim3(blocks), dim3(256), 0, st, p, n, vec_ok, f);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((ew_kernel<f16_t, NIN, NOUT, F>), dim3(blocks), dim3(256), 0, st, p, n, vec_ok, f);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((ew_kernel<float, NIN, NOUT, F>), dim3(blocks), dim3(256), 0, st, p, n, vec_ok, f);
   else return d2r_fail(D2R_ERR_INVALID, "%s: bad dtype %d", name, dtype);
   return d2r_check_launch(name);
@@ -205,11 +206,12 @@ extern "C" int d2r_dropout(int dtype, const void* x, const void* add, void* y, i
   const uint32_t thresh = (uint32_t)((double)p * 16777216.0);  // drop when the 24-bit uniform is below p * 2^24
   const float scale = 1.f / (1.f - p);
   const int vec_ok = d2r_aligned16(x) && d2r_aligned16(y) && d2r_aligned16(add);
-  const int64_t work = n / (dtype == D2R_BF16 ? 8 : 4) + 1;
+  const int64_t work = n / (dtype != D2R_F32 ? 8 : 4) + 1;
   int blocks = (int)((work + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)add, (bf16_t*)y, n, thresh, scale, seed, vec_ok);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((dropout_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, (const f16_t*)x, (const f16_t*)add, (f16_t*)y, n, thresh, scale, seed, vec_ok);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)add, (float*)y, n, thresh, scale, seed, vec_ok);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_dropout: bad dtype %d", dtype);
   return d2r_check_launch("d2r_dropout");
@@ -264,19 +266,24 @@ extern "C" int d2r_cast(int src_dtype, const void* src, int dst_dtype, void* dst
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (src_dtype == D2R_F32 && dst_dtype == D2R_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == D2R_F32 && dst_dtype == D2R_F16) hipLaunchKernelGGL((cast_kernel<float, f16_t>), dim3(blocks), dim3(256), 0, st, (const float*)src, (f16_t*)dst, n);
   else if (src_dtype == D2R_BF16 && dst_dtype == D2R_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == D2R_F16 && dst_dtype == D2R_F32) hipLaunchKernelGGL((cast_kernel<f16_t, float>), dim3(blocks), dim3(256), 0, st, (const f16_t*)src, (float*)dst, n);
   else if (src_dtype == D2R_F32 && dst_dtype == D2R_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
   else if (src_dtype == D2R_BF16 && dst_dtype == D2R_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  else if (src_dtype == D2R_F16 && dst_dtype == D2R_F16) hipLaunchKernelGGL((cast_kernel<f16_t, f16_t>), dim3(blocks), dim3(256), 0, st, (const f16_t*)src, (f16_t*)dst, n);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
   return d2r_check_launch("d2r_cast");
 }
 
 // ---- K14 AdamW over a flat fp32 range (modules/train.py:287-322; torch.optim.AdamW semantics) -----------
+template <typename H>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
-                                                    bf16_t* __restrict__ w16, int64_t n, float lr, float b1, float b2,
+                                                    H* __restrict__ w16, int64_t n, float lr, float b1, float b2,
                                                     float eps, float wd, float bc1, float bc2_sqrt, float gscale,
-                                                    const float* __restrict__ d_hyper) {
+                                                    const float* __restrict__ d_hyper, const int* __restrict__ d_skip) {
+  if (d_skip && *d_skip) return;  // overflowed loss-scaled gradients: this step is dropped
   if (d_hyper) {  // hipGraph-safe variant: per-step scalars live in device memory, refreshed before each replay
     lr = d_hyper[0];
     bc1 = d_hyper[1];
@@ -303,47 +310,77 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
     st_pack<float, 4>(m + k * 4, pm);
     st_pack<float, 4>(v + k * 4, pv);
     if (w16) {
-      Pack<bf16_t, 4> ph;
+      Pack<H, 4> ph;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ph.v[j] = (bf16_t)pw.v[j];
-      st_pack<bf16_t, 4>(w16 + k * 4, ph);
+      for (int j = 0; j < 4; ++j) ph.v[j] = (H)pw.v[j];
+      st_pack<H, 4>(w16 + k * 4, ph);
     }
   }
   for (int64_t e = n4 * 4 + tid; e < n; e += nthreads) {
     float wi = w[e], mi = m[e], vi = v[e];
     upd(wi, g[e], mi, vi);
     w[e] = wi; m[e] = mi; v[e] = vi;
-    if (w16) w16[e] = (bf16_t)wi;
+    if (w16) w16[e] = (H)wi;
   }
 }
 
-extern "C" int d2r_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr,
-                              float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                              float grad_scale, void* stream) {
-  D2R_REQUIRE(w && g && m && v && n >= 0 && step >= 1, "d2r_adamw_step: bad arguments");
-  D2R_REQUIRE(d2r_aligned16(w) && d2r_aligned16(g) && d2r_aligned16(m) && d2r_aligned16(v), "d2r_adamw_step: pointers must be 16-byte aligned");
-  D2R_REQUIRE(!w_bf16 || (reinterpret_cast<uintptr_t>(w_bf16) & 7u) == 0, "d2r_adamw_step: bf16 shadow must be 8-byte aligned");
+static int adamw_launch(const char* name, float* w, const float* g, float* m, float* v, void* w16, int w16_dtype, int64_t n, float lr,
+                        float b1, float b2, float eps, float wd, float bc1, float bc2s, float gscale, const float* d_hyper,
+                        const int* d_skip, void* stream) {
+  D2R_REQUIRE(d2r_aligned16(w) && d2r_aligned16(g) && d2r_aligned16(m) && d2r_aligned16(v), "%s: pointers must be 16-byte aligned", name);
+  D2R_REQUIRE(!w16 || ((reinterpret_cast<uintptr_t>(w16) & 7u) == 0 && d2r_is16(w16_dtype)),
+              "%s: the 16-bit shadow must be 8-byte aligned and D2R_BF16 or D2R_F16 (got dtype %d)", name, w16_dtype);
   if (n == 0) return D2R_OK;
+  int blocks = (int)((n / 4 + 256) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (w16 && w16_dtype == D2R_F16)
+    hipLaunchKernelGGL(adamw_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (f16_t*)w16, n, lr, b1, b2, eps, wd,
+                       bc1, bc2s, gscale, d_hyper, d_skip);
+  else
+    hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (bf16_t*)w16, n, lr, b1, b2, eps,
+                       wd, bc1, bc2s, gscale, d_hyper, d_skip);
+  return d2r_check_launch(name);
+}
+
+extern "C" int d2r_adamw_step(float* w, const float* g, float* m, float* v, void* w16, int w16_dtype, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                              float grad_scale, const int* d_skip, void* stream) {
+  D2R_REQUIRE(w && g && m && v && n >= 0 && step >= 1, "d2r_adamw_step: bad arguments");
   // double on the host, rounded once: FusedAdamW.stage_hyper (the hipGraph path) computes the very same values
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  int blocks = (int)((n / 4 + 256) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (bf16_t*)w_bf16, n, lr,
-                     beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, (const float*)nullptr);
-  return d2r_check_launch("d2r_adamw_step");
+  return adamw_launch("d2r_adamw_step", w, g, m, v, w16, w16_dtype, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale,
+                      nullptr, d_skip, stream);
 }
 
 // hipGraph-capturable form: d_hyper = device float[4] {lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale}
-extern "C" int d2r_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w_bf16, int64_t n,
+extern "C" int d2r_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16, int w16_dtype, int64_t n,
                                   const float* d_hyper, float beta1, float beta2, float eps, float weight_decay,
-                                  void* stream) {
+                                  const int* d_skip, void* stream) {
   D2R_REQUIRE(w && g && m && v && d_hyper && n >= 0, "d2r_adamw_step_dev: bad arguments");
-  D2R_REQUIRE(d2r_aligned16(w) && d2r_aligned16(g) && d2r_aligned16(m) && d2r_aligned16(v), "d2r_adamw_step_dev: pointers must be 16-byte aligned");
+  return adamw_launch("d2r_adamw_step_dev", w, g, m, v, w16, w16_dtype, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.f, d_hyper,
+                      d_skip, stream);
+}
+
+// ---- overflow check of loss-scaled gradients (fp16 compute dtype): one streaming pass, flag |= any(!isfinite(g)) -----
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, int64_t n, int* __restrict__ flag) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n / 4;
+  bool bad = false;
+  for (int64_t k = tid; k < n4; k += nthreads) {
+    const Pack<float, 4> p = ld_pack<float, 4>(g + k * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bad |= !(fabsf(p.v[j]) <= 3.4028234e38f);  // false for inf and for NaN
+  }
+  for (int64_t e = n4 * 4 + tid; e < n; e += nthreads) bad |= !(fabsf(g[e]) <= 3.4028234e38f);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+extern "C" int d2r_grad_nonfinite(const float* g, int64_t n, int* d_flag, void* stream) {
+  D2R_REQUIRE(g && d_flag && n >= 0 && d2r_aligned16(g), "d2r_grad_nonfinite: bad arguments");
   if (n == 0) return D2R_OK;
   int blocks = (int)((n / 4 + 256) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (bf16_t*)w_bf16, n, 0.f,
-                     beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.f, d_hyper);
-  return d2r_check_launch("d2r_adamw_step_dev");
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, d_flag);
+  return d2r_check_launch("d2r_grad_nonfinite");
 }

@@ -95,7 +95,7 @@ extern "C" size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F) {
 
 static int check_desc(const d2r_encoder_layer_desc* L, const char* fn) {
   D2R_REQUIRE(L != nullptr, "%s: null descriptor", fn);
-  D2R_REQUIRE(L->dtype == D2R_BF16, "%s: bf16 only (the fp32 path runs op by op)", fn);
+  D2R_REQUIRE(d2r_is16(L->dtype), "%s: 16-bit compute dtypes only (the fp32 path runs op by op)", fn);
   D2R_REQUIRE(L->B >= 1 && L->L >= 1 && L->E >= 8 && L->H >= 1 && L->F >= 8 && L->E % L->H == 0, "%s: bad shape", fn);
   D2R_REQUIRE(d2r_mha_supported(L->dtype, L->L, L->L, L->E / L->H), "%s: attention shape unsupported by the fused core", fn);
   D2R_REQUIRE(L->act == D2R_ACT_GELU || L->act == D2R_ACT_QUICK_GELU, "%s: activation must be gelu or quick_gelu", fn);

@@ -188,41 +188,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
     if constexpr (IS_BF16) {
 #pragma unroll
       for (int kk = 0; kk < BK / 32; ++kk) {
-        bf16x8 af[TM], bfr[TN];
+        typedef typename H16<T>::v8 h8;
+        typedef typename H16<T>::v4 h4;
+        h8 af[TM], bfr[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           if constexpr (A_KCONT) {
-            af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm0 + i * 16 + fr) * LDK + kk * 32 + fq * 8]);
+            af[i] = *reinterpret_cast<const h8*>(&As[(wm0 + i * 16 + fr) * LDK + kk * 32 + fq * 8]);
           } else {
-            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
             const T* p0 = &As[(kk * 32 + fq * 8 + tq) * LDA_T + wm0 + i * 16 + tp * 4];
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * LDA_T));
-            af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const h4 lo = H16<T>::tr_read(p0), hi = H16<T>::tr_read(p0 + 4 * LDA_T);
+            af[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if constexpr (B_KCONT) {
-            bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn0 + j * 16 + fr) * LDK + kk * 32 + fq * 8]);
+            bfr[j] = *reinterpret_cast<const h8*>(&Bs[(wn0 + j * 16 + fr) * LDK + kk * 32 + fq * 8]);
           } else {
-            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
             const T* p0 = &Bs[(kk * 32 + fq * 8 + tq) * LDB_T + wn0 + j * 16 + tp * 4];
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * LDB_T));
-            bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const h4 lo = H16<T>::tr_read(p0), hi = H16<T>::tr_read(p0 + 4 * LDB_T);
+            bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = H16<T>::mfma32(af[i], bfr[j], acc[i][j]);
         if constexpr (LAYOUT == D2R_GEMM_TN) {
           if (do_bias) {
-            const bf16_t one = (bf16_t)1.f;
-            const bf16x8 ones = {one, one, one, one, one, one, one, one};
+            const T one = (T)1.f;
+            const h8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc_b[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_b[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc_b[i] = H16<T>::mfma32(af[i], ones, acc_b[i]);
           }
         }
       }
@@ -291,12 +289,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
   }
   const int64_t cz = zb * g.sCb + zh * g.sCh;
   const int64_t rz = zb * g.sRb + zh * g.sRh;
-  if (g.c_dtype == D2R_BF16 && g.vecC) {
-    // bf16 output: the MFMA layout gives each lane one column of four rows (2-byte stores, 32 B segments).
+  typedef typename Out16<T>::type O16;
+  if (g.c_dtype == H16<O16>::DT && g.vecC) {
+    // 16-bit output: the MFMA layout gives each lane one column of four rows (2-byte stores, 32 B segments).
     // Stage v = alpha*acc + bias per wave in LDS as bf16 [WM][WN+8], then each lane handles 8 consecutive columns
     // of one row: 16-byte loads of residual / old C, 16-byte stores of preact and C (8 lanes = one 128 B row).
     constexpr int LDE = WN + 8;
-    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem) + wave * WM * LDE;
+    O16* Cs = reinterpret_cast<O16*>(smem) + wave * WM * LDE;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -304,23 +303,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
         const int col = n0 + wn0 + j * 16 + fr;
         const float bv = (g.bias && col < g.N) ? g.bias[zb * g.sBiasB + col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cs[(i * 16 + fq * 4 + r) * LDE + j * 16 + fr] = (bf16_t)(g.alpha * acc[i][j][r] + bv);
+        for (int r = 0; r < 4; ++r) Cs[(i * 16 + fq * 4 + r) * LDE + j * 16 + fr] = (O16)(g.alpha * acc[i][j][r] + bv);
       }
     // same-wave hand-off through LDS: wait for the wave's own ds_writes (no block barrier: regions are private)
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
     constexpr int CPR = WN / 8;  // 16-byte chunks per row
-    bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C);
-    bf16_t* Pg = reinterpret_cast<bf16_t*>(g.P);
-    const bf16_t* Rg = reinterpret_cast<const bf16_t*>(g.R);
-    const bf16_t* Gg = reinterpret_cast<const bf16_t*>(g.G);
+    O16* Cg = reinterpret_cast<O16*>(g.C);
+    O16* Pg = reinterpret_cast<O16*>(g.P);
+    const O16* Rg = reinterpret_cast<const O16*>(g.R);
+    const O16* Gg = reinterpret_cast<const O16*>(g.G);
 #pragma unroll 1
     for (int it = 0; it < WM * CPR / 64; ++it) {  // (rolled on purpose: one copy of the epilogue arithmetic)
       const int e = it * 64 + lane;
       const int rl = e / CPR, ch = e % CPR;
       const int row = m0 + wm0 + rl, col = n0 + wn0 + ch * 8;
       if (row >= g.M || col >= g.N) continue;
-      const Pack<bf16_t, 8> pv = ld_pack<bf16_t, 8>(Cs + rl * LDE + ch * 8);
+      const Pack<O16, 8> pv = ld_pack<O16, 8>(Cs + rl * LDE + ch * 8);
       const int64_t ci = cz + (int64_t)row * g.ldc + col;
       const int64_t ri = rz + (int64_t)row * g.ldr + col;
       epilogue_pack8(g, pv, Cg, Pg, Rg, Gg, ci, ri, g.N - col);
@@ -443,7 +442,8 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
   else tile = 1;
   if (g_tile >= 0 && g_tile <= 3 && a.M > 32) tile = g_tile;
   if (a.G) {  // the activation-gradient epilogue exists in the LDS-staged (vectorised, bf16) epilogue of the small tiles only
-    if (!a.vecC || a.c_dtype != D2R_BF16) return d2r_fail(D2R_ERR_INVALID, "d2r_gemm: grad_ref needs a bf16 output with 16-byte aligned rows");
+    if (!a.vecC || a.c_dtype != H16<typename Out16<T>::type>::DT)
+      return d2r_fail(D2R_ERR_INVALID, "d2r_gemm: grad_ref needs a 16-bit output (of the input type) with 16-byte aligned rows");
     if (tile > 1) tile = 1;
   }
   if (tile > 1) a.vecC = 0;  // the LDS-staged epilogue only pays on the small tiles (register pressure on the large ones)
@@ -504,8 +504,10 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   D2R_REQUIRE(d != nullptr, "d2r_gemm: null descriptor");
   D2R_REQUIRE(d->A && d->B && d->C, "d2r_gemm: null operand");
   D2R_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "d2r_gemm: negative size");
-  D2R_REQUIRE(d->dtype == D2R_F32 || d->dtype == D2R_BF16, "d2r_gemm: bad dtype %d", d->dtype);
-  D2R_REQUIRE(d->c_dtype == D2R_F32 || d->c_dtype == D2R_BF16, "d2r_gemm: bad c_dtype %d", d->c_dtype);
+  D2R_REQUIRE(d->dtype == D2R_F32 || d2r_is16(d->dtype), "d2r_gemm: bad dtype %d", d->dtype);
+  D2R_REQUIRE(d->c_dtype == D2R_F32 || d2r_is16(d->c_dtype), "d2r_gemm: bad c_dtype %d", d->c_dtype);
+  D2R_REQUIRE(d->c_dtype == D2R_F32 || d->dtype == D2R_F32 || d->c_dtype == d->dtype,
+              "d2r_gemm: a 16-bit output of 16-bit inputs has the inputs' type (dtype %d, c_dtype %d)", d->dtype, d->c_dtype);
   D2R_REQUIRE(d->nb >= 1 && d->nh >= 1, "d2r_gemm: batch must be >= 1");
   D2R_REQUIRE((int64_t)d->nb * d->nh <= 65535, "d2r_gemm: batch %lld exceeds grid.z", (long long)d->nb * d->nh);
   const bool a_kcont = d->layout != D2R_GEMM_TN, b_kcont = d->layout == D2R_GEMM_NT;
@@ -521,7 +523,7 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldr = d->ldr;
   a.sAb = d->sAb; a.sAh = d->sAh; a.sBb = d->sBb; a.sBh = d->sBh;
   a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh; a.sBiasB = d->s_bias_b;
-  a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype;
+  a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype; a.dtype = d->dtype;
   a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd;
   static const int g_dbg = env_int("D2R_GEMM_DBG", 0);
   a.dbg = g_dbg;
@@ -548,6 +550,7 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   const int batch = d->nb * d->nh;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == D2R_BF16) return launch_dtype<bf16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
+  if (d->dtype == D2R_F16) return launch_dtype<f16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
   return launch_dtype<float>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
 }
 
@@ -595,13 +598,13 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
                                    const void* const* h_A, const void* const* h_B, float* const* h_C,
                                    float* const* h_dbias, int count, float beta, void* stream) {
   D2R_REQUIRE(h_A && h_B && h_C && count >= 0, "d2r_gemm_tn_grouped: null pointer array");
-  D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_gemm_tn_grouped: bad dtype %d", dtype);
+  D2R_REQUIRE(dtype == D2R_F32 || d2r_is16(dtype), "d2r_gemm_tn_grouped: bad dtype %d", dtype);
   D2R_REQUIRE(M >= 1 && N >= 1 && K >= 0 && lda >= M && ldb >= N && ldc >= N, "d2r_gemm_tn_grouped: bad shape");
   if (count == 0) return D2R_OK;
   const int64_t es = (int64_t)d2r_esize(dtype);
   GemmArgs a = {};
   a.M = M, a.N = N, a.K = K, a.nh = 1, a.splits = 1, a.lda = lda, a.ldb = ldb, a.ldc = ldc;
-  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.xcd = g_xcd, a.grouped = 1, a.dbg = 0;
+  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.dtype = dtype, a.xcd = g_xcd, a.grouped = 1, a.dbg = 0;
   a.vecA = (lda * es) % 16 == 0, a.vecB = (ldb * es) % 16 == 0, a.vecC = 0;
   for (int i = 0; i < count; ++i) {
     D2R_REQUIRE(h_A[i] && h_B[i] && h_C[i] && (!h_dbias || h_dbias[i]), "d2r_gemm_tn_grouped: null operand in problem %d", i);
@@ -616,5 +619,6 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == D2R_BF16) return launch_grouped_tn<bf16_t>(a, h_A, h_B, h_C, h_dbias, count, st);
+  if (dtype == D2R_F16) return launch_grouped_tn<f16_t>(a, h_A, h_B, h_C, h_dbias, count, st);
   return launch_grouped_tn<float>(a, h_A, h_B, h_C, h_dbias, count, st);
 }

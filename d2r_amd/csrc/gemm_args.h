@@ -5,7 +5,44 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// The two 16-bit element types share every kernel: same tiles, same LDS images, same transposing reads (ds_read_b64_tr_b16 moves
+// 16-bit lanes whatever they hold); only the MFMA opcode differs.  H16<T> names the vector types and the opcodes for T.
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+  static constexpr int DT = D2R_BF16;
+  static __device__ __forceinline__ f32x4 mfma32(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 mfma16(v4 a, v4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ v4 tr_read(const bf16_t* lds) {  // compiler-tracked form (kernels without LDS-DMA in flight)
+    typedef __attribute__((address_space(3))) v4 lds_v4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)lds);
+  }
+};
+template <> struct H16<f16_t> {
+  typedef f16x8 v8;
+  typedef f16x4 v4;
+  static constexpr int DT = D2R_F16;
+  static __device__ __forceinline__ f32x4 mfma32(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 mfma16(v4 a, v4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ v4 tr_read(const f16_t* lds) {
+    typedef __attribute__((ext_vector_type(4))) short i16x4;
+    typedef __attribute__((address_space(3))) i16x4 lds_v4;
+    return __builtin_bit_cast(v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)lds));
+  }
+};
+template <> struct H16<float> {  // placeholder so that `typename H16<T>::v8` parses in the discarded 16-bit branches of fp32 kernels
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+  static constexpr int DT = D2R_F32;
+};
+// 16-bit OUTPUT type of a kernel instantiated for inputs T: T itself, or bf16 for the fp32-input kernels
+template <typename T> struct Out16 { typedef T type; };
+template <> struct Out16<float> { typedef bf16_t type; };
 
 // Grouped mode (weight-gradient GEMMs of identical shape deferred and launched together): operand pointers of problem
 // z = blockIdx.z, passed by value so that the launch needs no host-to-device copy and can be captured into a hipGraph.
@@ -34,6 +71,7 @@ struct GemmArgs {
   int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh, sBiasB;
   float alpha, beta;
   int act, c_dtype, vecA, vecB, vecC, xcd;
+  int dtype;  // element type of A and B
   int dbg;  // timing experiments (D2R_GEMM_DBG): 1 = no MFMA, 2 = no DMA issue, 3 = no epilogue stores
 };
 
@@ -82,10 +120,13 @@ __device__ __forceinline__ void xcd_tile_3d(int enable, int& tile_m, int& tile_n
 
 __device__ __forceinline__ void store_c(void* C, int c_dtype, int64_t idx, float v) {
   if (c_dtype == D2R_BF16) reinterpret_cast<bf16_t*>(C)[idx] = (bf16_t)v;
+  else if (c_dtype == D2R_F16) reinterpret_cast<f16_t*>(C)[idx] = (f16_t)v;
   else reinterpret_cast<float*>(C)[idx] = v;
 }
 __device__ __forceinline__ float load_c(const void* C, int c_dtype, int64_t idx) {
-  return c_dtype == D2R_BF16 ? (float)reinterpret_cast<const bf16_t*>(C)[idx] : reinterpret_cast<const float*>(C)[idx];
+  return c_dtype == D2R_BF16  ? (float)reinterpret_cast<const bf16_t*>(C)[idx]
+         : c_dtype == D2R_F16 ? (float)reinterpret_cast<const f16_t*>(C)[idx]
+                              : reinterpret_cast<const float*>(C)[idx];
 }
 
 
@@ -95,8 +136,9 @@ __device__ __forceinline__ float load_c(const void* C, int c_dtype, int64_t idx)
 // keeps tiles in flight across the reads.  The asm form is invisible to that pass: the caller orders DMA arrival itself
 // (counted vmcnt + barrier) and must put `lds_reads_done()` between the reads and the first MFMA that consumes them
 // (cdna_hip_programming.md 5.7 form (iii), rule 18).
-__device__ __forceinline__ bf16x4 lds_tr_read(const void* p) {
-  bf16x4 r;
+template <typename V4>
+__device__ __forceinline__ V4 lds_tr_read(const void* p) {
+  V4 r;
   const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
   return r;
@@ -183,36 +225,37 @@ __device__ __forceinline__ void act_grad_mul_vec(int act, const float (&r)[N], f
 static __device__ __attribute__((noinline)) float act_apply_cold(int act, float x) { return act_apply(act, x); }
 static __device__ __attribute__((noinline)) float act_grad_cold(int act, float r) { return act_grad(act, r); }
 
-// One 8-column pack of the LDS-staged bf16 epilogue, shared by the MFMA GEMM kernels:
+// One 8-column pack of the LDS-staged 16-bit epilogue, shared by the MFMA GEMM kernels:
 //   out = act(pv) [* act'(G)] [+ R] [+ beta * C_old],  preact <- pv;   `n_ok` = valid columns of the pack (8 = whole pack)
-__device__ __forceinline__ void epilogue_pack8(const GemmArgs& g, const Pack<bf16_t, 8>& pv, bf16_t* Cg, bf16_t* Pg, const bf16_t* Rg,
-                                               const bf16_t* Gg, int64_t ci, int64_t ri, int n_ok) {
+template <typename H>
+__device__ __forceinline__ void epilogue_pack8(const GemmArgs& g, const Pack<H, 8>& pv, H* Cg, H* Pg, const H* Rg, const H* Gg, int64_t ci,
+                                               int64_t ri, int n_ok) {
   float v[8], t[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) v[u] = (float)pv.v[u];
   if (n_ok >= 8) {
-    if (Pg) st_pack<bf16_t, 8>(Pg + ci, pv);
+    if (Pg) st_pack<H, 8>(Pg + ci, pv);
     act_apply_vec<8>(g.act, v);
     if (Gg) {
-      const Pack<bf16_t, 8> gv = ld_pack<bf16_t, 8>(Gg + ci);
+      const Pack<H, 8> gv = ld_pack<H, 8>(Gg + ci);
 #pragma unroll
       for (int u = 0; u < 8; ++u) t[u] = (float)gv.v[u];
       act_grad_mul_vec<8>(g.gact, t, v);
     }
     if (Rg) {
-      const Pack<bf16_t, 8> rv = ld_pack<bf16_t, 8>(Rg + ri);
+      const Pack<H, 8> rv = ld_pack<H, 8>(Rg + ri);
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] += (float)rv.v[u];
     }
     if (g.beta != 0.f) {
-      const Pack<bf16_t, 8> cv = ld_pack<bf16_t, 8>(Cg + ci);
+      const Pack<H, 8> cv = ld_pack<H, 8>(Cg + ci);
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] += g.beta * (float)cv.v[u];
     }
-    Pack<bf16_t, 8> ov;
+    Pack<H, 8> ov;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ov.v[u] = (bf16_t)v[u];
-    st_pack<bf16_t, 8>(Cg + ci, ov);
+    for (int u = 0; u < 8; ++u) ov.v[u] = (H)v[u];
+    st_pack<H, 8>(Cg + ci, ov);
     return;
   }
   // ragged right edge: element by element (static indices only: a runtime index into the packs would go to scratch)
@@ -225,7 +268,7 @@ __device__ __forceinline__ void epilogue_pack8(const GemmArgs& g, const Pack<bf1
       if (Gg) x *= act_grad_cold(g.gact, (float)Gg[ci + u]);
       if (Rg) x += (float)Rg[ri + u];
       if (g.beta != 0.f) x += g.beta * (float)Cg[ci + u];
-      Cg[ci + u] = (bf16_t)x;
+      Cg[ci + u] = (H)x;
     }
   }
 }

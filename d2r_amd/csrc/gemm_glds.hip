@@ -14,7 +14,6 @@
 // bf16, batch 1, K % 64 == 0, 16-B aligned operands, and M % 8 == N % 8 == 0 for k-strided operands.
 #include "gemm_args.h"
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
 // NWN waves along N (2: four waves, 4: eight waves per workgroup); a wave owns 64 rows x BN/NWN columns.
 // PIPE = 1: software-pipelined K-step (all fragment reads of the step issued up front behind counted lgkmcnt waits, the
@@ -22,8 +21,10 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 // WGRAD (TN only): grouped weight-gradient mode — blockIdx.z selects one of up to 16 same-shape problems (operand pointers in
 // `grp`), the output is fp32 and ACCUMULATED (C += A^T B, 16-byte loads / stores), and the workgroups of the first tile column
 // also produce the bias gradient dbias[m] += sum_k A[k,m] (their A fragments times an all-ones fragment).
-template <int LAYOUT, int BN, int NWN = 2, int PIPE = 0, bool WGRAD = false>
+template <typename E, int LAYOUT, int BN, int NWN = 2, int PIPE = 0, bool WGRAD = false>
 __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, GemmGroup grp) {
+  typedef typename H16<E>::v8 h8;  // E: E or f16_t (same tiles and LDS images; the MFMA opcode differs)
+  typedef typename H16<E>::v4 h4;
   constexpr int BM = 128, BK = 64, NW = 2 * NWN;
   constexpr bool A_KCONT = (LAYOUT != D2R_GEMM_TN);
   constexpr bool B_KCONT = (LAYOUT == D2R_GEMM_NT);
@@ -43,12 +44,12 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
   if constexpr (WGRAD) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
   else xcd_tile(g.xcd, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+  const E* A = reinterpret_cast<const E*>(g.A);
+  const E* B = reinterpret_cast<const E*>(g.B);
   if constexpr (WGRAD) {
     static_assert(LAYOUT == D2R_GEMM_TN, "the weight-gradient mode is a TN product");
-    A = reinterpret_cast<const bf16_t*>(grp.A[z]);
-    B = reinterpret_cast<const bf16_t*>(grp.B[z]);
+    A = reinterpret_cast<const E*>(grp.A[z]);
+    B = reinterpret_cast<const E*>(grp.B[z]);
     g.C = grp.C[z];
     g.dbias = grp.dbias[z];
   }
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
         const int krow = (wave + NW * i) * 4 + (lane >> 4);
         adjA = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.lda : 0;
       }
-      const bf16_t* src = A + offA[i] + adjA + (A_KCONT ? (int64_t)k0 : (int64_t)k0 * g.lda);
+      const E* src = A + offA[i] + adjA + (A_KCONT ? (int64_t)k0 : (int64_t)k0 * g.lda);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
     }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
         const int krow = (wave + NW * i) * 4 + (lane >> 4);
         adjB = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.ldb : 0;
       }
-      const bf16_t* src = B + offB[i] + adjB + (B_KCONT ? (int64_t)k0 : (int64_t)k0 * g.ldb);
+      const E* src = B + offB[i] + adjB + (B_KCONT ? (int64_t)k0 : (int64_t)k0 * g.ldb);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
     }
@@ -129,32 +130,32 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
   const int fr = lane & 15, fq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
   const int nk = WGRAD ? nk_w : g.K / BK;
   // fragments of K-substep kk (32 k) from the staged tile at bA / bB
-  auto read_frags = [&](const unsigned char* bA, const unsigned char* bB, int kk, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) {
+  auto read_frags = [&](const unsigned char* bA, const unsigned char* bB, int kk, h8 (&af)[TM], h8 (&bfr)[TN]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if constexpr (A_KCONT) {
         const int row = wm0 + i * 16 + fr, c = kk * 4 + fq;
-        af[i] = *reinterpret_cast<const bf16x8*>(bA + row * 128 + ((c ^ (row & 7)) << 4));
+        af[i] = *reinterpret_cast<const h8*>(bA + row * 128 + ((c ^ (row & 7)) << 4));
       } else {
         const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
         const int c = col >> 3, h = (col & 7) >> 2;
-        const bf16x4 lo = lds_tr_read(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8);
-        const bf16x4 hi = lds_tr_read(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8);
-        af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const h4 lo = lds_tr_read<h4>(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8);
+        const h4 hi = lds_tr_read<h4>(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8);
+        af[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if constexpr (B_KCONT) {
         const int row = wn0 + j * 16 + fr, c = kk * 4 + fq;
-        bfr[j] = *reinterpret_cast<const bf16x8*>(bB + row * 128 + ((c ^ (row & 7)) << 4));
+        bfr[j] = *reinterpret_cast<const h8*>(bB + row * 128 + ((c ^ (row & 7)) << 4));
       } else {
         constexpr int ROWB = BN * 2, PM = BN / 8 - 1;
         const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
         const int c = col >> 3, h = (col & 7) >> 2;
-        const bf16x4 lo = lds_tr_read(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8);
-        const bf16x4 hi = lds_tr_read(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8);
-        bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8);
+        const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8);
+        bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
   };
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
       }
-      bf16x8 af0[TM], bf0[TN], af1[TM], bf1[TN];
+      h8 af0[TM], bf0[TN], af1[TM], bf1[TN];
       read_frags(bA, bB, 0, af0, bf0);
       read_frags(bA, bB, 1, af1, bf1);
       if constexpr (!A_KCONT || !B_KCONT) lds_reads_done();  // (asm transposed reads are not tracked by the compiler)
@@ -191,15 +192,15 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = H16<E>::mfma32(bf0[j], af0[i], acc[i][j]);
       if constexpr (WGRAD) {
         if (do_bias) {
-          const bf16_t one = (bf16_t)1.f;
-          const bf16x8 ones = {one, one, one, one, one, one, one, one};
+          const E one = (E)1.f;
+          const h8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            acc_b[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af0[i], acc_b[i], 0, 0, 0);
-            acc_b[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af1[i], acc_b[i], 0, 0, 0);
+            acc_b[i] = H16<E>::mfma32(ones, af0[i], acc_b[i]);
+            acc_b[i] = H16<E>::mfma32(ones, af1[i], acc_b[i]);
           }
         }
       }
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = H16<E>::mfma32(bf1[j], af1[i], acc[i][j]);
     }
   } else {
   issue(0, 0);
@@ -232,32 +233,32 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     const unsigned char* bB = bA + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[TM], bfr[TN];
+      h8 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if constexpr (A_KCONT) {
           const int row = wm0 + i * 16 + fr, c = kk * 4 + fq;
-          af[i] = *reinterpret_cast<const bf16x8*>(bA + row * 128 + ((c ^ (row & 7)) << 4));
+          af[i] = *reinterpret_cast<const h8*>(bA + row * 128 + ((c ^ (row & 7)) << 4));
         } else {
           const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
           const int c = col >> 3, h = (col & 7) >> 2;
-          const bf16x4 lo = lds_tr_read(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8);
-          const bf16x4 hi = lds_tr_read(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8);
-          af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const h4 lo = lds_tr_read<h4>(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8);
+          const h4 hi = lds_tr_read<h4>(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8);
+          af[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (B_KCONT) {
           const int row = wn0 + j * 16 + fr, c = kk * 4 + fq;
-          bfr[j] = *reinterpret_cast<const bf16x8*>(bB + row * 128 + ((c ^ (row & 7)) << 4));
+          bfr[j] = *reinterpret_cast<const h8*>(bB + row * 128 + ((c ^ (row & 7)) << 4));
         } else {
           constexpr int ROWB = BN * 2, PM = BN / 8 - 1;
           const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
           const int c = col >> 3, h = (col & 7) >> 2;
-          const bf16x4 lo = lds_tr_read(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8);
-          const bf16x4 hi = lds_tr_read(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8);
-          bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8);
+          const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8);
+          bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       }
       if constexpr (!A_KCONT || !B_KCONT) lds_reads_done();  // (asm transposed reads are not tracked by the compiler)
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)  // operands swapped: the accumulator tile is C^T, a lane owns ONE row and 4 consecutive columns
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = H16<E>::mfma32(bfr[j], af[i], acc[i][j]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading buffer `cur` before it is refilled at t+1
   }
@@ -313,37 +314,37 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     return;
   }
   // ---- epilogue (same semantics as the generic kernel) ------------------------------------------------
-  if (g.c_dtype == D2R_BF16 && g.vecC) {
+  if (g.c_dtype == H16<E>::DT && g.vecC) {
     constexpr int LDE = WN + 8;
-    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem) + wave * WM * LDE;
+    E* Cs = reinterpret_cast<E*>(smem) + wave * WM * LDE;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         // acc[i][j][r] = C[wm0 + i*16 + fr][wn0 + j*16 + fq*4 + r]: four consecutive columns -> one 8-byte LDS store
         const int col = n0 + wn0 + j * 16 + fq * 4;
-        Pack<bf16_t, 4> pk;
+        Pack<E, 4> pk;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float bv = (g.bias && g.dbg != 4 && col + r < g.N) ? g.bias[col + r] : 0.f;
-          pk.v[r] = (bf16_t)(g.alpha * acc[i][j][r] + bv);
+          pk.v[r] = (E)(g.alpha * acc[i][j][r] + bv);
         }
-        st_pack<bf16_t, 4>(Cs + (i * 16 + fr) * LDE + j * 16 + fq * 4, pk);
+        st_pack<E, 4>(Cs + (i * 16 + fr) * LDE + j * 16 + fq * 4, pk);
       }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     constexpr int CPR = WN / 8;
-    bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C);
-    bf16_t* Pg = reinterpret_cast<bf16_t*>(g.P);
-    const bf16_t* Rg = reinterpret_cast<const bf16_t*>(g.R);
-    const bf16_t* Gg = reinterpret_cast<const bf16_t*>(g.G);
+    E* Cg = reinterpret_cast<E*>(g.C);
+    E* Pg = reinterpret_cast<E*>(g.P);
+    const E* Rg = reinterpret_cast<const E*>(g.R);
+    const E* Gg = reinterpret_cast<const E*>(g.G);
 #pragma unroll 1
     for (int it = 0; it < WM * CPR / 64; ++it) {  // (rolled on purpose: one copy of the epilogue arithmetic)
       const int e = it * 64 + lane;
       const int rl = e / CPR, ch = e % CPR;
       const int row = m0 + wm0 + rl, col = n0 + wn0 + ch * 8;
       if (row >= g.M || col >= g.N) continue;
-      const Pack<bf16_t, 8> pv = ld_pack<bf16_t, 8>(Cs + rl * LDE + ch * 8);
+      const Pack<E, 8> pv = ld_pack<E, 8>(Cs + rl * LDE + ch * 8);
       const int64_t ci = (int64_t)row * g.ldc + col;
       const int64_t ri = (int64_t)row * g.ldr + col;
       if (g.dbg == 5) continue;
@@ -373,40 +374,41 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
   }
 }
 
-template <int LAYOUT>
+template <typename E, int LAYOUT>
 static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
   static const GemmGroup no_group = {};
   const bool pipe = bn >= 1000;  // 1064 / 1128 / 1129: the software-pipelined K-loop
   if (pipe) bn -= 1000;
   if (bn == 129) {  // 128 x 128 tile on EIGHT waves (2 x 4): per wave as the 128x64 kernel, a third less L2 traffic per flop
     dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
-    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128, 4, 1>), grid, dim3(512), 0, st, a, no_group);
-    else hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128, 4>), grid, dim3(512), 0, st, a, no_group);
+    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 4, 1>), grid, dim3(512), 0, st, a, no_group);
+    else hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 4>), grid, dim3(512), 0, st, a, no_group);
     return;
   }
   if (bn == 128) {
     dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
-    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128, 2, 1>), grid, dim3(256), 0, st, a, no_group);
-    else hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 128>), grid, dim3(256), 0, st, a, no_group);
+    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 2, 1>), grid, dim3(256), 0, st, a, no_group);
+    else hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128>), grid, dim3(256), 0, st, a, no_group);
   } else {
     dim3 grid(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 128));
-    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 64, 2, 1>), grid, dim3(256), 0, st, a, no_group);
-    else hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, 64>), grid, dim3(256), 0, st, a, no_group);
+    if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 64, 2, 1>), grid, dim3(256), 0, st, a, no_group);
+    else hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 64>), grid, dim3(256), 0, st, a, no_group);
   }
 }
 
 // Returns 1 when the launch was taken by the LDS-DMA kernel, 0 when the shape is not eligible.
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st) {
-  if (batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
+  if (!d2r_is16(a.dtype) || batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
   if ((bn % 1000) == 129 && a.N < 128) return 0;
   if (!a.vecA || !a.vecB) return 0;
-  if (a.G && !(a.vecC && a.c_dtype == D2R_BF16)) return 0;  // the activation-gradient epilogue is in the vectorised path only
+  if (a.G && !(a.vecC && a.c_dtype == a.dtype)) return 0;  // the activation-gradient epilogue is in the vectorised path only
   const bool a_strided = layout == D2R_GEMM_TN, b_strided = layout != D2R_GEMM_NT;
   if ((a_strided && a.M % 8 != 0) || (b_strided && a.N % 8 != 0)) return 0;
+  const bool f16 = a.dtype == D2R_F16;
   switch (layout) {
-    case D2R_GEMM_NT: launch_glds<D2R_GEMM_NT>(a, bn, st); break;
-    case D2R_GEMM_NN: launch_glds<D2R_GEMM_NN>(a, bn, st); break;
-    case D2R_GEMM_TN: launch_glds<D2R_GEMM_TN>(a, bn, st); break;
+    case D2R_GEMM_NT: f16 ? launch_glds<f16_t, D2R_GEMM_NT>(a, bn, st) : launch_glds<bf16_t, D2R_GEMM_NT>(a, bn, st); break;
+    case D2R_GEMM_NN: f16 ? launch_glds<f16_t, D2R_GEMM_NN>(a, bn, st) : launch_glds<bf16_t, D2R_GEMM_NN>(a, bn, st); break;
+    case D2R_GEMM_TN: f16 ? launch_glds<f16_t, D2R_GEMM_TN>(a, bn, st) : launch_glds<bf16_t, D2R_GEMM_TN>(a, bn, st); break;
     default: return 0;
   }
   return 1;
@@ -417,8 +419,9 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
 // K-loop over the token rows, fp32 accumulate epilogue, bias gradients.  Returns 1 when taken, 0 when the shape is not
 // eligible (then the generic 64 x 64 kernel runs).
 int d2r_gemm_glds_wgrad_try(const GemmArgs& a, const GemmGroup& grp, int n, hipStream_t st) {
-  if (a.K < 128 || a.M < 128 || a.N < 128 || !a.vecA || !a.vecB || a.M % 8 != 0 || a.N % 8 != 0) return 0;
+  if (!d2r_is16(a.dtype) || a.K < 128 || a.M < 128 || a.N < 128 || !a.vecA || !a.vecB || a.M % 8 != 0 || a.N % 8 != 0) return 0;
   dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), n);
-  hipLaunchKernelGGL((gemm_glds_kernel<D2R_GEMM_TN, 128, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
+  if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
+  else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
   return 1;
 }

@@ -607,7 +607,7 @@ int check(const d2r_interaction_desc* D, const char* fn, bool bwd) {
 }  // namespace
 
 extern "C" int d2r_interaction_supported(int dtype, int Lq, int Lk, int ncell, int heads_imrc) {
-  if (dtype != D2R_BF16 || ncell < 2 || ncell > 6 || heads_imrc < 1 || heads_imrc > 64 || E % heads_imrc) return 0;
+  if (!d2r_is16(dtype) || ncell < 2 || ncell > 6 || heads_imrc < 1 || heads_imrc > 64 || E % heads_imrc) return 0;
   if (!d2r_xattn_supported(dtype, Lq, Lk, E)) return 0;
   if (ncell > 4 && !d2r_xattn_supported(dtype, Lq, Lq, E)) return 0;
   if (ncell > 2 && !d2r_mha_supported(dtype, Lq, Lq, E / heads_imrc)) return 0;

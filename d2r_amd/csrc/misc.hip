@@ -320,6 +320,7 @@ extern "C" int d2r_block_merge_fwd(int dtype, const void* m0, const void* m1, in
   dim3 grid(d2r_cdiv((int64_t)B * C, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((block_merge_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)m0, (const bf16_t*)m1, B, C, R, S, (bf16_t*)out, zraw);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((block_merge_fwd_kernel<f16_t>), grid, block, 0, st, (const f16_t*)m0, (const f16_t*)m1, B, C, R, S, (f16_t*)out, zraw);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((block_merge_fwd_kernel<float>), grid, block, 0, st, (const float*)m0, (const float*)m1, B, C, R, S, (float*)out, zraw);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_block_merge_fwd: bad dtype %d", dtype);
   return d2r_check_launch("d2r_block_merge_fwd");
@@ -330,6 +331,7 @@ extern "C" int d2r_block_merge_bwd(int dtype, const void* m0, const void* m1, co
   dim3 grid(d2r_cdiv((int64_t)B * C, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((block_merge_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)m0, (const bf16_t*)m1, zraw, (const bf16_t*)dout, B, C, R, S, (bf16_t*)dm0, (bf16_t*)dm1);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((block_merge_bwd_kernel<f16_t>), grid, block, 0, st, (const f16_t*)m0, (const f16_t*)m1, zraw, (const f16_t*)dout, B, C, R, S, (f16_t*)dm0, (f16_t*)dm1);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((block_merge_bwd_kernel<float>), grid, block, 0, st, (const float*)m0, (const float*)m1, zraw, (const float*)dout, B, C, R, S, (float*)dm0, (float*)dm1);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_block_merge_bwd: bad dtype %d", dtype);
   return d2r_check_launch("d2r_block_merge_bwd");
@@ -473,6 +475,7 @@ extern "C" int d2r_bert_embed_fwd(int dtype, const int64_t* ids, const int64_t* 
   dim3 grid(d2r_cdiv((int64_t)B * L, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((bert_embed_fwd_kernel<bf16_t>), grid, block, 0, st, ids, tt, word, pos, type, B, L, D, (bf16_t*)out);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((bert_embed_fwd_kernel<f16_t>), grid, block, 0, st, ids, tt, word, pos, type, B, L, D, (f16_t*)out);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((bert_embed_fwd_kernel<float>), grid, block, 0, st, ids, tt, word, pos, type, B, L, D, (float*)out);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_bert_embed_fwd: bad dtype %d", dtype);
   return d2r_check_launch("d2r_bert_embed_fwd");
@@ -495,6 +498,7 @@ extern "C" int d2r_bert_embed_bwd(int dtype, const void* dY, const int64_t* ids,
   D2R_REQUIRE(d2r_aligned16(dword) && (reinterpret_cast<uintptr_t>(dY) & 7u) == 0, "d2r_bert_embed_bwd: dword must be 16-byte, dY 8-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) launch_bert_embed_bwd<bf16_t>(dY, ids, tt, B, L, D, ntype, pad_id, dword, dpos, dtype_tab, st);
+  else if (dtype == D2R_F16) launch_bert_embed_bwd<f16_t>(dY, ids, tt, B, L, D, ntype, pad_id, dword, dpos, dtype_tab, st);
   else if (dtype == D2R_F32) launch_bert_embed_bwd<float>(dY, ids, tt, B, L, D, ntype, pad_id, dword, dpos, dtype_tab, st);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_bert_embed_bwd: bad dtype %d", dtype);
   return d2r_check_launch("d2r_bert_embed_bwd");
@@ -521,6 +525,7 @@ extern "C" int d2r_patchify(int dtype, const float* pixels, int B, int H, int W,
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, pixels, B, H, W, p, (bf16_t*)patches);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((patchify_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, pixels, B, H, W, p, (f16_t*)patches);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((patchify_kernel<float>), dim3(blocks), dim3(256), 0, st, pixels, B, H, W, p, (float*)patches);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_patchify: bad dtype %d", dtype);
   return d2r_check_launch("d2r_patchify");
@@ -544,6 +549,7 @@ extern "C" int d2r_clip_embed_finish(int dtype, void* x, const float* cls, const
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((clip_embed_finish_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (bf16_t*)x, cls, pos, B, ntok, D);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((clip_embed_finish_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, (f16_t*)x, cls, pos, B, ntok, D);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((clip_embed_finish_kernel<float>), dim3(blocks), dim3(256), 0, st, (float*)x, cls, pos, B, ntok, D);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_clip_embed_finish: bad dtype %d", dtype);
   return d2r_check_launch("d2r_clip_embed_finish");
@@ -557,6 +563,7 @@ extern "C" int d2r_clip_embed_bwd(int dtype, const void* dX, int B, int ntok, in
   D2R_REQUIRE(dX && dcls && dpos && B >= 1 && ntok >= 1 && D >= 1, "d2r_clip_embed_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((batch_sum_rows_kernel<bf16_t, false>), dim3(ntok), dim3(256), 0, st, (const bf16_t*)dX, B, ntok, D, dpos);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((batch_sum_rows_kernel<f16_t, false>), dim3(ntok), dim3(256), 0, st, (const f16_t*)dX, B, ntok, D, dpos);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((batch_sum_rows_kernel<float, false>), dim3(ntok), dim3(256), 0, st, (const float*)dX, B, ntok, D, dpos);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_clip_embed_bwd: bad dtype %d", dtype);
   hipLaunchKernelGGL(copy_row_kernel, dim3(d2r_cdiv(D, 256)), dim3(256), 0, st, (const float*)dpos, dcls, D);  // dcls = dpos[0]

@@ -61,7 +61,7 @@ extern "C" int d2r_meanpool_fwd(int dtype, const void* const* h_srcs, int nsrc, 
   D2R_REQUIRE(h_srcs && pooled, "d2r_meanpool_fwd: null pointer");
   D2R_REQUIRE(nsrc >= 1 && nsrc <= 8, "d2r_meanpool_fwd: nsrc=%d outside [1,8]", nsrc);
   D2R_REQUIRE(B >= 1 && L >= 1 && D >= 1, "d2r_meanpool_fwd: bad shape");
-  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  const int VEC = dtype != D2R_F32 ? 8 : 4;
   D2R_REQUIRE(D % VEC == 0, "d2r_meanpool_fwd: D=%d must be a multiple of %d", D, VEC);
   Ptrs8 ps;
   for (int i = 0; i < 8; ++i) ps.p[i] = i < nsrc ? h_srcs[i] : nullptr;
@@ -69,6 +69,7 @@ extern "C" int d2r_meanpool_fwd(int dtype, const void* const* h_srcs, int nsrc, 
   dim3 grid(d2r_cdiv(D, 16 * VEC), B, nsrc), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((meanpool_fwd_kernel<bf16_t>), grid, block, 0, st, ps, B, L, D, pooled);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((meanpool_fwd_kernel<f16_t>), grid, block, 0, st, ps, B, L, D, pooled);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((meanpool_fwd_kernel<float>), grid, block, 0, st, ps, B, L, D, pooled);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_meanpool_fwd: bad dtype %d", dtype);
   return d2r_check_launch("d2r_meanpool_fwd");
@@ -103,12 +104,13 @@ __global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restri
 extern "C" int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, int D, void* dX, int accumulate,
                                 void* stream) {
   D2R_REQUIRE(dpooled && dX && d2r_aligned16(dX), "d2r_meanpool_bwd: null or unaligned pointer");
-  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  const int VEC = dtype != D2R_F32 ? 8 : 4;
   D2R_REQUIRE(B >= 1 && L >= 1 && D % VEC == 0, "d2r_meanpool_bwd: bad shape");
   int blocks = d2r_cdiv((int64_t)B * L * (D / VEC), 256);
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == D2R_BF16) hipLaunchKernelGGL((meanpool_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, dpooled, B, L, D, (bf16_t*)dX, accumulate);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((meanpool_bwd_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, dpooled, B, L, D, (f16_t*)dX, accumulate);
   else if (dtype == D2R_F32) hipLaunchKernelGGL((meanpool_bwd_kernel<float>), dim3(blocks), dim3(256), 0, st, dpooled, B, L, D, (float*)dX, accumulate);
   else return d2r_fail(D2R_ERR_INVALID, "d2r_meanpool_bwd: bad dtype %d", dtype);
   return d2r_check_launch("d2r_meanpool_bwd");
@@ -257,8 +259,8 @@ extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, con
   D2R_REQUIRE(P == ncell || P == 1, "d2r_route_aggregate_fwd: P=%d (must be ncell=%d or 1)", P, ncell);
   D2R_REQUIRE(P != 1 || h_refs, "d2r_route_aggregate_fwd: the final layer needs refs");
   D2R_REQUIRE(ld_probs >= (int64_t)P * ncell, "d2r_route_aggregate_fwd: ld_probs %lld < P*ncell", (long long)ld_probs);
-  D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_route_aggregate_fwd: bad dtype %d", dtype);
-  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16 || dtype == D2R_F16, "d2r_route_aggregate_fwd: bad dtype %d", dtype);
+  const int VEC = dtype != D2R_F32 ? 8 : 4;
   D2R_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D % VEC == 0, "d2r_route_aggregate_fwd: bad shape B=%d L=%d D=%d", B, L, D);
   Ptrs8 e{}, r{};
   MPtrs8 o{};
@@ -278,9 +280,11 @@ extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, con
   hipStream_t st = (hipStream_t)stream;
   if (P != 1) {
     if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd6_kernel<bf16_t>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs, ld_probs);
+    else if (dtype == D2R_F16) hipLaunchKernelGGL((agg_fwd6_kernel<f16_t>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs, ld_probs);
     else hipLaunchKernelGGL((agg_fwd6_kernel<float>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs, ld_probs);
   } else {
     if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd1_kernel<bf16_t>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (bf16_t*)o.p[0], probs, ld_probs);
+    else if (dtype == D2R_F16) hipLaunchKernelGGL((agg_fwd1_kernel<f16_t>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (f16_t*)o.p[0], probs, ld_probs);
     else hipLaunchKernelGGL((agg_fwd1_kernel<float>), grid, block, 0, st, e, r, gates, B, L, D, ncell, (float*)o.p[0], probs, ld_probs);
   }
   return d2r_check_launch("d2r_route_aggregate_fwd");
@@ -633,8 +637,8 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
   D2R_REQUIRE(ncell >= 2 && ncell <= 6, "d2r_route_aggregate_bwd: ncell=%d (2..6)", ncell);
   D2R_REQUIRE(P == ncell || P == 1, "d2r_route_aggregate_bwd: P=%d (must be ncell=%d or 1)", P, ncell);
   D2R_REQUIRE(P != 1 || (h_refs && h_drefs && h_outs), "d2r_route_aggregate_bwd: the final layer needs refs, d_refs and outs");
-  D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16, "d2r_route_aggregate_bwd: bad dtype %d", dtype);
-  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  D2R_REQUIRE(dtype == D2R_F32 || dtype == D2R_BF16 || dtype == D2R_F16, "d2r_route_aggregate_bwd: bad dtype %d", dtype);
+  const int VEC = dtype != D2R_F32 ? 8 : 4;
   D2R_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D % VEC == 0 && D / VEC <= 256, "d2r_route_aggregate_bwd: bad shape B=%d L=%d D=%d", B, L, D);
   if (!workspace || workspace_bytes < d2r_route_aggregate_bwd_workspace(B, L, D, P))
     return d2r_fail(D2R_ERR_WORKSPACE, "d2r_route_aggregate_bwd: workspace %zu < %zu", workspace_bytes, d2r_route_aggregate_bwd_workspace(B, L, D, P));
@@ -666,6 +670,9 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     if (dtype == D2R_BF16) {
       hipLaunchKernelGGL((agg_bwd6_kernel<bf16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
       hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+    } else if (dtype == D2R_F16) {
+      hipLaunchKernelGGL((agg_bwd6_kernel<f16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd6_finish_kernel<f16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (f16_t*)de.p[1], (f16_t*)de.p[5], d_gates);
     } else {
       hipLaunchKernelGGL((agg_bwd6_kernel<float>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
       hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (float*)de.p[1], (float*)de.p[5], d_gates);
@@ -678,6 +685,9 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     if (dtype == D2R_BF16) {
       hipLaunchKernelGGL((agg_bwd1_kernel<bf16_t>), grid, block, shmem, st, e, r, gates, (const bf16_t*)dv.p[0], (const bf16_t*)outp, B, L, D, ncell, de, dr, ws_dots, ws_bc);
       hipLaunchKernelGGL((agg_bwd1_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
+    } else if (dtype == D2R_F16) {
+      hipLaunchKernelGGL((agg_bwd1_kernel<f16_t>), grid, block, shmem, st, e, r, gates, (const f16_t*)dv.p[0], (const f16_t*)outp, B, L, D, ncell, de, dr, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd1_finish_kernel<f16_t>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (f16_t*)de.p[1], (f16_t*)de.p[5], d_gates);
     } else {
       hipLaunchKernelGGL((agg_bwd1_kernel<float>), grid, block, shmem, st, e, r, gates, (const float*)dv.p[0], (const float*)outp, B, L, D, ncell, de, dr, ws_dots, ws_bc);
       hipLaunchKernelGGL((agg_bwd1_finish_kernel<float>), dim3(B, d2r_cdiv(D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (float*)de.p[1], (float*)de.p[5], d_gates);

@@ -102,7 +102,9 @@ extern "C" int d2r_softmax_fwd(int x_dtype, int y_dtype, const void* X, void* Y,
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == D2R_F32 && y_dtype == D2R_F32) return softmax_fwd_launch<float, float>(X, Y, ld, rows, cols, scale, mask, rows_per_mask, st);
   if (x_dtype == D2R_F32 && y_dtype == D2R_BF16) return softmax_fwd_launch<float, bf16_t>(X, Y, ld, rows, cols, scale, mask, rows_per_mask, st);
+  else if (x_dtype == D2R_F32 && y_dtype == D2R_F16) return softmax_fwd_launch<float, f16_t>(X, Y, ld, rows, cols, scale, mask, rows_per_mask, st);
   if (x_dtype == D2R_BF16 && y_dtype == D2R_BF16) return softmax_fwd_launch<bf16_t, bf16_t>(X, Y, ld, rows, cols, scale, mask, rows_per_mask, st);
+  else if (x_dtype == D2R_F16 && y_dtype == D2R_F16) return softmax_fwd_launch<f16_t, f16_t>(X, Y, ld, rows, cols, scale, mask, rows_per_mask, st);
   return d2r_fail(D2R_ERR_INVALID, "d2r_softmax_fwd: unsupported dtypes %d -> %d", x_dtype, y_dtype);
 }
 
@@ -129,7 +131,9 @@ extern "C" int d2r_softmax_bwd(int p_dtype, int dp_dtype, const void* P, const v
   hipStream_t st = (hipStream_t)stream;
   if (p_dtype == D2R_F32 && dp_dtype == D2R_F32) return softmax_bwd_launch<float, float>(P, dP, dS, ld, rows, cols, scale, st);
   if (p_dtype == D2R_BF16 && dp_dtype == D2R_F32) return softmax_bwd_launch<bf16_t, float>(P, dP, dS, ld, rows, cols, scale, st);
+  else if (p_dtype == D2R_F16 && dp_dtype == D2R_F32) return softmax_bwd_launch<f16_t, float>(P, dP, dS, ld, rows, cols, scale, st);
   if (p_dtype == D2R_BF16 && dp_dtype == D2R_BF16) return softmax_bwd_launch<bf16_t, bf16_t>(P, dP, dS, ld, rows, cols, scale, st);
+  else if (p_dtype == D2R_F16 && dp_dtype == D2R_F16) return softmax_bwd_launch<f16_t, f16_t>(P, dP, dS, ld, rows, cols, scale, st);
   return d2r_fail(D2R_ERR_INVALID, "d2r_softmax_bwd: unsupported dtypes %d / %d", p_dtype, dp_dtype);
 }
 
@@ -361,6 +365,10 @@ extern "C" int d2r_layernorm_fwd(int dtype, const void* X, const float* gamma, c
     if (int rc = ln_check<bf16_t>("d2r_layernorm_fwd", D)) return rc;
     if (D <= 64 * 8 * 2) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 2>), grid, block, 0, st, (const bf16_t*)X, gamma, beta, eps, rows, D, (bf16_t*)Y, mean, rstd);
     else hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 4>), grid, block, 0, st, (const bf16_t*)X, gamma, beta, eps, rows, D, (bf16_t*)Y, mean, rstd);
+  } else if (dtype == D2R_F16) {
+    if (int rc = ln_check<f16_t>("d2r_layernorm_fwd", D)) return rc;
+    if (D <= 64 * 8 * 2) hipLaunchKernelGGL((layernorm_fwd_kernel<f16_t, 2>), grid, block, 0, st, (const f16_t*)X, gamma, beta, eps, rows, D, (f16_t*)Y, mean, rstd);
+    else hipLaunchKernelGGL((layernorm_fwd_kernel<f16_t, 4>), grid, block, 0, st, (const f16_t*)X, gamma, beta, eps, rows, D, (f16_t*)Y, mean, rstd);
   } else if (dtype == D2R_F32) {
     if (int rc = ln_check<float>("d2r_layernorm_fwd", D)) return rc;
     hipLaunchKernelGGL((layernorm_fwd_kernel<float, 4>), grid, block, 0, st, (const float*)X, gamma, beta, eps, rows, D, (float*)Y, mean, rstd);
@@ -387,6 +395,11 @@ extern "C" int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, co
     // register arrays are sized by MAXP = ceil(D / (64 lanes * 8)): D=768 needs 2, not 4 (occupancy)
     if (D <= 64 * 8 * 2) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 2>), dim3(nb), dim3(256), shmem, st, (const bf16_t*)dY, (const bf16_t*)X, gamma, mean, rstd, rows, D, (bf16_t*)dX, ws, (const bf16_t*)dres);
     else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 4>), dim3(nb), dim3(256), shmem, st, (const bf16_t*)dY, (const bf16_t*)X, gamma, mean, rstd, rows, D, (bf16_t*)dX, ws, (const bf16_t*)dres);
+  } else if (dtype == D2R_F16) {
+    if (int rc = ln_check<f16_t>("d2r_layernorm_bwd", D)) return rc;
+    // register arrays are sized by MAXP = ceil(D / (64 lanes * 8)): D=768 needs 2, not 4 (occupancy)
+    if (D <= 64 * 8 * 2) hipLaunchKernelGGL((layernorm_bwd_kernel<f16_t, 2>), dim3(nb), dim3(256), shmem, st, (const f16_t*)dY, (const f16_t*)X, gamma, mean, rstd, rows, D, (f16_t*)dX, ws, (const f16_t*)dres);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<f16_t, 4>), dim3(nb), dim3(256), shmem, st, (const f16_t*)dY, (const f16_t*)X, gamma, mean, rstd, rows, D, (f16_t*)dX, ws, (const f16_t*)dres);
   } else if (dtype == D2R_F32) {
     if (int rc = ln_check<float>("d2r_layernorm_bwd", D)) return rc;
     if (D <= 64 * 4 * 3) hipLaunchKernelGGL((layernorm_bwd_kernel<float, 3>), dim3(nb), dim3(256), shmem, st, (const float*)dY, (const float*)X, gamma, mean, rstd, rows, D, (float*)dX, ws, (const float*)dres);
@@ -502,6 +515,9 @@ extern "C" int d2r_l2norm_fwd(int dtype, const void* X, void* Y, float* norm, in
   if (dtype == D2R_BF16) {
     if (int rc = ln_check<bf16_t>("d2r_l2norm_fwd", D)) return rc;
     hipLaunchKernelGGL((l2norm_fwd_kernel<bf16_t, 4>), grid, block, 0, st, (const bf16_t*)X, (bf16_t*)Y, norm, rows, D);
+  } else if (dtype == D2R_F16) {
+    if (int rc = ln_check<f16_t>("d2r_l2norm_fwd", D)) return rc;
+    hipLaunchKernelGGL((l2norm_fwd_kernel<f16_t, 4>), grid, block, 0, st, (const f16_t*)X, (f16_t*)Y, norm, rows, D);
   } else if (dtype == D2R_F32) {
     if (int rc = ln_check<float>("d2r_l2norm_fwd", D)) return rc;
     hipLaunchKernelGGL((l2norm_fwd_kernel<float, 4>), grid, block, 0, st, (const float*)X, (float*)Y, norm, rows, D);
@@ -521,6 +537,9 @@ extern "C" int d2r_l2norm_bwd(int dtype, const void* dY, const void* X, const fl
   if (dtype == D2R_BF16) {
     if (int rc = ln_check<bf16_t>("d2r_l2norm_bwd", D)) return rc;
     hipLaunchKernelGGL((l2norm_bwd_kernel<bf16_t, 4>), grid, block, 0, st, (const bf16_t*)dY, (const bf16_t*)X, norm, (bf16_t*)dX, rows, D);
+  } else if (dtype == D2R_F16) {
+    if (int rc = ln_check<f16_t>("d2r_l2norm_bwd", D)) return rc;
+    hipLaunchKernelGGL((l2norm_bwd_kernel<f16_t, 4>), grid, block, 0, st, (const f16_t*)dY, (const f16_t*)X, norm, (f16_t*)dX, rows, D);
   } else if (dtype == D2R_F32) {
     if (int rc = ln_check<float>("d2r_l2norm_bwd", D)) return rc;
     hipLaunchKernelGGL((l2norm_bwd_kernel<float, 4>), grid, block, 0, st, (const float*)dY, (const float*)X, norm, (float*)dX, rows, D);
@@ -589,14 +608,16 @@ extern "C" int d2r_colsum(int dtype, const void* X, int64_t ld, int64_t M, int N
   const int S = colsum_slices(M);
   dim3 grid(d2r_cdiv(N, 256), S), block(256);
   float* ws = (float*)workspace;
-  if (dtype != D2R_BF16 && dtype != D2R_F32) return d2r_fail(D2R_ERR_INVALID, "d2r_colsum: bad dtype %d", dtype);
-  const int VEC = dtype == D2R_BF16 ? 8 : 4;
+  if (dtype != D2R_BF16 && dtype != D2R_F16 && dtype != D2R_F32) return d2r_fail(D2R_ERR_INVALID, "d2r_colsum: bad dtype %d", dtype);
+  const int VEC = dtype != D2R_F32 ? 8 : 4;
   const bool vec = d2r_aligned16(X) && (ld * (int64_t)d2r_esize(dtype)) % 16 == 0 && N % VEC == 0;
   if (vec) {
     dim3 gv(d2r_cdiv(N, 64 * VEC), S);
     if (dtype == D2R_BF16) hipLaunchKernelGGL((colsum_vec_kernel<bf16_t>), gv, block, 0, st, (const bf16_t*)X, ld, M, N, ws);
+    else if (dtype == D2R_F16) hipLaunchKernelGGL((colsum_vec_kernel<f16_t>), gv, block, 0, st, (const f16_t*)X, ld, M, N, ws);
     else hipLaunchKernelGGL((colsum_vec_kernel<float>), gv, block, 0, st, (const float*)X, ld, M, N, ws);
   } else if (dtype == D2R_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)X, ld, M, N, ws);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((colsum_kernel<f16_t>), grid, block, 0, st, (const f16_t*)X, ld, M, N, ws);
   else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)X, ld, M, N, ws);
   if (int rc = d2r_check_launch("d2r_colsum")) return rc;
   hipLaunchKernelGGL(sum_partials_kernel, dim3(d2r_cdiv(N, 64)), dim3(256), 0, st, ws, S, N, N, out);

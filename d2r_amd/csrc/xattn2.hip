@@ -26,11 +26,10 @@
 
 namespace {
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t2;
-
+template <typename E>
 struct X2Args {
-  const bf16_t *q, *k, *v, *res;
-  bf16_t* o;
+  const E *q, *k, *v, *res;
+  E* o;
   const float* mask;
   float* lse;
   int64_t ldq, sqb, ldk, skb, ldv, svb, ldo, sob, ldr, srb;
@@ -57,8 +56,10 @@ struct X2Lds {
   static_assert(QT * (XE + 8) * 2 <= NB * CB, "the output tile is staged in the ring");
 };
 
-template <int NQT, int LKMAX>
-__global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args a) {
+template <typename E, int NQT, int LKMAX>
+__global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
+  typedef typename H16<E>::v8 E8;
+  typedef typename H16<E>::v4 E4;
   using L = X2Lds<NQT, LKMAX>;
   constexpr int QT = L::QT, LSS = L::LSS;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[L::TOTAL];
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args a) {
   }
   if (b >= a.B) return;
   const int q0 = tile * QT;
-  const bf16_t* Kg = a.k + b * a.skb;
-  const bf16_t* Vg = a.v + b * a.svb;
+  const E* Kg = a.k + b * a.skb;
+  const E* Vg = a.v + b * a.svb;
   float* Sm = reinterpret_cast<float*>(smem + L::S);
   float* Sp = reinterpret_cast<float*>(smem + L::SPART);
   float* Ms = reinterpret_cast<float*>(smem + L::MS);
@@ -84,13 +85,13 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args a) {
   // key mask into LDS and the Q fragments of this wave's 96-feature slice into registers BEFORE the DMA stream starts
   // (an ordinary global load beside in-flight LDS-DMA makes the compiler drain the whole queue)
   for (int key = tid; key < LKMAX; key += 512) Ms[key] = key < a.Lk ? (a.mask ? a.mask[(int64_t)b * a.Lk + key] : 0.f) : -INFINITY;
-  bf16x8 qf[NQT][3];
+  E8 qf[NQT][3];
 #pragma unroll
   for (int t = 0; t < NQT; ++t) {
     const int qrow = min(q0 + t * 16 + fr, a.Lq - 1);
-    const bf16_t* qp = a.q + b * a.sqb + (int64_t)qrow * a.ldq + wave * 96 + fq * 8;
+    const E* qp = a.q + b * a.sqb + (int64_t)qrow * a.ldq + wave * 96 + fq * 8;
 #pragma unroll
-    for (int kk = 0; kk < 3; ++kk) qf[t][kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 32);
+    for (int kk = 0; kk < 3; ++kk) qf[t][kk] = *reinterpret_cast<const E8*>(qp + kk * 32);
   }
   // per-lane source of this wave's three 1-KiB pieces of a chunk image [16 rows][1536 B]
   int prow[3], pcol[3];
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args a) {
   }
   auto issue = [&](int g) {
     const bool isv = g >= nkc;
-    const bf16_t* src = isv ? Vg : Kg;
+    const E* src = isv ? Vg : Kg;
     const int64_t ld = isv ? a.ldv : a.ldk;
     const int key0 = (isv ? g - nkc : g) * CH;
     unsigned char* base = smem + L::RING + (g & (NB - 1)) * CB;
@@ -140,9 +141,9 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args a) {
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) {
       const int c = wave * 12 + kk * 4 + fq;
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(slot + fr * ROWB + swz(c, fr) * 16);
+      const E8 kf = *reinterpret_cast<const E8*>(slot + fr * ROWB + swz(c, fr) * 16);
 #pragma unroll
-      for (int t = 0; t < NQT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][kk], s[t], 0, 0, 0);
+      for (int t = 0; t < NQT; ++t) s[t] = H16<E>::mfma32(kf, qf[t][kk], s[t]);
     }
     // s[t][r] = partial S[key = fq*4 + r][q = fr] over this wave's 96 features
 #pragma unroll
@@ -181,11 +182,11 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args a) {
       const float inv = 1.f / sum;
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();  // every lane has its scores in registers before the row is overwritten
-      bf16_t* Prow = reinterpret_cast<bf16_t*>(Sm + row * LSS);
+      E* Prow = reinterpret_cast<E*>(Sm + row * LSS);
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int key = lane + 64 * i;
-        if (key < nkeys) Prow[key] = (bf16_t)(v[i] * inv);
+        if (key < nkeys) Prow[key] = (E)(v[i] * inv);
       }
       if (lane == 0 && q0 + row < a.Lq) a.lse[(int64_t)b * a.Lq + q0 + row] = mx + logf(sum);
     }
@@ -214,60 +215,57 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args a) {
     const unsigned char* slot = smem + L::RING + (g & (NB - 1)) * CB;
     const int key0 = (g - nkc) * CH;
     if (a.dbg == 2) continue;
-    bf16x4 pf[NQT];
+    E4 pf[NQT];
 #pragma unroll
-    for (int t = 0; t < NQT; ++t) pf[t] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(Sm + (t * 16 + fr) * LSS) + key0 + fq * 4);
+    for (int t = 0; t < NQT; ++t) pf[t] = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(Sm + (t * 16 + fr) * LSS) + key0 + fq * 4);
     const int vrow = fq * 4 + tq;
-    bf16x4 vf[6];
+    E4 vf[6];
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
       const int c = wave * 12 + dt * 2 + (tp >> 1);
-      vf[dt] = lds_tr_read(slot + vrow * ROWB + swz(c, vrow) * 16 + (tp & 1) * 8);
+      vf[dt] = lds_tr_read<E4>(slot + vrow * ROWB + swz(c, vrow) * 16 + (tp & 1) * 8);
     }
     lds_reads_done();
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
 #pragma unroll
-      for (int t = 0; t < NQT; ++t) o[dt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[dt], pf[t], o[dt][t], 0, 0, 0);
+      for (int t = 0; t < NQT; ++t) o[dt][t] = H16<E>::mfma16(vf[dt], pf[t], o[dt][t]);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the ring is dead: it now stages the output tile
   // ---- epilogue: o[dt][t][r] = O[q = t*16 + fr][d = wave*96 + dt*16 + fq*4 + r] -> LDS rows -> whole-row global stores ----
   constexpr int LDO = XE + 8;
-  bf16_t* Os = reinterpret_cast<bf16_t*>(smem + L::RING);
+  E* Os = reinterpret_cast<E*>(smem + L::RING);
 #pragma unroll
   for (int t = 0; t < NQT; ++t)
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
-      Pack<bf16_t, 4> pk;
+      Pack<E, 4> pk;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pk.v[r] = (bf16_t)o[dt][t][r];
-      st_pack<bf16_t, 4>(Os + (t * 16 + fr) * LDO + wave * 96 + dt * 16 + fq * 4, pk);
+      for (int r = 0; r < 4; ++r) pk.v[r] = (E)o[dt][t][r];
+      st_pack<E, 4>(Os + (t * 16 + fr) * LDO + wave * 96 + dt * 16 + fq * 4, pk);
     }
   __syncthreads();
   for (int e = tid; e < QT * (XE / 8); e += 512) {
     const int row = e / (XE / 8), ch = e - row * (XE / 8);
     const int qrow = q0 + row;
     if (qrow >= a.Lq) continue;
-    Pack<bf16_t, 8> v = ld_pack<bf16_t, 8>(Os + row * LDO + ch * 8);
+    Pack<E, 8> v = ld_pack<E, 8>(Os + row * LDO + ch * 8);
     if (a.res) {
-      const Pack<bf16_t, 8> rv = ld_pack<bf16_t, 8>(a.res + b * a.srb + (int64_t)qrow * a.ldr + ch * 8);
+      const Pack<E, 8> rv = ld_pack<E, 8>(a.res + b * a.srb + (int64_t)qrow * a.ldr + ch * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v.v[j] = (bf16_t)((float)v.v[j] + (float)rv.v[j]);
+      for (int j = 0; j < 8; ++j) v.v[j] = (E)((float)v.v[j] + (float)rv.v[j]);
     }
-    st_pack<bf16_t, 8>(a.o + b * a.sob + (int64_t)qrow * a.ldo + ch * 8, v);
+    st_pack<E, 8>(a.o + b * a.sob + (int64_t)qrow * a.ldo + ch * 8, v);
   }
 }
 
-}  // namespace
-
-// Host entry used by d2r_xattn_fwd (attention.hip).  Returns 1 when the launch was taken.
-int d2r_xattn2_fwd_try(const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb, const void* v, int64_t ldv,
-                       int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual, int64_t ldr, int64_t srb, const float* mask,
-                       float* lse, int B, int Lq, int Lk, float scale, hipStream_t st) {
-  if (Lk > 640 || Lk < 1 || Lq < 1) return 0;
-  X2Args a = {};
-  a.q = (const bf16_t*)q, a.k = (const bf16_t*)k, a.v = (const bf16_t*)v, a.res = (const bf16_t*)residual, a.o = (bf16_t*)o;
+template <typename E>
+static int x2_launch(const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb, const void* v, int64_t ldv,
+                     int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual, int64_t ldr, int64_t srb, const float* mask,
+                     float* lse, int B, int Lq, int Lk, float scale, hipStream_t st) {
+  X2Args<E> a = {};
+  a.q = (const E*)q, a.k = (const E*)k, a.v = (const E*)v, a.res = (const E*)residual, a.o = (E*)o;
   a.mask = mask, a.lse = lse;
   a.ldq = ldq, a.sqb = sqb, a.ldk = ldk, a.skb = skb, a.ldv = ldv, a.svb = svb, a.ldo = ldo, a.sob = sob, a.ldr = ldr, a.srb = srb;
   a.B = B, a.Lq = Lq, a.Lk = Lk, a.scale = scale;
@@ -279,14 +277,26 @@ int d2r_xattn2_fwd_try(const void* q, int64_t ldq, int64_t sqb, const void* k, i
     const int nt32 = (Lq + 31) / 32;
     if (nt32 * B >= 192) {
       a.ntile = nt32;
-      hipLaunchKernelGGL((xattn2_fwd_kernel<2, 256>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
+      hipLaunchKernelGGL((xattn2_fwd_kernel<E, 2, 256>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
     } else {
       a.ntile = (Lq + 15) / 16;
-      hipLaunchKernelGGL((xattn2_fwd_kernel<1, 256>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
+      hipLaunchKernelGGL((xattn2_fwd_kernel<E, 1, 256>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
     }
   } else {
     a.ntile = (Lq + 15) / 16;
-    hipLaunchKernelGGL((xattn2_fwd_kernel<1, 640>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((xattn2_fwd_kernel<E, 1, 640>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
   }
   return 1;
+}
+
+}  // namespace
+
+// Host entry used by d2r_xattn_fwd (attention.hip).  Returns 1 when the launch was taken.
+int d2r_xattn2_fwd_try(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb, const void* v,
+                       int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual, int64_t ldr, int64_t srb,
+                       const float* mask, float* lse, int B, int Lq, int Lk, float scale, hipStream_t st) {
+  if (Lk > 640 || Lk < 1 || Lq < 1) return 0;
+  if (dtype == D2R_F16)
+    return x2_launch<f16_t>(q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, Lq, Lk, scale, st);
+  return x2_launch<bf16_t>(q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, Lq, Lk, scale, st);
 }

@@ -4,7 +4,7 @@ are launches of the hand-written gfx950 kernels in libd2r_hip.so (C ABI: include
 PyTorch supplies device memory, the current HIP stream and the autograd tape — no arithmetic.  Nothing here
 falls back to ATen: a missing library or a failing launch raises ``d2r_amd._lib.D2RError``.
 
-dtype policy: activations and GEMM weights are ``T`` in {float32, bfloat16}; accumulation, softmax logits and
+dtype policy: activations and GEMM weights are ``T`` in {float32, bfloat16, float16}; accumulation, softmax logits and
 statistics, router gates, biases, LayerNorm parameters, losses and every reduction are fp32.
 """
 from __future__ import annotations
@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_TANH_RELU, BF16, F32,
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_TANH_RELU, BF16, F16, F32,
                    GEMM_NN, GEMM_NT, GEMM_TN, GemmDesc)
 
 _ACT_FROM_OUTPUT = (ACT_RELU, ACT_TANH, ACT_TANH_RELU, ACT_SIGMOID)
@@ -33,12 +33,20 @@ def _stream() -> int:
     return _raw_stream(_current_device())
 
 
+LOWP = (torch.bfloat16, torch.float16)  # the 16-bit compute dtypes: same kernels, the MFMA operand type differs
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_DT_NAME = {F32: "f32", BF16: "bf16", F16: "f16"}
+
+
+def _dt_of(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"d2r_amd supports float32 / bfloat16 / float16 tensors, got {dtype}") from None
+
+
 def _dt(t: torch.Tensor) -> int:
-    if t.dtype == torch.float32:
-        return F32
-    if t.dtype == torch.bfloat16:
-        return BF16
-    raise TypeError(f"d2r_amd supports float32/bfloat16 tensors, got {t.dtype}")
+    return _dt_of(t.dtype)
 
 
 def _require_cuda(*ts):
@@ -148,8 +156,8 @@ def _flush_wgrad_group(key, jobs):
     D = _iparr([j[3] for j in jobs]) if has_b else None
     meta = None
     if _lib._timer is not None:
-        meta = dict(group=f"gemm_{'bf16' if dt == BF16 else 'f32'}_TN", flops=2.0 * n * M * N * K,
-                    bytes=float(n) * ((M * N + M * K) * (2 if dt == BF16 else 4) + 2 * N * K * 4))
+        meta = dict(group=f"gemm_{_DT_NAME[dt]}_TN_grouped", flops=2.0 * n * M * N * K,
+                    bytes=float(n) * ((M * N + M * K) * (4 if dt == F32 else 2) + 2 * N * K * 4))
     _lib.call("d2r_gemm_tn_grouped", dt, N, K, M, N, lda_x, K, A, B, Cc, D, n, 1.0, _stream(), meta=meta)
     for j in jobs:  # data-parallel bucket readiness (d2r_amd.dp)
         for p in j[4]:
@@ -274,8 +282,8 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cc, ldc, *, dtype, c_dtype, nb=1, nh=1
         d.workspace, d.workspace_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
     meta = None
     if _lib._timer is not None:  # algorithmic flops / bytes of this launch for bench.py's roofline
-        z, es, cs = nb * nh, (2 if dtype == BF16 else 4), (2 if c_dtype == BF16 else 4)
-        meta = dict(group=tag or f"gemm_{'bf16' if dtype == BF16 else 'f32'}_{('NT', 'NN', 'TN')[layout]}",
+        z, es, cs = nb * nh, (4 if dtype == F32 else 2), (4 if c_dtype == F32 else 2)
+        meta = dict(group=tag or f"gemm_{_DT_NAME[dtype]}_{('NT', 'NN', 'TN')[layout]}",
                     flops=2.0 * M * N * K * z,
                     bytes=float(z) * ((M * K + N * K) * es + M * N * cs * (2 if (beta != 0.0 or residual) else 1)))
     _lib.call("d2r_gemm", C.byref(d), _stream() if stream is None else stream, meta=meta)
@@ -526,7 +534,7 @@ def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device, p_drop=0.0)
     B, Lq, Lk, E = geo
     d = E // H
     Lkp = (Lk + 7) // 8 * 8
-    dt = BF16 if dtype == torch.bfloat16 else F32
+    dt = _dt_of(dtype)
     tag = "xattn_core_fwd" if H == 1 else "mha_core_fwd"
     if p_drop <= 0.0 and FUSED_MHA and H > 1 and _lib.load().d2r_mha_supported(dt, Lq, Lk, d):
         # one launch, scores/probabilities stay in registers; the saved state is the row log-sum-exp, not P
@@ -547,7 +555,7 @@ def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device, p_drop=0.0)
     gemm(GEMM_NT, Lq, Lk, d, q[0], q[1], k[0], k[1], S.data_ptr(), Lkp, dtype=dt, c_dtype=F32, nb=B, nh=H,
          sA=(q[2], d), sB=(k[2], d), sC=(H * Lq * Lkp, Lq * Lkp), tag=tag)
     if _lib._timer is not None:  # algorithmic bytes of the fused core = B(2Lq+2Lk)D s
-        _lib._timer.records[-1][1]["algo_bytes"] = float(B * (2 * Lq + 2 * Lk) * E * (2 if dt == BF16 else 4))
+        _lib._timer.records[-1][1]["algo_bytes"] = float(B * (2 * Lq + 2 * Lk) * E * (4 if dt == F32 else 2))
     P = S if dtype == torch.float32 else torch.empty(B, H, Lq, Lkp, dtype=dtype, device=device)
     _lib.call("d2r_softmax_fwd", F32, dt, S.data_ptr(), P.data_ptr(), Lkp, B * H * Lq, Lk, scale, _ptr(mask), H * Lq,
               _stream(), meta=dict(group=tag))  # padding columns of P are never read (K = Lk below)
@@ -568,7 +576,7 @@ def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None
     of the unfused forward, or the fp32 log-sum-exp [B,H,Lq] of the fused one."""
     B, Lq, Lk, E = geo
     d = E // H
-    dt = BF16 if dtype == torch.bfloat16 else F32
+    dt = _dt_of(dtype)
     tag = "xattn_core_bwd" if H == 1 else "mha_core_bwd"
     if P.dim() == 3 and H == 1:  # fused single-head forward: dS, P and dQ in one launch, then the two key-side GEMMs
         Lkp = (Lk + 7) // 8 * 8
@@ -721,7 +729,7 @@ def attention_kv(q, kv, num_heads, scale, mask=None, residual=None, p_drop=0.0):
 
 
 # ------------------------------------------------------------------------------------------------------
-# K15 whole encoder layer (bf16): one C call forward, one backward
+# K15 whole encoder layer (16-bit compute dtypes): one C call forward, one backward
 # ------------------------------------------------------------------------------------------------------
 class LayerBundle:
     """Pointers of one encoder layer's parameters and fp32 gradient sinks (stable across steps: they live in the flat
@@ -732,12 +740,14 @@ class LayerBundle:
         self.params = [t for pair in (qkv, o, fc1, fc2, ln1, ln2) for t in pair]
         if any(getattr(t, "_d2r_grad", None) is None for t in self.params) or any(
                 getattr(w, "_d2r_lp", None) is None for w in (qkv[0], o[0], fc1[0], fc2[0])):
-            raise _lib.D2RError("LayerBundle needs a model prepared by ParamStore with a bf16 shadow")
+            raise _lib.D2RError("LayerBundle needs a model prepared by ParamStore with a 16-bit weight shadow")
         E, Fi = o[0].shape[0], fc1[0].shape[0]
         assert qkv[0].shape == (3 * E, E) and fc2[0].shape == (E, Fi)
         self.E, self.F, self.H = E, Fi, H
         t = _lib.EncoderLayerDesc()
-        t.dtype, t.pre_ln, t.act, t.E, t.H, t.F, t.eps, t.scale = BF16, int(pre_ln), act, E, H, Fi, eps, float((E // H) ** -0.5)
+        self.tdtype = qkv[0]._d2r_lp.dtype  # the 16-bit compute dtype of the shadow: bf16 or fp16
+        self.dt = _dt_of(self.tdtype)
+        t.dtype, t.pre_ln, t.act, t.E, t.H, t.F, t.eps, t.scale = self.dt, int(pre_ln), act, E, H, Fi, eps, float((E // H) ** -0.5)
         for name, (w, b) in (("qkv", qkv), ("o", o), ("1", fc1), ("2", fc2)):
             setattr(t, "w_" + name, w._d2r_lp.data_ptr())
             setattr(t, "b_" + name, b.data_ptr())
@@ -752,8 +762,8 @@ class LayerBundle:
         self.key = (qkv[0]._d2r_lp.data_ptr(), qkv[0]._d2r_grad.data_ptr())
 
     def supports(self, x) -> bool:
-        return (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.shape[-1] == self.E
-                and bool(_lib.load().d2r_mha_supported(BF16, x.shape[1], x.shape[1], self.E // self.H)))
+        return (x.dtype == self.tdtype and x.is_cuda and x.dim() == 3 and x.shape[-1] == self.E
+                and bool(_lib.load().d2r_mha_supported(self.dt, x.shape[1], x.shape[1], self.E // self.H)))
 
 
 _SCRATCH = {}
@@ -778,7 +788,7 @@ class _EncoderLayer(torch.autograd.Function):
         C.memmove(C.byref(d), C.byref(bundle.template), C.sizeof(d))
         d.B, d.L = B, L
         d.mask = _ptr(mask)
-        acts = torch.empty(T * (7 * E + 2 * Fi), dtype=torch.bfloat16, device=x.device)  # qkv ctx h1 n1 h2 | f_pre f
+        acts = torch.empty(T * (7 * E + 2 * Fi), dtype=x.dtype, device=x.device)  # qkv ctx h1 n1 h2 | f_pre f
         stats = torch.empty(B * H * L + 4 * T, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         a0, s0 = acts.data_ptr(), stats.data_ptr()
@@ -832,7 +842,7 @@ class _EncoderLayer(torch.autograd.Function):
             ffn_in = d.h2 if d.pre_ln else d.n1
             for which, (N, K, xin, gw, gb) in enumerate(((3 * E, E, attn_in, d.gw_qkv, d.gb_qkv), (E, E, d.ctx, d.gw_o, d.gb_o),
                                                           (Fi, E, ffn_in, d.gw_1, d.gb_1), (E, Fi, d.f, d.gw_2, d.gb_2))):
-                _defer_wgrad_raw(BF16, N, K, T, K, d.o_dy[which], xin, gw, gb, (P[2 * which], P[2 * which + 1]), keep,
+                _defer_wgrad_raw(d.dtype, N, K, T, K, d.o_dy[which], xin, gw, gb, (P[2 * which], P[2 * which + 1]), keep,
                                  flush_at=D2R_LAYER_GROUP)
             ready = bundle.params[8:]  # LayerNorm gradients were accumulated inside the call
         else:
@@ -863,6 +873,7 @@ class InteractionBundle:
 
     def __init__(self, layers, ncell, hid_router, heads_imrc, hid_imrc):
         self.ncell, self.nlayer = ncell, len(layers)
+        self.tdtype = None  # the 16-bit compute dtype of the weight shadows (bf16 or fp16)
         self.hid_router, self.heads_imrc, self.hid_imrc = hid_router, heads_imrc, hid_imrc
         self.table = (_lib.RoutingLayerParams * self.nlayer)()
         self.params = []  # every leaf whose gradient sink the backward call writes (data-parallel readiness)
@@ -880,6 +891,8 @@ class InteractionBundle:
                 wc = w if fp32 else getattr(w, "_d2r_lp", None)
                 if wc is None:
                     raise _lib.D2RError("InteractionBundle needs the 16-bit weight shadow of ParamStore")
+                if not fp32:
+                    self.tdtype = wc.dtype
                 e = t.lin[_lib.RL[name]]
                 e.w, e.b, e.gw, e.gb = wc.data_ptr(), b.data_ptr(), w._d2r_grad.data_ptr(), b._d2r_grad.data_ptr()
                 self.params += [w, b]
@@ -894,9 +907,9 @@ class InteractionBundle:
         self.total_paths = ncell * ncell * (self.nlayer - 1) + ncell
 
     def supports(self, own, other) -> bool:
-        return (own.dtype == torch.bfloat16 and other.dtype == torch.bfloat16 and own.is_cuda and own.dim() == 3 and own.shape[-1] == 768
+        return (own.dtype == self.tdtype and other.dtype == self.tdtype and own.is_cuda and own.dim() == 3 and own.shape[-1] == 768
                 and other.shape[-1] == 768
-                and bool(_lib.load().d2r_interaction_supported(BF16, own.shape[1], other.shape[1], self.ncell, self.heads_imrc)))
+                and bool(_lib.load().d2r_interaction_supported(_dt_of(self.tdtype), own.shape[1], other.shape[1], self.ncell, self.heads_imrc)))
 
 
 class _Interaction(torch.autograd.Function):
@@ -907,7 +920,7 @@ class _Interaction(torch.autograd.Function):
         Lk = other.shape[1]
         lib = _lib.load()
         d = _lib.InteractionDesc()
-        d.dtype, d.B, d.Lq, d.Lk, d.ncell, d.nlayer = BF16, B, Lq, Lk, bundle.ncell, bundle.nlayer
+        d.dtype, d.B, d.Lq, d.Lk, d.ncell, d.nlayer = _dt(own), B, Lq, Lk, bundle.ncell, bundle.nlayer
         d.hid_router, d.heads_imrc, d.hid_imrc, d.train = bundle.hid_router, bundle.heads_imrc, bundle.hid_imrc, int(train)
         d.layers = bundle.table
         out = torch.empty_like(own)
@@ -1223,7 +1236,7 @@ class _MeanPool(torch.autograd.Function):
         outs = []
         for i in range(n):
             dx = torch.empty(B, L, D, dtype=dtype, device=g.device)
-            _lib.call("d2r_meanpool_bwd", BF16 if dtype == torch.bfloat16 else F32, g[i].data_ptr(), B, L, D,
+            _lib.call("d2r_meanpool_bwd", _dt_of(dtype), g[i].data_ptr(), B, L, D,
                       dx.data_ptr(), 0, _stream())
             outs.append(dx)
         return tuple(outs)

@@ -38,7 +38,7 @@ class D2RModule(nn.Module):
     cdtype = torch.float32
 
     def set_compute_dtype(self, dtype: torch.dtype):
-        assert dtype in (torch.float32, torch.bfloat16)
+        assert dtype in (torch.float32, torch.bfloat16, torch.float16)
         for m in self.modules():
             if isinstance(m, D2RModule):
                 m.cdtype = dtype
@@ -466,7 +466,7 @@ class _InteractionBase(D2RModule):
     def _bundle(self, own, other):
         """The cached InteractionBundle when the one-call path applies (bf16 model prepared by ParamStore, token counts the
         fused attention cores support), else None -> the layers run op by op."""
-        if not COMPOSITE_ROUTING or self.cdtype != torch.bfloat16 or own.dtype != torch.bfloat16 or not own.is_cuda:
+        if not COMPOSITE_ROUTING or self.cdtype not in F.LOWP or own.dtype != self.cdtype or not own.is_cuda:
             return None
         b = getattr(self, "_bundle_cache", None)
         l0 = self.dynamic_itr_l0
@@ -526,7 +526,7 @@ COMPOSITE_ROUTING = os.environ.get("D2R_COMPOSITE_ROUTING", "1") != "0"  # whole
 def _layer_bundle(layer, x):
     """The cached LayerBundle of a BertLayer / CLIPEncoderLayer when the one-call path applies (bf16 model prepared by
     ParamStore, fused q|k|v, attention shape supported by the fused core), else None -> the op-by-op path."""
-    if not COMPOSITE_LAYERS or layer.cdtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not x.is_cuda:
+    if not COMPOSITE_LAYERS or layer.cdtype not in F.LOWP or x.dtype != layer.cdtype or not x.is_cuda:
         return None
     att = layer.attention.self if hasattr(layer, "attention") else layer.self_attn
     fz = att._fused_linear()

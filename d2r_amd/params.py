@@ -5,7 +5,7 @@ Memory layout in HBM (one allocation each, 288 GB/GPU makes this trivially affor
     flat_g  fp32 [n_live]   gradients (``p.grad`` are views; zeroed once per step by one memset; the dW GEMMs
                             accumulate straight into it — see functional._Linear.backward)
     flat_m, flat_v fp32     AdamW moments
-    flat_lp bf16 [n_live]   bf16 shadow of the weights (bf16 compute only), rewritten by the AdamW kernel
+    flat_lp 16-bit [n_live] bf16 / fp16 shadow of the weights (16-bit compute dtypes only), rewritten by the AdamW kernel
 Live parameters are ordered by the reference's four optimiser groups (modules/train.py:287-322) so each group is
 one contiguous range = one kernel launch per group.  The 52.6 M parameters that never receive a gradient in the
 reference stay outside the store and are never updated nor all-reduced (AdamW skips ``grad is None`` there too).
@@ -112,7 +112,8 @@ class ParamStore:
         self.n = off
         self.flat_w = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
-        self.flat_lp = torch.zeros(off, dtype=torch.bfloat16, device=device) if compute_dtype == torch.bfloat16 else None
+        self.flat_lp = torch.zeros(off, dtype=compute_dtype, device=device) if compute_dtype in (torch.bfloat16, torch.float16) else None
+        self.lp_dtype = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}.get(compute_dtype, _lib.BF16)
         with torch.no_grad():
             for n, p, o, k, g in self.entries:
                 w = self.flat_w[o:o + k].view(p.shape)
@@ -154,11 +155,11 @@ class ParamStore:
         out.extend((t, o, k) for t, o, k, _ in self.fused)
         return out
 
-    # -- bf16 shadow -------------------------------------------------------------------------------
+    # -- 16-bit shadow -----------------------------------------------------------------------------
     def refresh_lowp(self):
-        """Re-derives the bf16 shadow from the fp32 masters (after load_state_dict / broadcast)."""
+        """Re-derives the 16-bit shadow from the fp32 masters (after load_state_dict / broadcast)."""
         if self.flat_lp is not None:
-            _lib.call("d2r_cast", _lib.F32, self.flat_w.data_ptr(), _lib.BF16, self.flat_lp.data_ptr(), self.n, _stream())
+            _lib.call("d2r_cast", _lib.F32, self.flat_w.data_ptr(), self.lp_dtype, self.flat_lp.data_ptr(), self.n, _stream())
 
     def zero_grad(self):
         from .functional import wgrad_join
@@ -181,6 +182,8 @@ class FusedAdamW:
         self.v = torch.zeros_like(store.flat_w)
         self.step_count = 0
         self.grad_scale = 1.0  # 1/world_size under data parallelism (gradients are SUM-reduced)
+        self.loss_scale = 1.0  # > 1 after enable_loss_scaling() (fp16 compute dtype)
+        self._scaler = None
         names = {0: "other", 1: "text", 2: "vision", 3: "fc"}
         self.param_groups = []
         for g, (a, b) in sorted(store.group_ranges.items()):
@@ -193,9 +196,55 @@ class FusedAdamW:
     def zero_grad(self, set_to_none: bool = False):
         self.store.zero_grad()
 
+    # -- loss scaling for the fp16 compute dtype (the job torch.cuda.amp.GradScaler does for the reference's users) ----------
+    def enable_loss_scaling(self, init_scale: float = 2.0 ** 14, growth_interval: int = 500, max_scale: float = 2.0 ** 24):
+        """fp16 activation gradients underflow below 6e-8: the loss is multiplied by ``loss_scale`` before backward
+        (``scale_loss``), the AdamW kernel divides it out again (it is folded into grad_scale), a device-side check of the
+        reduced gradients drops a step whose gradients overflowed (no host round trip: the kernels read the flag), and the
+        host learns of the overflow one step later, halves the scale then, and doubles it after ``growth_interval`` clean steps."""
+        dev = self.store.flat_w.device
+        self.loss_scale = float(init_scale)
+        self._scaler = dict(flag=torch.zeros(1, dtype=torch.int32, device=dev), host=torch.zeros(1, dtype=torch.int32).pin_memory()
+                            if dev.type == "cuda" else torch.zeros(1, dtype=torch.int32), event=None, good=0,
+                            growth_interval=int(growth_interval), max_scale=float(max_scale), skipped=0, used_scale=self.loss_scale)
+        return self
+
+    def scale_loss(self, loss):
+        return loss if self._scaler is None else loss * self.loss_scale
+
+    def _scaler_before_step(self):
+        """Consumes the previous step's overflow flag (its copy has long landed), then arms the check for this step."""
+        sc = self._scaler
+        if sc["event"] is not None:
+            sc["event"].synchronize()
+            if int(sc["host"][0]) != 0:
+                sc["skipped"] += 1
+                sc["good"] = 0
+                self.step_count -= 1  # the dropped step does not count towards the bias correction
+                self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+            else:
+                sc["good"] += 1
+                if sc["good"] >= sc["growth_interval"]:
+                    sc["good"] = 0
+                    self.loss_scale = min(self.loss_scale * 2.0, sc["max_scale"])
+        st = self.store
+        sc["flag"].zero_()
+        _lib.call("d2r_grad_nonfinite", st.flat_g.data_ptr(), st.n, sc["flag"].data_ptr(), _stream())
+
+    def _scaler_after_step(self):
+        sc = self._scaler
+        sc["host"].copy_(sc["flag"], non_blocking=True)
+        sc["event"] = torch.cuda.Event()
+        sc["event"].record()
+
     def step(self):
         from .functional import wgrad_join
         wgrad_join()
+        used = self.loss_scale  # the scale this step's backward ran with (the host may change it below)
+        skip = None
+        if self._scaler is not None:
+            self._scaler_before_step()
+            skip = self._scaler["flag"].data_ptr()
         self.step_count += 1
         st = self.store
         for pg in self.param_groups:
@@ -204,8 +253,10 @@ class FusedAdamW:
                 continue
             lp = None if st.flat_lp is None else st.flat_lp.data_ptr() + 2 * a
             _lib.call("d2r_adamw_step", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
-                      self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, b - a, pg["lr"], self.betas[0],
-                      self.betas[1], self.eps, pg["weight_decay"], self.step_count, self.grad_scale, _stream())
+                      self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, st.lp_dtype, b - a, pg["lr"], self.betas[0],
+                      self.betas[1], self.eps, pg["weight_decay"], self.step_count, self.grad_scale / used, skip, _stream())
+        if self._scaler is not None:
+            self._scaler_after_step()
 
     # -- hipGraph-capturable stepping: per-step scalars come from a device array ------------------------
     def _hyper_buffers(self):
@@ -224,7 +275,7 @@ class FusedAdamW:
         bc1 = 1.0 - b1 ** self.step_count
         bc2s = math.sqrt(1.0 - b2 ** self.step_count)
         for i, pg in enumerate(self.param_groups):
-            cpu[i, 0], cpu[i, 1], cpu[i, 2], cpu[i, 3] = pg["lr"], bc1, bc2s, self.grad_scale
+            cpu[i, 0], cpu[i, 1], cpu[i, 2], cpu[i, 3] = pg["lr"], bc1, bc2s, self.grad_scale / self.loss_scale
         dev.copy_(cpu)  # pageable source: the runtime stages it before returning, so `cpu` may be rewritten at once
 
     def step_captured(self):
@@ -239,8 +290,8 @@ class FusedAdamW:
                 continue
             lp = None if st.flat_lp is None else st.flat_lp.data_ptr() + 2 * a
             _lib.call("d2r_adamw_step_dev", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
-                      self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, b - a, dev.data_ptr() + 16 * i,
-                      self.betas[0], self.betas[1], self.eps, pg["weight_decay"], _stream())
+                      self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, st.lp_dtype, b - a, dev.data_ptr() + 16 * i,
+                      self.betas[0], self.betas[1], self.eps, pg["weight_decay"], None, _stream())
 
     def state_dict(self):
         return dict(m=self.m, v=self.v, step=self.step_count, lrs=[pg["lr"] for pg in self.param_groups])

@@ -65,7 +65,7 @@ def build_parser():
     p.add_argument("--lambda_softmax_CMRC", default=4.0, type=float)
     p.add_argument("--hid_router", type=int, default=768)
     # --- extensions
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"])
     p.add_argument("--num_classes", default=3, type=int)
     p.add_argument("--num_cells", default=6, type=int, help="cells per routing layer: the first n of ric, glac, imrc, cmrc, "
                    "crcmc, gesc (6 = the reference; 2..5 = declared-subset extension, BASELINE configs[4] uses 4)")
@@ -93,7 +93,7 @@ def main(argv=None):
     rank, world = init_process_group_from_env()
     if args.device == "cuda":
         args.device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
-    args.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    args.compute_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[args.dtype]
     set_seed(args.seed)
     if args.save_path is not None and rank == 0:
         os.makedirs(args.save_path, exist_ok=True)

@@ -86,6 +86,8 @@ class MSDTrainer:
         from . import configure_runtime
         configure_runtime()
         self.optimizer = FusedAdamW(self.store, lr=self.args.lr, fc_lr=5e-2, weight_decay=1e-2)
+        if dtype == torch.float16:  # fp16 activation gradients need a scaled loss (AMP's GradScaler, here inside the optimiser)
+            self.optimizer.enable_loss_scaling()
         self.dp = DataParallel(self.store, self.optimizer, self.model,
                                overlap=bool(getattr(self.args, "dp_overlap", False)))
         self.dp.broadcast_parameters()
@@ -136,7 +138,7 @@ class MSDTrainer:
                 self.dp.begin_step()
                 (loss, logits), labels = self._step(batch, mode="train")
                 F._lib.call("d2r_axpby", F.F32, 1.0, loss.detach().data_ptr(), 1.0, run_loss.data_ptr(), 1, F._stream())
-                loss.backward()
+                self.optimizer.scale_loss(loss).backward()
                 self.dp.reduce_gradients()
                 self.optimizer.step()
                 self.scheduler.step()

@@ -13,8 +13,9 @@
  *   - kernels are enqueued on the caller's `stream` (a hipStream_t passed as void*); the library never
  *     allocates, frees, synchronises or takes ownership — workspaces are caller-provided;
  *   - return 0 on success, a negative d2r_status on error; d2r_last_error() gives a thread-local message;
- *   - dtype of activations/weights `T` is D2R_F32 or D2R_BF16; accumulation, softmax statistics, router
- *     logits, biases, LayerNorm parameters and all reductions are fp32;
+ *   - dtype of activations/weights `T` is D2R_F32, D2R_BF16 or D2R_F16 (IEEE half: BASELINE.json configs[4]); every
+ *     entry point that says "16-bit" takes either of the two and runs the same kernel with the other MFMA operand type;
+ *     accumulation, softmax statistics, router logits, biases, LayerNorm parameters and all reductions are fp32;
  *   - deterministic: fixed reduction order, no float atomics except the embedding-table scatter-add.
  */
 #ifndef D2R_HIP_H
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-typedef enum { D2R_F32 = 0, D2R_BF16 = 1 } d2r_dtype;
+typedef enum { D2R_F32 = 0, D2R_BF16 = 1, D2R_F16 = 2 } d2r_dtype;
 
 typedef enum {
   D2R_OK = 0,
@@ -417,16 +418,22 @@ int d2r_clip_embed_bwd(int dtype, const void* dX, int B, int ntok, int D, float*
 
 /* ------------------------------------------------------------------------------------------------
  * K14 fused AdamW over a flat fp32 parameter range (modules/train.py:287-322: torch.optim.AdamW defaults
- * betas=(0.9,0.999), eps=1e-8, weight_decay=1e-2, decoupled) + optional bf16 shadow copy of the weights.
+ * betas=(0.9,0.999), eps=1e-8, weight_decay=1e-2, decoupled) + optional 16-bit shadow copy of the weights.
  * lr already includes the schedule factor; step is the 1-based step count (bias correction).
  * ------------------------------------------------------------------------------------------------ */
-int d2r_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16 /*or NULL*/, int64_t n, float lr,
+int d2r_adamw_step(float* w, const float* g, float* m, float* v, void* w16 /*or NULL*/, int w16_dtype, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
-                   void* stream);
+                   const int* d_skip /*or NULL*/, void* stream);
 /* hipGraph-capturable form: the per-step scalars {lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale} are read from the
- * device array d_hyper[4], which the host refreshes before every graph replay. */
-int d2r_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w_bf16 /*or NULL*/, int64_t n,
-                       const float* d_hyper, float beta1, float beta2, float eps, float weight_decay, void* stream);
+ * device array d_hyper[4], which the host refreshes before every graph replay.
+ * w16 / w16_dtype: optional 16-bit shadow copy of the weights (D2R_BF16 or D2R_F16) rewritten by the same pass.
+ * d_skip: optional device flag; when *d_skip != 0 the launch changes nothing (loss-scaled fp16 training: the step whose
+ * gradients overflowed is dropped, as torch.cuda.amp.GradScaler.step does, without a host round trip). */
+int d2r_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16 /*or NULL*/, int w16_dtype, int64_t n,
+                       const float* d_hyper, float beta1, float beta2, float eps, float weight_decay,
+                       const int* d_skip /*or NULL*/, void* stream);
+/* *d_flag |= 1 when g[0..n) holds an inf or a NaN (d_flag is device memory the caller zeroes; one pass over g). */
+int d2r_grad_nonfinite(const float* g, int64_t n, int* d_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
 """GPU parity of every HIP op (forward AND backward, through the C ABI) against a plain PyTorch CPU fp64
-expression of the same op.  fp32 mode is checked tightly; bf16 mode within bf16 rounding of the fp64 truth."""
+expression of the same op.  fp32 mode is checked tightly; the 16-bit modes (bf16, fp16) within their rounding of the fp64 truth."""
 import math
 
 import pytest
@@ -7,11 +7,13 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DT = [torch.float32, torch.bfloat16]
+DT = [torch.float32, torch.bfloat16, torch.float16]
+LOWP = (torch.bfloat16, torch.float16)
 
 
 def tol(dtype, scale=1.0):
-    return (2e-5 if dtype == torch.float32 else 2.5e-2) * scale
+    # one rounding of a 16-bit type: 2^-9 (bf16) / 2^-12 (fp16) relative; the ops chain a handful of them
+    return {torch.float32: 2e-5, torch.bfloat16: 2.5e-2, torch.float16: 3.2e-3}[dtype] * scale
 
 
 def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
@@ -49,7 +51,7 @@ def run_both(fn_gpu, fn_ref, inputs, dtype, gpu, wrt=None, name="op", out_scale=
         out_g, out_r = [out_g], [out_r]
     loss_g, loss_r = 0, 0
     for k, (og, orr) in enumerate(zip(out_g, out_r)):
-        check(f"{name}.out{k}", og, orr, og.dtype if og.dtype == torch.bfloat16 else dtype, out_scale)
+        check(f"{name}.out{k}", og, orr, og.dtype if og.dtype in LOWP else dtype, out_scale)
         w = rnd(*orr.shape, seed=100 + k).double()
         loss_g = loss_g + (og.float() * w.float().to(gpu)).sum()
         loss_r = loss_r + (orr * w).sum()
@@ -356,20 +358,39 @@ def test_adamw_matches_torch(gpu):
     from d2r_amd.functional import _stream
     n = 1000 + 3
     w0, g = rnd(n), rnd(n, seed=1)
-    p = torch.nn.Parameter(w0.clone())
-    opt = torch.optim.AdamW([p], lr=3e-3, weight_decay=1e-2)
-    w = w0.clone().to(gpu)
-    m, v = torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
-    w16 = torch.zeros(n, dtype=torch.bfloat16, device=gpu)
-    for step in range(1, 4):
-        gs = g * step
-        p.grad = gs.clone()
-        opt.step()
-        gg = (gs * 2.0).to(gpu)  # grad_scale 0.5 undoes the doubling (data-parallel SUM -> mean)
-        _lib.call("d2r_adamw_step", w.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), w16.data_ptr(), n, 3e-3, 0.9,
-                  0.999, 1e-8, 1e-2, step, 0.5, _stream())
-    assert float((w.cpu() - p.detach()).abs().max()) < 1e-6
-    assert float((w16.float().cpu() - p.detach()).abs().max()) < 1e-2
+    for lp_dtype, lp_code in ((torch.bfloat16, _lib.BF16), (torch.float16, _lib.F16)):
+        p = torch.nn.Parameter(w0.clone())
+        opt = torch.optim.AdamW([p], lr=3e-3, weight_decay=1e-2)
+        w = w0.clone().to(gpu)
+        m, v = torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+        w16 = torch.zeros(n, dtype=lp_dtype, device=gpu)
+        skip = torch.zeros(1, dtype=torch.int32, device=gpu)
+        for step in range(1, 4):
+            gs = g * step
+            p.grad = gs.clone()
+            opt.step()
+            gg = (gs * 2.0).to(gpu)  # grad_scale 0.5 undoes the doubling (data-parallel SUM -> mean)
+            _lib.call("d2r_adamw_step", w.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), w16.data_ptr(), lp_code, n, 3e-3, 0.9,
+                      0.999, 1e-8, 1e-2, step, 0.5, skip.data_ptr(), _stream())
+        assert float((w.cpu() - p.detach()).abs().max()) < 1e-6
+        assert float((w16.float().cpu() - p.detach()).abs().max()) < (1e-2 if lp_dtype == torch.bfloat16 else 2e-3)
+        # overflowed loss-scaled gradients: the check raises the flag and the flagged launch changes nothing
+        before = (w.clone(), m.clone(), v.clone(), w16.clone())
+        gg[17] = float("inf")
+        _lib.call("d2r_grad_nonfinite", gg.data_ptr(), n, skip.data_ptr(), _stream())
+        assert int(skip) == 1
+        _lib.call("d2r_adamw_step", w.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), w16.data_ptr(), lp_code, n, 3e-3, 0.9,
+                  0.999, 1e-8, 1e-2, 4, 0.5, skip.data_ptr(), _stream())
+        for a, b in zip(before, (w, m, v, w16)):
+            assert torch.equal(a, b)
+        skip.zero_()
+        gg[17] = float("nan")
+        _lib.call("d2r_grad_nonfinite", gg.data_ptr(), n, skip.data_ptr(), _stream())
+        assert int(skip) == 1
+        skip.zero_()
+        gg[17] = 3.0e38
+        _lib.call("d2r_grad_nonfinite", gg.data_ptr(), n, skip.data_ptr(), _stream())
+        assert int(skip) == 0
 
 
 def test_ops_refuse_cpu_tensors():
@@ -379,8 +400,9 @@ def test_ops_refuse_cpu_tensors():
         F.linear(torch.zeros(2, 8), torch.zeros(4, 8), None)
 
 
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("kind", ["bert", "clip"])
-def test_encoder_layer_one_call_matches_op_by_op(gpu, kind):
+def test_encoder_layer_one_call_matches_op_by_op(gpu, kind, lowp):
     """d2r_encoder_layer_fwd/bwd (one C call per layer and direction) against the op-by-op path built from the same
     kernels: the forward is bit-identical; the backward differs only where a skip-connection gradient is now added in
     fp32 inside a GEMM / LayerNorm epilogue instead of by a separate bf16 add."""
@@ -401,14 +423,14 @@ def test_encoder_layer_one_call_matches_op_by_op(gpu, kind):
             self.layer = layer
 
     model = Wrap(layer).to(gpu)
-    model.set_compute_dtype(torch.bfloat16).train()
+    model.set_compute_dtype(lowp).train()
     with torch.no_grad():
         for n, p in model.named_parameters():
             if "LayerNorm" in n or "layer_norm" in n:
                 p.add_(0.1 * torch.randn_like(p))
-    store = ParamStore(model, torch.bfloat16)
-    x0 = torch.randn(B, L, 768, device=gpu).bfloat16()
-    gy = torch.randn(B, L, 768, device=gpu).bfloat16()
+    store = ParamStore(model, lowp)
+    x0 = torch.randn(B, L, 768, device=gpu).to(lowp)
+    gy = torch.randn(B, L, 768, device=gpu).to(lowp)
     mask = torch.zeros(B, L, device=gpu)
     mask[0, L // 2:] = -10000.0
     res = {}
@@ -433,10 +455,11 @@ def test_encoder_layer_one_call_matches_op_by_op(gpu, kind):
         assert r < 2e-2, (n, r)
 
 
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [("text", 6, 3, 3, 24, 10, True), ("image", 6, 4, 2, 10, 24, True), ("text", 4, 3, 2, 16, 7, True),
                                  ("image", 6, 3, 2, 12, 9, False), ("text", 6, 2, 2, 9, 5, True)],
                          ids=lambda c: f"{c[0]}-nc{c[1]}-dr{c[2]}-{'train' if c[6] else 'eval'}")
-def test_interaction_module_one_call_matches_op_by_op(gpu, cfg):
+def test_interaction_module_one_call_matches_op_by_op(gpu, cfg, lowp):
     """d2r_interaction_fwd/bwd (K16: one C call per module and direction) against the op-by-op path built from the same
     kernels, on identical weights and inputs with about half of the paths pruned: the forward (aggregated embedding, path
     similarities, BatchNorm running statistics) is bit-identical; the backward differs only in WHERE multi-consumer
@@ -449,14 +472,14 @@ def test_interaction_module_one_call_matches_op_by_op(gpu, cfg):
     torch.manual_seed(11)
     cls = M.InteractionModule if branch == "text" else M.Reversed_InteractionModule
     mod = cls(default_args(DR_step=dr), num_layer_routing=dr, num_cells=nc, path_hid=128).to(gpu)
-    mod.set_compute_dtype(torch.bfloat16).train(train)
+    mod.set_compute_dtype(lowp).train(train)
     with torch.no_grad():
         for n, p in mod.named_parameters():
             if n.endswith("router.mlp.2.bias"):
                 p.normal_()
-    store = ParamStore(mod, torch.bfloat16)
-    own0 = torch.randn(B, Lq, 768, device=gpu).bfloat16()
-    other0 = torch.randn(B, Lk, 768, device=gpu).bfloat16()
+    store = ParamStore(mod, lowp)
+    own0 = torch.randn(B, Lq, 768, device=gpu).to(lowp)
+    other0 = torch.randn(B, Lk, 768, device=gpu).to(lowp)
     r_emb = torch.randn(B, Lq, 768, device=gpu)
     r_sim = torch.randn(B, B, device=gpu)
     buffers0 = {k: v.clone() for k, v in mod.named_buffers()}
@@ -517,12 +540,13 @@ def test_dropout_kernel(gpu, dtype):
     keep = y != 0
     frac = float(keep.float().mean())
     assert abs(frac - (1 - p)) < 3e-3, frac
-    tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
-    assert torch.allclose(y[keep].float(), x.detach()[keep].float() / (1 - p), rtol=tol)
+    tol = {torch.bfloat16: 1e-2, torch.float16: 1.5e-3, torch.float32: 1e-6}[dtype]
+    atol = 1e-6 if dtype == torch.float16 else 1e-8  # fp16 values below 6e-5 are subnormal: absolute, not relative, rounding
+    assert torch.allclose(y[keep].float(), x.detach()[keep].float() / (1 - p), rtol=tol, atol=atol)
     g = torch.randn_like(y)
     y.backward(g)
     assert torch.equal(x.grad != 0, keep & (g != 0))  # same mask in the backward
-    assert torch.allclose(x.grad[keep].float(), g[keep].float() / (1 - p), rtol=tol)
+    assert torch.allclose(x.grad[keep].float(), g[keep].float() / (1 - p), rtol=tol, atol=atol)
     y2 = F.dropout(x, p, True)
     assert not torch.equal(y2 != 0, keep), "every call must draw a fresh mask"
     x.grad = None
@@ -590,7 +614,7 @@ def test_grouped_weight_gradient_gemm(gpu, dtype, shape):
     bsinks = [rnd(N, seed=300 + i).to(gpu) for i in range(n)]
     want_w = [s.double() + g.double().t() @ x.double() for s, g, x in zip(sinks, gs, xs)]
     want_b = [b.double() + g.double().sum(0) for b, g in zip(bsinks, gs)]
-    dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    dt = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float32: _lib.F32}[dtype]
     _lib.call("d2r_gemm_tn_grouped", dt, N, K, T, N, K, K, _parr(gs), _parr(xs), _parr(sinks), _parr(bsinks), n, 1.0, _stream())
     torch.cuda.synchronize()
     for i in range(n):
