@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--dr-step", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"])
+    ap.add_argument("--no-fp16-leg", action="store_true", help="skip the fp16-compute-dtype number reported beside the bf16 headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=32, help="batch of the CPU baseline (BASELINE.md section 3: the benchmark batch)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -163,7 +164,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)  # (% : gloo rehearsal on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[args.dtype]
 
     torch.manual_seed(2023)  # reference default seed (run.py:49); identical replicas, then broadcast anyway
     tc = TextConfig(num_hidden_layers=args.layers, hidden_dropout_prob=args.bert_dropout,
@@ -176,6 +177,8 @@ def main():
     store = ParamStore(model, dtype)
     log(f"model on {dev}: {store.live_numel() / 1e6:.1f} M live parameters in flat buffers")
     opt = FusedAdamW(store, lr=3e-5)
+    if dtype == torch.float16:
+        opt.enable_loss_scaling()  # scaled loss, device-side overflow check and step skip: all inside the timed step
     total_steps = args.warmup + args.steps + 8
     sched = LinearWarmupSchedule(opt, 0.01 * total_steps, total_steps)
     dp = DataParallel(store, opt, model, overlap=not args.no_overlap)  # (no effect at N = 1)
@@ -185,7 +188,7 @@ def main():
     def step():
         dp.begin_step()
         loss, logits = model(*batch)
-        loss.backward()
+        opt.scale_loss(loss).backward()
         dp.reduce_gradients()
         opt.step()
         sched.step()
@@ -264,7 +267,7 @@ def main():
     def fwd_bwd_only():
         dp.begin_step()
         loss, _ = model(*batch)
-        loss.backward()
+        opt.scale_loss(loss).backward()
         opt.zero_grad()
 
     n2 = max(3, args.steps // 2)
@@ -298,7 +301,7 @@ def main():
         # alone on the GPU — the durations rocprofv3 --kernel-trace reports (it serialises dispatches too).
         def local_step():  # the step without its collective: rank 0 is alone here
             loss, _ = model(*batch)
-            loss.backward()
+            opt.scale_loss(loss).backward()
             opt.step()
             sched.step()
             opt.zero_grad()
@@ -386,6 +389,26 @@ def main():
             out["fp32_path"] = {"error": repr(e)}
         finally:
             model.set_compute_dtype(dtype)
+
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_fp16_leg and not args.graph:
+        # The same step with the OTHER 16-bit compute dtype (IEEE half: same kernels and MFMA rate, 11 significant bits, scaled
+        # loss): the 16-bit mode whose logits stay within the north star's 1e-3 of the reference on every fixture
+        # (tests/test_gpu_model.py).  Run as a child process (its own ParamStore with an fp16 shadow); never `value`.
+        try:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp16", "--steps", str(min(args.steps, 10)), "--warmup", "3",
+                   "--batch", str(args.batch), "--seq", str(args.seq), "--layers", str(args.layers), "--no-cpu-baseline",
+                   "--no-fp32-leg", "--no-roofline"]
+            torch.cuda.synchronize()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            child = json.loads(line)
+            out["fp16_path"] = {"ms_per_step": child["ms_per_step"], "samples_per_s": child["value"], "final_loss": child.get("final_loss"),
+                                "note": "same step, fp16 activations / weights / MFMA operands, loss scale 2^14 with the device-side "
+                                        "overflow check inside the step; logits within 1e-3 of the reference on every golden fixture"}
+            log(f"fp16 path: {child['ms_per_step']:.2f} ms/step")
+        except Exception as e:
+            out["fp16_path"] = {"error": repr(e)}
 
     if sd_cpu is not None:
         try:

@@ -20,6 +20,20 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GEMM_SHAPES = [(6304, 3072, 768), (6304, 768, 3072), (4096, 2304, 768)]
+# (shape, 16-bit dtype): bf16 on every shape, fp16 (same kernels, the other MFMA opcode) on one of them
+GEMM_CASES = [pytest.param(s, torch.bfloat16, id="x".join(map(str, s)) + "-bf16") for s in GEMM_SHAPES] + [
+    pytest.param(GEMM_SHAPES[2], torch.float16, id="x".join(map(str, GEMM_SHAPES[2])) + "-fp16"),
+    pytest.param(GEMM_SHAPES[0], torch.float16, id="x".join(map(str, GEMM_SHAPES[0])) + "-fp16")]
+
+
+def _code(lowp):
+    from d2r_amd import _lib
+    return _lib.BF16 if lowp == torch.bfloat16 else _lib.F16
+
+
+def _r16(lowp):
+    """Relative error of ONE rounding of an fp32-accumulated value to the 16-bit type, with accumulation noise on top."""
+    return 6e-3 if lowp == torch.bfloat16 else 8e-4
 
 
 def _rnd(*shape, seed=0, scale=1.0):
@@ -56,71 +70,71 @@ def _max_rel(got, ref):
     return float((got.double().cpu() - ref).abs().max() / ref.abs().max())
 
 
-@pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_gemm_nt_bias_gelu_preact_and_residual(gpu, shape):
+@pytest.mark.parametrize("shape,lowp", GEMM_CASES)
+def test_gemm_nt_bias_gelu_preact_and_residual(gpu, shape, lowp):
     """y = gelu(x W^T + b) with the saved pre-activation (FFN up-projection) and y = x W^T + b + r (output projections)."""
     from d2r_amd import _lib
     M, N, K = shape
-    x = _rnd(M, K, seed=1).bfloat16()
-    w = _rnd(N, K, seed=2, scale=0.03).bfloat16()
+    x = _rnd(M, K, seed=1).to(lowp)
+    w = _rnd(N, K, seed=2, scale=0.03).to(lowp)
     b = _rnd(N, seed=3, scale=0.5)
-    r = _rnd(M, N, seed=4).bfloat16()
+    r = _rnd(M, N, seed=4).to(lowp)
     ref = x.double() @ w.double().t() + b.double()
     xg, wg, bg, rg = x.to(gpu), w.to(gpu), b.to(gpu), r.to(gpu)
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=gpu)
+    y = torch.empty(M, N, dtype=lowp, device=gpu)
     pre = torch.empty_like(y)
-    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y, dtype=_lib.BF16, c_dtype=_lib.BF16, bias=bg, act=_lib.ACT_GELU, preact=pre))
-    # bf16 output: one rounding of an fp32-accumulated value -> <= 2^-8 relative per element (+ accumulation noise)
-    assert _max_rel(pre, ref) <= 6e-3
-    assert _max_rel(y, torch.nn.functional.gelu(ref)) <= 6e-3
-    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y, dtype=_lib.BF16, c_dtype=_lib.BF16, bias=bg, residual=rg))
-    assert _max_rel(y, ref + r.double()) <= 6e-3
+    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y, dtype=_code(lowp), c_dtype=_code(lowp), bias=bg, act=_lib.ACT_GELU, preact=pre))
+    # 16-bit output: one rounding of an fp32-accumulated value -> <= 2^-8 (bf16) / 2^-11 (fp16) relative per element (+ noise)
+    assert _max_rel(pre, ref) <= _r16(lowp)
+    assert _max_rel(y, torch.nn.functional.gelu(ref)) <= _r16(lowp)
+    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y, dtype=_code(lowp), c_dtype=_code(lowp), bias=bg, residual=rg))
+    assert _max_rel(y, ref + r.double()) <= _r16(lowp)
     # fp32 output of the same product: only the fp32 accumulation order differs from the fp64 sum
     y32 = torch.empty(M, N, dtype=torch.float32, device=gpu)
-    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y32, dtype=_lib.BF16, c_dtype=_lib.F32, bias=bg))
+    _call_gemm(_gemm_desc(_lib.GEMM_NT, M, N, K, xg, wg, y32, dtype=_code(lowp), c_dtype=_lib.F32, bias=bg))
     assert _max_rel(y32, ref) <= 2e-5
 
 
-@pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_gemm_nn_dx_with_activation_backward_and_accumulate(gpu, shape):
+@pytest.mark.parametrize("shape,lowp", GEMM_CASES)
+def test_gemm_nn_dx_with_activation_backward_and_accumulate(gpu, shape, lowp):
     """dX = dY W (NN, the direction no other test runs on the 128x128 LDS-DMA tile), (i) plain, (ii) multiplied by
     gelu'(pre) in the epilogue (`grad_ref`: the FFN's activation backward), (iii) accumulated onto an existing
     gradient (beta = 1: skip-connection / multi-consumer gradients)."""
     from d2r_amd import _lib
     M, N, K = shape  # output [M,N], reduction K: dY [M,K], W [K,N]
-    dy = _rnd(M, K, seed=5).bfloat16()
-    w = _rnd(K, N, seed=6, scale=0.03).bfloat16()
-    pre = _rnd(M, N, seed=7).bfloat16()
-    old = _rnd(M, N, seed=8).bfloat16()
+    dy = _rnd(M, K, seed=5).to(lowp)
+    w = _rnd(K, N, seed=6, scale=0.03).to(lowp)
+    pre = _rnd(M, N, seed=7).to(lowp)
+    old = _rnd(M, N, seed=8).to(lowp)
     ref = dy.double() @ w.double()
     dyg, wg, preg = dy.to(gpu), w.to(gpu), pre.to(gpu)
-    dx = torch.empty(M, N, dtype=torch.bfloat16, device=gpu)
-    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, dx, dtype=_lib.BF16, c_dtype=_lib.BF16))
-    assert _max_rel(dx, ref) <= 6e-3
-    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, dx, dtype=_lib.BF16, c_dtype=_lib.BF16, grad_ref=preg, grad_act=_lib.ACT_GELU))
+    dx = torch.empty(M, N, dtype=lowp, device=gpu)
+    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, dx, dtype=_code(lowp), c_dtype=_code(lowp)))
+    assert _max_rel(dx, ref) <= _r16(lowp)
+    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, dx, dtype=_code(lowp), c_dtype=_code(lowp), grad_ref=preg, grad_act=_lib.ACT_GELU))
     p = pre.double()
     gelu_grad = 0.5 * (1 + torch.erf(p / math.sqrt(2))) + p * torch.exp(-0.5 * p * p) / math.sqrt(2 * math.pi)
-    # TWO bf16 roundings here (the vectorised epilogue stages the product in LDS as bf16 before the gelu' factor): 2 x 2^-8
-    assert _max_rel(dx, ref * gelu_grad) <= 1e-2
+    # TWO roundings here (the vectorised epilogue stages the product in LDS in the 16-bit type before the gelu' factor)
+    assert _max_rel(dx, ref * gelu_grad) <= 1.7 * _r16(lowp)
     acc = old.to(gpu).clone()
-    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, acc, dtype=_lib.BF16, c_dtype=_lib.BF16, beta=1.0))
-    assert _max_rel(acc, ref + old.double()) <= 6e-3
+    _call_gemm(_gemm_desc(_lib.GEMM_NN, M, N, K, dyg, wg, acc, dtype=_code(lowp), c_dtype=_code(lowp), beta=1.0))
+    assert _max_rel(acc, ref + old.double()) <= _r16(lowp)
 
 
-@pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_gemm_tn_weight_gradient_with_bias_gradient(gpu, shape):
+@pytest.mark.parametrize("shape,lowp", GEMM_CASES)
+def test_gemm_tn_weight_gradient_with_bias_gradient(gpu, shape, lowp):
     """dW[N,K] += dY[M,N]^T X[M,K] reduced over the M token rows, fp32 output accumulated into a pre-filled sink, with
     the bias gradient (column sums of dY) as a side product — split-K slabs + the fixed-order reduce."""
     from d2r_amd import _lib
     T, N, K = shape
-    dy = _rnd(T, N, seed=9).bfloat16()
-    x = _rnd(T, K, seed=10).bfloat16()
+    dy = _rnd(T, N, seed=9).to(lowp)
+    x = _rnd(T, K, seed=10).to(lowp)
     sink0, bsink0 = _rnd(N, K, seed=11), _rnd(N, seed=12)
     ref = sink0.double() + dy.double().t() @ x.double()
     refb = bsink0.double() + dy.double().sum(0)
     sink, bsink = sink0.to(gpu), bsink0.to(gpu)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
-    d = _gemm_desc(_lib.GEMM_TN, N, K, T, dy.to(gpu), x.to(gpu), sink, dtype=_lib.BF16, c_dtype=_lib.F32, beta=1.0, ws=ws)
+    d = _gemm_desc(_lib.GEMM_TN, N, K, T, dy.to(gpu), x.to(gpu), sink, dtype=_code(lowp), c_dtype=_lib.F32, beta=1.0, ws=ws)
     d.dbias = bsink.data_ptr()
     _call_gemm(d)
     assert _max_rel(sink, ref) <= 2e-5
@@ -160,7 +174,7 @@ def test_grouped_weight_gradient_rejects_a_repeated_sink(gpu):
         _lib.call("d2r_gemm_tn_grouped", _lib.BF16, 64, 64, 128, 64, 64, 64, _parr([g, g]), _parr([x, x]), _parr([sink, sink]), None, 2, 1.0, _stream())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "fp16"])
 @pytest.mark.parametrize("lq,lk", [(128, 197), (197, 128)])
 def test_cross_modal_attention_core_at_the_real_temperature(gpu, dtype, lq, lk):
     """softmax(100 q k^T / sqrt(768)) v on unit-variance tokens projected by default-init Linears (element std 0.58: the
@@ -184,14 +198,14 @@ def test_cross_modal_attention_core_at_the_real_temperature(gpu, dtype, lq, lk):
     orf = p @ vr
     (orf * w.double()).sum().backward()
     assert float(p.detach().max(-1).values.median()) > 0.9, "this test is meant to run in the near-one-hot regime"
-    tol = 1e-4 if dtype == torch.float32 else 2.5e-2
+    tol = {torch.float32: 1e-4, torch.bfloat16: 2.5e-2, torch.float16: 4e-3}[dtype]
     for name, got, ref in (("o", o, orf), ("dq", qg.grad, qr.grad), ("dk", kg.grad, kr.grad), ("dv", vg.grad, vr.grad)):
         err = float((got.detach().double().cpu() - ref.detach()).abs().max())
         s = float(ref.detach().abs().max())
         assert err <= tol * s + 1e-7, f"{name}: err {err:.3e} vs scale {s:.3e} ({dtype}, Lq={lq}, Lk={lk})"
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "fp16"])
 def test_full_model_at_the_benchmark_shape_vs_oracle(gpu, dtype):
     """UnimoModelF forward + backward at the C2 shape (L = 128, 197 image tokens, 12 + 12 encoder layers, DR_step 3;
     batch 8 -> 1024 text rows and 1576 image rows: every LDS-DMA / grouped GEMM variant, the whole-layer C calls, the
@@ -199,6 +213,8 @@ def test_full_model_at_the_benchmark_shape_vs_oracle(gpu, dtype):
     init, against the pinned oracle in fp32 on the host.
 
     fp32 compute : |logits|, |loss| errors <= 2e-5; global gradient cosine >= 0.9999.
+    fp16 compute : |logits|, |loss| errors <= 1e-3 (the north star's tolerance); global gradient cosine >= 0.9, >= 0.999 for the
+                   parameters whose gradient does not pass through Block's signed square root.
     bf16 compute : the error is printed next to the emulated floor ("bf16 MFMA operands, fp32 everything else" applied
                    to the oracle, tests/lowp_emulation.py); asserted: <= max(1e-3, 3 x floor) for logits and loss, global
                    gradient cosine >= 0.9."""
@@ -224,23 +240,43 @@ def test_full_model_at_the_benchmark_shape_vs_oracle(gpu, dtype):
     model.to(gpu).set_compute_dtype(dtype).train()
     ParamStore(model, dtype)
     loss, logits = model(*[t.to(gpu) for t in batch])
-    loss.backward()
+    lscale = 1024.0 if dtype == torch.float16 else 1.0  # fp16 activation gradients need a scaled loss
+    (loss * lscale).backward()
     torch.cuda.synchronize()
+    for p in model.parameters():
+        if p.grad is not None and lscale != 1.0:
+            p.grad.mul_(1.0 / lscale)
     e_logit = float((logits.double().cpu() - logits_o.detach().double()).abs().max())
     e_loss = abs(float(loss) - float(lo))
     dot = ng = nr = 0.0
+    side = [0.0, 0.0, 0.0]  # the parameters whose gradient does NOT pass through Block's signed square root (they see the JS loss only)
     for name, p in model.named_parameters():
         ref = osd[name].grad
         if ref is None:
             continue
         got = p.grad.detach().float().cpu()
         assert torch.isfinite(got).all(), name
-        dot, ng, nr = dot + float((got.double() * ref.double()).sum()), ng + float(got.double().pow(2).sum()), nr + float(ref.double().pow(2).sum())
+        d_, g_, r_ = float((got.double() * ref.double()).sum()), float(got.double().pow(2).sum()), float(ref.double().pow(2).sum())
+        dot, ng, nr = dot + d_, ng + g_, nr + r_
+        if name.startswith(("model.self_text", "model.self_vision", "model.text_cls_pool", "model.vision_cls_pool")):
+            side = [side[0] + d_, side[1] + g_, side[2] + r_]
     cos = dot / max((ng * nr) ** 0.5, 1e-300)
+    cos_side = side[0] / max((side[1] * side[2]) ** 0.5, 1e-300)
     if dtype == torch.float32:
         print(f"[C2-shape fp32] logits err {e_logit:.2e} loss err {e_loss:.2e} gradient cosine {cos:.6f}")
         assert e_logit <= 2e-5 and e_loss <= 2e-5, (e_logit, e_loss)
         assert cos >= 0.9999, cos
+    elif dtype == torch.float16:
+        # fp16: the 16-bit compute dtype that meets the north star's 1e-3 at the benchmark shape, with a real gradient bound
+        print(f"[C2-shape fp16] logits err {e_logit:.2e} loss err {e_loss:.2e} gradient cosine {cos:.4f} (parameters not behind Block's "
+              f"signed square root: {cos_side:.4f}); north-star tolerance 1e-3")
+        assert e_logit <= 1e-3 and e_loss <= 1e-3, (e_logit, e_loss)
+        # Gradient direction, measured 0.9425 (bf16: 0.877): every gradient that reaches the encoders passes through the signed square
+        # root of Block (models/XModules.py:547, derivative 0.5/sqrt|z|, unbounded at z = 0), which multiplies whatever error the
+        # 24 encoder + 3 routing layers left in the pooled vectors; Block itself already runs in fp32 here.  Control experiment
+        # (tests/probes/lowp_c2_parts.py): the fp32 path with ONLY Block's two input vectors rounded to fp16 gives 0.9987, rounded
+        # to bf16 0.976.  The parameters that do not sit behind Block keep cos >= 0.999.
+        assert cos >= 0.9 and cos_side >= 0.999, (cos, cos_side)
     else:
         from lowp_emulation import STORE_ALL
         fl, flog = lowp_floor(sd, cfg, batch, True, torch.bfloat16)

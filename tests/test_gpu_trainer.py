@@ -66,12 +66,13 @@ def test_one_optimizer_step_matches_torch_adamw_on_oracle_gradients(gpu):
     assert abs(opt.param_groups[0]["lr"] - args.lr * 0.9) < 1e-12  # linear decay after one scheduler step of 10
 
 
-def test_trainer_end_to_end_synthetic(gpu, tmp_path):
+@pytest.mark.parametrize("lowp", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_trainer_end_to_end_synthetic(gpu, tmp_path, lowp):
     from d2r_amd.data import SyntheticMSDDataset, make_loader
     from d2r_amd.train import MSDTrainer
     from oracle import d2r_oracle as O
     torch.manual_seed(0)
-    model, args = _tiny(torch.bfloat16)
+    model, args = _tiny(lowp)
     args.save_path = str(tmp_path) + "/"
     args.lr = 1e-4
     mk = lambda n, seed, sh: make_loader(SyntheticMSDDataset(n, 16, 64, 3, seed=seed, num_image_tokens=5), 4, sh, 0, drop_last=sh)
@@ -90,6 +91,8 @@ def test_trainer_end_to_end_synthetic(gpu, tmp_path):
                     args=args, logger=logger, writer=None)
     tr.train(None, None)
     assert len(losses) == 8 and all(l == l and abs(l) < 50 for l in losses), losses
+    if lowp == torch.float16:  # the trainer switched loss scaling on by itself and no step overflowed at the initial scale
+        assert tr.optimizer._scaler is not None and tr.optimizer.loss_scale >= 1024.0 and tr.optimizer._scaler["skipped"] == 0
     assert tr.samples_per_sec and tr.samples_per_sec > 0
     ck = os.path.join(str(tmp_path), "best_model.pth")
     assert os.path.exists(ck)
@@ -101,6 +104,67 @@ def test_trainer_end_to_end_synthetic(gpu, tmp_path):
     res = tr.evaluate(3)
     assert set(res) == {"eval_accuracy", "precision", "recall", "f_score", "global_step", "loss"}
     assert 0.0 <= res["eval_accuracy"] <= 1.0
+
+
+def test_fp16_loss_scaling_matches_fp32_steps_and_survives_an_overflow(gpu):
+    """fp16 compute dtype with the scaled loss (FusedAdamW.enable_loss_scaling): (i) three optimiser steps move the fp32
+    master weights like the fp32 compute path does (same data, same init: AdamW's first steps are +-lr per element, so the
+    comparison is on the SIGN pattern of the update where the gradient is not at the noise floor); (ii) a step whose
+    gradients overflow is dropped on the device (weights, moments, shadow unchanged), the host halves the scale one step
+    later and training continues with finite weights."""
+    from d2r_amd.params import FusedAdamW, ParamStore
+    from oracle import d2r_oracle as O
+    cfg = O.OracleConfig(text_layers=1, vision_layers=1, image_size=64, patch_size=32)
+    torch.manual_seed(5)
+    sd = {k: v.detach().clone() for k, v in _tiny(torch.float32)[0].state_dict().items()}  # the reference's construction-time init
+    batch = [t.to(gpu) for t in O.synthetic_batch(cfg, 4, 12, seed=4)]
+    final, stores = {}, {}
+    for dtype in (torch.float32, torch.float16):
+        model, args = _tiny(dtype)
+        model.load_state_dict(sd, strict=True)
+        model.to(gpu).set_compute_dtype(dtype).train()
+        store = ParamStore(model, dtype)
+        opt = FusedAdamW(store, lr=1e-3)
+        if dtype == torch.float16:
+            opt.enable_loss_scaling(init_scale=4096.0, growth_interval=2)
+        w0 = store.flat_w.clone()
+        for _ in range(3):
+            loss, _ = model(*batch)
+            opt.scale_loss(loss).backward()
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        final[dtype] = (store.flat_w - w0).cpu()
+        stores[dtype] = (model, store, opt)
+    d32, d16 = final[torch.float32], final[torch.float16]
+    moved = d32.abs() > 2.5e-3  # three steps of lr 1e-3 in one direction: elements with a stable gradient sign
+    assert int(moved.sum()) > 1e6
+    agree = float((torch.sign(d16[moved]) == torch.sign(d32[moved])).float().mean())
+    print(f"[fp16 vs fp32, three AdamW steps] update sign agreement {agree:.4f} over {int(moved.sum())} elements")
+    assert agree >= 0.97, agree
+    model, store, opt = stores[torch.float16]
+    assert opt.loss_scale == 8192.0, opt.loss_scale  # grew once after two clean steps (growth_interval = 2)
+    assert store.flat_lp.dtype == torch.float16 and torch.equal(store.flat_lp, store.flat_w.half())  # the shadow follows the masters
+    # (ii) an overflow: scale the loss so far up that fp16 activation gradients become inf
+    opt.loss_scale = 2.0 ** 40
+    before = (store.flat_w.clone(), opt.m.clone(), opt.v.clone(), store.flat_lp.clone())
+    count = opt.step_count
+    loss, _ = model(*batch)
+    opt.scale_loss(loss).backward()
+    assert not bool(torch.isfinite(store.flat_g).all()), "this loss scale was meant to overflow"
+    opt.step()
+    opt.zero_grad()
+    torch.cuda.synchronize()
+    for a, b in zip(before, (store.flat_w, opt.m, opt.v, store.flat_lp)):
+        assert torch.equal(a, b), "the overflowed step must change nothing"
+    opt.loss_scale = 4096.0
+    loss, _ = model(*batch)
+    opt.scale_loss(loss).backward()
+    opt.step()  # learns of the overflow here: halves the scale it finds, does not count the dropped step
+    opt.zero_grad()
+    torch.cuda.synchronize()
+    assert opt._scaler["skipped"] == 1 and opt.loss_scale == 2048.0 and opt.step_count == count + 1, (opt._scaler, opt.loss_scale)
+    assert not torch.equal(before[0], store.flat_w) and bool(torch.isfinite(store.flat_w).all())
 
 
 def test_cli_smoke(gpu, tmp_path):
