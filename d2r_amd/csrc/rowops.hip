@@ -163,28 +163,30 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   if (grp == 0 && c < ncols) out[c] = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
 }
 
-// stage 2 of LayerNorm backward: column c < D -> dgamma, else dbeta; ws rows are [2*D]; optional accumulation
+// stage 2 of LayerNorm backward: column c < D -> dgamma, else dbeta; ws rows are [2*D]; optional accumulation.
+// A block sums 16 columns: thread (g = tid / 16, l = tid % 16) walks the partial rows g, g + 16, ... (64-byte segments of the
+// freshly written, L2-resident partials), then the 16 groups are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void ln_sum_partials_kernel(const float* __restrict__ ws, int nparts, int D,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               int accumulate) {
-  __shared__ float sh[4][64];
-  const int l = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + l, stride = 2 * D;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  __shared__ float sh[16][17];
+  const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + l, stride = 2 * D;
+  float a0 = 0.f, a1 = 0.f;
   if (c < stride) {
     int p = grp;
-    for (; p + 12 < nparts; p += 16) {
+    for (; p + 16 < nparts; p += 32) {
       a0 += ws[(int64_t)p * stride + c];
-      a1 += ws[(int64_t)(p + 4) * stride + c];
-      a2 += ws[(int64_t)(p + 8) * stride + c];
-      a3 += ws[(int64_t)(p + 12) * stride + c];
+      a1 += ws[(int64_t)(p + 16) * stride + c];
     }
-    for (; p < nparts; p += 4) a0 += ws[(int64_t)p * stride + c];
+    if (p < nparts) a0 += ws[(int64_t)p * stride + c];
   }
-  sh[grp][l] = (a0 + a1) + (a2 + a3);
+  sh[grp][l] = a0 + a1;
   __syncthreads();
   if (grp == 0 && c < stride) {
-    const float t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += sh[g][l];
     float* dst = c < D ? dgamma + c : dbeta + (c - D);
     *dst = accumulate ? *dst + t : t;
   }
@@ -252,8 +254,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
-// Backward: each wave walks rows (stride = 4*gridDim.x) keeping per-column dgamma/dbeta partials in registers;
-// the block's 4 waves are combined through LDS and written to ws[block][2][D].
+// Backward: each wave walks rows (stride = 4*gridDim.x) keeping per-column dgamma/dbeta partials in registers; the loads of the
+// NEXT row are issued before the current row is reduced (one row per wave in flight left the kernel latency-bound at ~2 TB/s:
+// the chip needs ~13 MB outstanding, 1024 waves x 6 KB gave half of that).  The block's 4 waves are combined through LDS and
+// written to ws[block][2][D].
 template <typename T, int MAXP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ X,
                                                             const float* __restrict__ gamma,
@@ -276,22 +280,41 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       gm[i][j] = (pk < npk) ? gamma[pk * VEC + j] : 0.f;
     }
   }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    const T* x = X + row * D;
-    const T* dy = dY + row * D;
+  struct RowRegs {
+    Pack<T, VEC> x[MAXP], dy[MAXP], r[MAXP];
+    float mu, rs;
+  };
+  auto fetch = [&](int64_t row, RowRegs& q) {
+    q.mu = mean[row];
+    q.rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int pk = lane + i * 64;
+      if (pk < npk) {
+        q.x[i] = ld_pack<T, VEC>(X + row * D + pk * VEC);
+        q.dy[i] = ld_pack<T, VEC>(dY + row * D + pk * VEC);
+        if (dres) q.r[i] = ld_pack<T, VEC>(dres + row * D + pk * VEC);
+      }
+    }
+  };
+  const int64_t step = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  RowRegs cur, nxt;
+  if (row < rows) fetch(row, cur);
+  for (; row < rows; row += step) {
+    const bool more = row + step < rows;
+    if (more) fetch(row + step, nxt);  // in flight while this row is reduced and stored
+    const float mu = cur.mu, rs = cur.rs;
     float xh[MAXP][VEC], g[MAXP][VEC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       const int pk = lane + i * 64;
       if (pk < npk) {
-        Pack<T, VEC> px = ld_pack<T, VEC>(x + pk * VEC);
-        Pack<T, VEC> pd = ld_pack<T, VEC>(dy + pk * VEC);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          const float d = to_f<T>(pd.v[j]);
-          xh[i][j] = (to_f<T>(px.v[j]) - mu) * rs;
+          const float d = to_f<T>(cur.dy[i].v[j]);
+          xh[i][j] = (to_f<T>(cur.x[i].v[j]) - mu) * rs;
           g[i][j] = d * gm[i][j];
           s1 += g[i][j];
           s2 += g[i][j] * xh[i][j];
@@ -309,9 +332,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       if (pk < npk) {
         Pack<T, VEC> o;
         if (dres) {  // gradient arriving through the skip connection around this LayerNorm's block
-          const Pack<T, VEC> r = ld_pack<T, VEC>(dres + row * D + pk * VEC);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(rs * (g[i][j] - s1 - xh[i][j] * s2) + to_f<T>(r.v[j]));
+          for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(rs * (g[i][j] - s1 - xh[i][j] * s2) + to_f<T>(cur.r[i].v[j]));
         } else {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(rs * (g[i][j] - s1 - xh[i][j] * s2));
@@ -319,6 +341,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         st_pack<T, VEC>(dx + pk * VEC, o);
       }
     }
+    if (more) cur = nxt;
   }
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
@@ -340,7 +363,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 
 static int ln_blocks(int64_t rows) {
   int64_t b = (rows + 3) / 4;
-  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));  // two 4-wave blocks per CU, two rows per wave in flight
 }
 
 extern "C" size_t d2r_layernorm_bwd_workspace(int64_t rows, int D) {
@@ -408,7 +431,7 @@ extern "C" int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, co
     return d2r_fail(D2R_ERR_INVALID, "d2r_layernorm_bwd: bad dtype %d", dtype);
   }
   if (int rc = d2r_check_launch("d2r_layernorm_bwd")) return rc;
-  hipLaunchKernelGGL(ln_sum_partials_kernel, dim3(d2r_cdiv(2 * D, 64)), dim3(256), 0, st, ws, nb, D, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_sum_partials_kernel, dim3(d2r_cdiv(2 * D, 16)), dim3(256), 0, st, ws, nb, D, dgamma, dbeta, accumulate);
   return d2r_check_launch("d2r_layernorm_bwd(sum)");
 }
 

@@ -9,13 +9,15 @@ from d2r_amd.config import TextConfig, VisionConfig, default_args
 from d2r_amd.params import ParamStore
 
 gpu = torch.device("cuda:0")
-layers, B, L = int(os.environ.get("LAYERS", "12")), 8, 128
-torch.manual_seed(2023)
+env = lambda k, d: int(os.environ.get(k, d))
+layers, B, L, IMG = env("LAYERS", "12"), env("BATCH", "8"), env("SEQ", "128"), env("IMG", "224")
+DR, CELLS, CLASSES = env("DR", "3"), env("CELLS", "6"), env("CLASSES", "3")
+torch.manual_seed(env("SEED", "2023"))
 tc = TextConfig(num_hidden_layers=layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-vc = VisionConfig(num_hidden_layers=layers, image_size=224, patch_size=16)
-mk = lambda: M.UnimoModelF(default_args(), vc, tc)
+vc = VisionConfig(num_hidden_layers=layers, image_size=IMG, patch_size=16)
+mk = lambda: M.UnimoModelF(default_args(DR_step=DR, num_cells=CELLS), vc, tc, num_classes=CLASSES)
 sd = {k: v.detach().clone() for k, v in mk().state_dict().items()}
-cfg = O.OracleConfig(text_layers=layers, vision_layers=layers, image_size=224, patch_size=16)
+cfg = O.OracleConfig(text_layers=layers, vision_layers=layers, image_size=IMG, patch_size=16, DR_step=DR, num_cells=CELLS, num_classes=CLASSES)
 batch = [t.to(gpu) for t in O.synthetic_batch(cfg, B, L, seed=9, ragged=False)]
 grads = {}
 for dtype in (torch.float32, torch.float16, torch.bfloat16):
@@ -36,13 +38,15 @@ for dtype in (torch.float16, torch.bfloat16):
     for n, r in ref.items():
         g = grads[dtype][n]
         d, gg, rr = float((g * r).sum()), float(g.pow(2).sum()), float(r.pow(2).sum())
-        key = ".".join(n.split(".")[:4]) if n.startswith("model.") else n.split(".")[0]
+        key = ".".join(n.split(".")[:int(os.environ.get("DEPTH", "4"))]) if n.startswith("model.") else n.split(".")[0]
         a = parts.setdefault(key, [0.0, 0.0, 0.0]); a[0] += d; a[1] += gg; a[2] += rr
         tot[0] += d; tot[1] += gg; tot[2] += rr
     print(f"== {dtype}: global cos {tot[0] / (tot[1] * tot[2]) ** 0.5:.4f} |g|/|ref| {(tot[1] / tot[2]) ** 0.5:.3f}")
     for k, (d, gg, rr) in parts.items():
         print(f"   {k:60s} cos {d / max((gg * rr) ** 0.5, 1e-300):.4f} |g|/|ref| {(gg / max(rr, 1e-300)) ** 0.5:.3f} |ref| {rr ** 0.5:.2e}")
 
+if os.environ.get('NO_CONTROL'):
+    sys.exit(0)
 # Control experiment: the fp32 path with ONLY the two pooled vectors entering Block rounded to fp16 / bf16 (everything else fp32)
 for rd in (torch.float16, torch.bfloat16):
     model = mk()
