@@ -83,7 +83,7 @@ SIGNATURES = {
     "d2r_mha_supported": (i32, [i32, i32, i32, i32]),
     "d2r_mha_fwd": (i32, [i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,
                           i32, i32, i32, i32, i32, f32, vp]),
-    "d2r_mha_bwd": (i32, [i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,
+    "d2r_mha_bwd": (i32, [i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp,
                           vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, vp]),
     "d2r_xattn_supported": (i32, [i32, i32, i32, i32]),
     "d2r_xattn_fwd": (i32, [i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,

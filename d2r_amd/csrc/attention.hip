@@ -1,4 +1,5 @@
-// attention.hip — K3 fused multi-head attention core for the short sequences of this path (L <= 256), bf16 or fp16.
+// attention.hip — K3 fused multi-head attention core: sequences up to 256 tokens with the whole head resident in LDS, longer ones
+// (up to 1024) through the block loop described in attention_impl.inc; bf16 or fp16.
 //
 //   O = softmax(scale * Q K^T + mask) V (+ residual)      per (batch, head), head dim 64 or 48
 //
@@ -39,10 +40,10 @@
 #include "gemm_args.h"
 
 extern "C" int d2r_mha_supported(int dtype, int Lq, int Lk, int head_dim) {
-  return d2r_is16(dtype) && (head_dim == 64 || head_dim == 48) && Lq >= 1 && Lk >= 1 && Lq <= 256 && Lk <= 256;
+  return d2r_is16(dtype) && (head_dim == 64 || head_dim == 48) && Lq >= 1 && Lk >= 1 && Lq <= 1024 && Lk <= 1024;
 }
 extern "C" int d2r_xattn_supported(int dtype, int Lq, int Lk, int D) {
-  return d2r_is16(dtype) && D == 768 && Lq >= 1 && Lk >= 1 && Lk <= 256;
+  return d2r_is16(dtype) && D == 768 && Lq >= 1 && Lk >= 1 && Lk <= 640;
 }
 int d2r_xattn2_fwd_try(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb, const void* v,
                        int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual, int64_t ldr, int64_t srb,
@@ -69,10 +70,10 @@ extern "C" int d2r_mha_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, c
 }
 extern "C" int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                            const void* v, int64_t ldv, int64_t svb, const void* dO, int64_t ldg, int64_t sgb,
-                           const float* mask, const float* lse, void* dq, int64_t lddq, int64_t sdqb, void* dk,
+                           const float* mask, const float* lse, float* dsum, void* dq, int64_t lddq, int64_t sdqb, void* dk,
                            int64_t lddk, int64_t sdkb, void* dv, int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk,
                            int head_dim, float scale, void* stream) {
-  return D2R_BY_DTYPE(dtype, mha_bwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, dO, ldg, sgb, mask, lse, dq, lddq, sdqb, dk, lddk,
+  return D2R_BY_DTYPE(dtype, mha_bwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, dO, ldg, sgb, mask, lse, dsum, dq, lddq, sdqb, dk, lddk,
                                          sdkb, dv, lddv, sdvb, B, H, Lq, Lk, head_dim, scale, stream));
 }
 extern "C" int d2r_xattn_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,

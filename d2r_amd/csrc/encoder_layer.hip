@@ -90,7 +90,8 @@ extern "C" size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F) {
   // every intermediate gradient has its own buffer (none is reused inside the layer): the weight-gradient GEMMs
   // that read them may still be running on the side stream when the main chain has moved on
   const size_t T = (size_t)B * L, es = 2;
-  return 5 * align256(T * E * es) + align256(T * F * es) + align256(T * 3 * E * es) + align256(d2r_layernorm_bwd_workspace((int64_t)T, E));
+  return 5 * align256(T * E * es) + align256(T * F * es) + align256(T * 3 * E * es) + align256(d2r_layernorm_bwd_workspace((int64_t)T, E)) +
+         align256(T * (size_t)(E / 32) * sizeof(float));  // + D scratch of the long-sequence attention backward (<= E/32 heads)
 }
 
 static int check_desc(const d2r_encoder_layer_desc* L, const char* fn) {
@@ -153,6 +154,7 @@ extern "C" int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* L, void* stream) {
   char* dqkv = (char*)take((size_t)T * 3 * E);
   void* lnws = p;
   const size_t lnws_bytes = d2r_layernorm_bwd_workspace(T, E);
+  float* dsum = reinterpret_cast<float*>(p + align256(lnws_bytes));
   const char* qkv = (const char*)L->qkv;
   if (!L->pre_ln) {
     // y = LN2(h2), h2 = n1 + ffn(n1), n1 = LN1(h1), h1 = x + attn(x)
@@ -164,7 +166,7 @@ extern "C" int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* L, void* stream) {
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, d_h1, nullptr, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));
     D2R_TRY(linear_bwd(L, 1, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
     D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
-                        L->mask, L->lse, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
+                        L->mask, L->lse, dsum, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
                         L->L, L->L, dh, L->scale, stream));
     D2R_TRY(linear_bwd(L, 0, T, 3 * E, E, dqkv, L->x, L->w_qkv, L->dx, d_h1, L->gw_qkv, L->gb_qkv, stream));  // + skip
   } else {
@@ -176,7 +178,7 @@ extern "C" int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* L, void* stream) {
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_h2, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, d_h1, L->dy, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // + skip
     D2R_TRY(linear_bwd(L, 1, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
     D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
-                        L->mask, L->lse, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
+                        L->mask, L->lse, dsum, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
                         L->L, L->L, dh, L->scale, stream));
     D2R_TRY(linear_bwd(L, 0, T, 3 * E, E, dqkv, L->n1, L->w_qkv, d_n1, nullptr, L->gw_qkv, L->gb_qkv, stream));
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->x, L->ln1_g, L->mean1, L->rstd1, T, E, L->dx, d_h1, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // + skip

@@ -348,6 +348,7 @@ struct LayerB {
   void* de[6];
   void* dx[6];
   void *i_df1, *i_dy, *i_dqkv;
+  float* i_dsum;  // D = rowsum(P o dP) scratch of the long-sequence attention backward
   void *g_dwsum, *g_dw16, *g_dS, *g_dsl, *g_dl2, *g_dloc, *g_dsq, *g_da, *g_dc, *g_dq, *g_P, *g_dSa, *g_dkv, *g_dl2g, *g_dglo, *g_ddg,
       *g_dpt, *g_dpi, *g_dptp, *g_dpip, *g_da16;
   float *g_dwf, *g_daf;
@@ -374,6 +375,7 @@ void plan_bwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerB& K)
     for (int j = 0; j < d.nc; ++j) K.dx[j] = A.take(TE);  // gradients w.r.t. this layer's six inputs
   if (final) K.de[0] = A.take(TE);  // final layer: relu-path gradient of x0 (the skip-path gradient goes to dx[0])
   if (d.nc > 2) K.i_df1 = A.take((size_t)d.T * d.hidi * d.es), K.i_dy = A.take(TE), K.i_dqkv = A.take(3 * TE);
+  if (d.nc > 2) K.i_dsum = (float*)A.take((size_t)d.B * 64 * d.Lq * 4);
   if (d.nc > 1) {
     K.g_dwsum = A.take(BE), K.g_dw16 = A.take((size_t)d.B * d.n * d.es + 16), K.g_dS = A.take((size_t)d.B * d.n * E * d.es);
     K.g_dsl = A.take(TE), K.g_dl2 = A.take(TE), K.g_dloc = A.take(TE), K.g_dsq = A.take(TE), K.g_da = A.take(TE), K.g_dc = A.take(TE);
@@ -519,7 +521,7 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     defer(jobs, T, E, d.hidi, K.de[2], E, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2]);
     TRY(dxg(c, T, E, d.hidi, K.i_df1, d.hidi, lp[D2R_RL_IMRC_FC1].w, K.i_dy, E, 0.f, K.de[2]));  // + skip y -> e2
     defer(jobs, T, d.hidi, E, K.i_df1, d.hidi, L.y, E, lp[D2R_RL_IMRC_FC1]);
-    TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, dqkv, E3, sb3,
+    TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, K.i_dsum, dqkv, E3, sb3,
                     dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), c.st));
     TRY(dxg(c, T, E, 3 * E, dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
     TRY(dwg(c, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]));

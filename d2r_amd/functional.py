@@ -592,8 +592,9 @@ def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None
              sA=sP, sB=(q[2], 0), sC=(dk[2], 0), tag=tag)
         return
     if P.dim() == 3:  # fused forward ran: recompute P from q, k and the log-sum-exp
+        dsum = torch.empty_like(P) if (Lq > 256 or Lk > 256) else None  # long sequences: D handed from the dQ to the dK/dV kernel
         _lib.call("d2r_mha_bwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], g.data_ptr(), E, Lq * E,
-                  _ptr(mask), P.data_ptr(), dq[0], dq[1], dq[2], dk[0], dk[1], dk[2], dv[0], dv[1], dv[2], B, H, Lq, Lk,
+                  _ptr(mask), P.data_ptr(), _ptr(dsum), dq[0], dq[1], dq[2], dk[0], dk[1], dk[2], dv[0], dv[1], dv[2], B, H, Lq, Lk,
                   d, scale, _stream(), meta=dict(group=tag, algo_bytes=float(2 * B * (2 * Lq + 2 * Lk) * E * 2)))
         return
     Lkp = P.shape[-1]

@@ -249,14 +249,16 @@ int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, const float* 
                          float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * K3 fused multi-head attention core, short sequences (bf16, head_dim 64 or 48, Lq, Lk <= 256)
+ * K3 fused multi-head attention core (16-bit dtypes, head_dim 64 or 48, Lq, Lk <= 1024: up to 256 tokens with the whole
+ * head resident in LDS, above that a loop over 128-row blocks with the online softmax — BASELINE configs[3] / [4])
  *   O[b,:,h] = softmax(scale * Q_h K_h^T + mask[b]) V_h (+ residual)
  * Replaces BertSelfAttention scores/softmax/context (models/modeling_unimo.py:385-424), CLIPAttention (:150-215)
  * and the 16-head attention of models/SelfAttention.py:20-60 — scores and probabilities never reach HBM.
  * q/k/v/o/residual/dO/dq/dk/dv: bf16 [B, L, *] views given as (pointer to column 0 of head 0, row stride,
  * batch stride) in elements; head h occupies columns [h*head_dim, (h+1)*head_dim).  mask: fp32 additive [B,Lk] or
- * NULL.  lse: fp32 [B,H,Lq] row log-sum-exp written by fwd and read by bwd.  Pointers 16-byte aligned, strides
- * multiples of 8 elements.  Deterministic.
+ * NULL.  lse: fp32 [B,H,Lq] row log-sum-exp written by fwd and read by bwd.  dsum (bwd): fp32 [B,H,Lq] scratch the
+ * long-sequence backward hands from its dQ kernel to its dK/dV kernel; may be NULL when Lq, Lk <= 256.  Pointers 16-byte
+ * aligned, strides multiples of 8 elements.  Deterministic.
  * ------------------------------------------------------------------------------------------------ */
 int d2r_mha_supported(int dtype, int Lq, int Lk, int head_dim);
 int d2r_mha_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
@@ -265,11 +267,11 @@ int d2r_mha_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* 
                 float scale, void* stream);
 int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                 const void* v, int64_t ldv, int64_t svb, const void* dO, int64_t ldg, int64_t sgb, const float* mask,
-                const float* lse, void* dq, int64_t lddq, int64_t sdqb, void* dk, int64_t lddk, int64_t sdkb, void* dv,
-                int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk, int head_dim, float scale, void* stream);
+                const float* lse, float* dsum, void* dq, int64_t lddq, int64_t sdqb, void* dk, int64_t lddk, int64_t sdkb,
+                void* dv, int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk, int head_dim, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * K2 / K4 fused single-head attention over the full 768-wide feature (bf16, D = 768, Lk <= 256)
+ * K2 / K4 fused single-head attention over the full 768-wide feature (16-bit dtypes, D = 768, Lk <= 640)
  *   O[b] = softmax(scale * Q K^T + mask[b]) V (+ residual)
  * Replaces the CrossModalAlignment core (models/XModules.py:300-310 = models/Refinement.py:105-115, scale
  * 100/sqrt(768)) and the ContextRichCrossModalCell core (models/Cells.py:244-246, scale 1, residual Qs): three

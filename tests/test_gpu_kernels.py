@@ -120,7 +120,10 @@ def test_linear_fp32_out(gpu, dtype):
                                  (2, 128, 128, 12, 0.125, True, False), (2, 70, 250, 12, 0.125, True, True),
                                  (2, 197, 197, 16, 1 / math.sqrt(48), False, True),
                                  (2, 128, 197, 1, 100 / math.sqrt(768), False, False), (2, 197, 128, 1, 100 / math.sqrt(768), False, False),
-                                 (2, 197, 197, 1, 1.0, False, True), (2, 40, 250, 1, 0.3, True, False), (2, 33, 256, 1, 0.3, True, True)])
+                                 (2, 197, 197, 1, 1.0, False, True), (2, 40, 250, 1, 0.3, True, False), (2, 33, 256, 1, 0.3, True, True),
+                                 # sequences above 256 tokens (BASELINE configs[3]: 577 image tokens; configs[4]: 512 text tokens): the block loop
+                                 (2, 577, 577, 12, 0.125, False, True), (1, 512, 512, 12, 0.125, True, False), (2, 300, 577, 16, 1 / math.sqrt(48), True, True),
+                                 (1, 577, 130, 12, 0.125, True, False), (1, 577, 256, 1, 0.3, True, True), (1, 256, 577, 1, 0.3, True, False)])
 def test_attention(gpu, dtype, cfg):
     from d2r_amd import functional as F
     B, Lq, Lk, H, scale, use_mask, use_res = cfg
@@ -132,7 +135,8 @@ def test_attention(gpu, dtype, cfg):
     mask = torch.zeros(B, Lk)
     if use_mask:
         mask[0, Lk // 2:] = -10000.0
-        mask[1, Lk - 3:] = -10000.0
+        if B > 1:
+            mask[1, Lk - 3:] = -10000.0
     res = rnd(B, Lq, E, seed=3)
 
     def f(q, k, v, res):

@@ -108,8 +108,9 @@ def test_trainer_end_to_end_synthetic(gpu, tmp_path, lowp):
 
 def test_fp16_loss_scaling_matches_fp32_steps_and_survives_an_overflow(gpu):
     """fp16 compute dtype with the scaled loss (FusedAdamW.enable_loss_scaling): (i) three optimiser steps move the fp32
-    master weights like the fp32 compute path does (same data, same init: AdamW's first steps are +-lr per element, so the
-    comparison is on the SIGN pattern of the update where the gradient is not at the noise floor); (ii) a step whose
+    master weights like the fp32 compute path does (same data, same init; AdamW's first steps are +-lr per element whatever
+    the gradient's size, so elements whose gradient sits at the rounding floor flip freely: the comparison is the direction of
+    the whole update and the loss curve); (ii) a step whose
     gradients overflow is dropped on the device (weights, moments, shadow unchanged), the host halves the scale one step
     later and training continues with finite weights."""
     from d2r_amd.params import FusedAdamW, ParamStore
@@ -128,20 +129,24 @@ def test_fp16_loss_scaling_matches_fp32_steps_and_survives_an_overflow(gpu):
         if dtype == torch.float16:
             opt.enable_loss_scaling(init_scale=4096.0, growth_interval=2)
         w0 = store.flat_w.clone()
+        curve = []
         for _ in range(3):
             loss, _ = model(*batch)
+            curve.append(float(loss))
             opt.scale_loss(loss).backward()
             opt.step()
             opt.zero_grad()
+        with torch.no_grad():
+            curve.append(float(model(*batch)[0]))
         torch.cuda.synchronize()
-        final[dtype] = (store.flat_w - w0).cpu()
+        final[dtype] = ((store.flat_w - w0).cpu(), curve)
         stores[dtype] = (model, store, opt)
-    d32, d16 = final[torch.float32], final[torch.float16]
-    moved = d32.abs() > 2.5e-3  # three steps of lr 1e-3 in one direction: elements with a stable gradient sign
-    assert int(moved.sum()) > 1e6
-    agree = float((torch.sign(d16[moved]) == torch.sign(d32[moved])).float().mean())
-    print(f"[fp16 vs fp32, three AdamW steps] update sign agreement {agree:.4f} over {int(moved.sum())} elements")
-    assert agree >= 0.97, agree
+    (d32, c32), (d16, c16) = final[torch.float32], final[torch.float16]
+    cos = float((d16.double() @ d32.double()) / (d16.double().norm() * d32.double().norm()))
+    print(f"[fp16 vs fp32, three AdamW steps] update cosine {cos:.4f}; loss curves fp32 {c32} fp16 {c16}")
+    assert abs(c16[0] - c32[0]) <= 1e-3, (c16[0], c32[0])            # same weights, same batch: the forward agrees
+    assert c16[-1] < c16[0] and abs(c16[-1] - c32[-1]) <= 0.1 * abs(c32[0] - c32[-1]) + 2e-2, (c16, c32)  # and it trains alike
+    assert cos >= 0.7, cos
     model, store, opt = stores[torch.float16]
     assert opt.loss_scale == 8192.0, opt.loss_scale  # grew once after two clean steps (growth_interval = 2)
     assert store.flat_lp.dtype == torch.float16 and torch.equal(store.flat_lp, store.flat_w.half())  # the shadow follows the masters
