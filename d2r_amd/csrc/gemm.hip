@@ -18,6 +18,9 @@
 // include/d2r_hip.h, section K11.
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "gemm_args.h"
 
 template <typename T, int LAYOUT, int BM, int BN, int WAVES_M, int WAVES_N, int NBUF, bool GROUPED = false>
@@ -385,6 +388,66 @@ static int g_vepi = env_int("D2R_GEMM_VEPI", 1);
 static int g_tile = env_int("D2R_GEMM_TILE", -1);
 static int g_xcd = env_int("D2R_GEMM_XCD", 1);
 static int g_wgrad_glds = env_int("D2R_WGRAD_GLDS", 1);
+
+// ---- optional per-launch timing of the GEMM entry points (bench.py's roofline leg) -----------------------------------------
+// The whole-layer / whole-module C calls (encoder_layer.hip, interaction.hip) launch their GEMMs from inside the library, where
+// a Python-side event bracket cannot see them.  When enabled, d2r_gemm and d2r_gemm_tn_grouped bracket each launch with a pair
+// of HIP events on the launching stream and remember (family, flops, algorithmic bytes); d2r_gemm_timer_read resolves them.
+// Measurement aid: off by default, one mutex acquisition per GEMM when off is avoided by the plain flag test.
+struct GemmTimerRec {
+  int family;  // dtype * 8 + layout * 2 + grouped
+  double flops, bytes;
+  hipEvent_t e0, e1;
+};
+static std::vector<GemmTimerRec> g_timer_recs;
+static std::mutex g_timer_mu;
+static volatile int g_timer_on = 0;
+
+struct GemmTimerScope {
+  bool armed = false;
+  GemmTimerRec rec;
+  hipStream_t st;
+  GemmTimerScope(hipStream_t stream, int family, double flops, double bytes) : st(stream) {
+    if (!g_timer_on) return;
+    rec.family = family, rec.flops = flops, rec.bytes = bytes;
+    if (hipEventCreate(&rec.e0) != hipSuccess) return;
+    if (hipEventCreate(&rec.e1) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
+    (void)hipEventRecord(rec.e0, st);
+    armed = true;
+  }
+  ~GemmTimerScope() {
+    if (!armed) return;
+    (void)hipEventRecord(rec.e1, st);
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    g_timer_recs.push_back(rec);
+  }
+};
+
+extern "C" int d2r_gemm_timer(int on) {
+  std::lock_guard<std::mutex> lk(g_timer_mu);
+  if (on) {
+    for (auto& r : g_timer_recs) (void)hipEventDestroy(r.e0), (void)hipEventDestroy(r.e1);
+    g_timer_recs.clear();
+  }
+  g_timer_on = on ? 1 : 0;
+  return D2R_OK;
+}
+
+extern "C" int d2r_gemm_timer_read(int* family, double* flops, double* bytes, float* ms, int capacity) {
+  std::lock_guard<std::mutex> lk(g_timer_mu);
+  int n = 0;
+  for (auto& r : g_timer_recs) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess && n < capacity && family) {
+      family[n] = r.family, flops[n] = r.flops, bytes[n] = r.bytes, ms[n] = t;
+      ++n;
+    }
+    (void)hipEventDestroy(r.e0), (void)hipEventDestroy(r.e1);
+  }
+  const int total = (int)g_timer_recs.size();
+  g_timer_recs.clear();
+  return family ? n : total;
+}
 extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
   g_nbuf = nbuf & 0xff;
   g_xcd = (nbuf >> 8) & 1 ? 0 : 1;  // bit 8 of the first argument disables the XCD-aware tile order (A/B runs)
@@ -549,6 +612,9 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   }
   const int batch = d->nb * d->nh;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const double cs_ = (double)d2r_esize(d->c_dtype);
+  GemmTimerScope timed(st, d->dtype * 8 + d->layout * 2, 2.0 * batch * d->M * d->N * (double)d->K,
+                       (double)batch * (((double)d->M * d->K + (double)d->N * d->K) * es + (double)d->M * d->N * cs_ * (d->beta != 0.f ? 2 : 1)));
   if (d->dtype == D2R_BF16) return launch_dtype<bf16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
   if (d->dtype == D2R_F16) return launch_dtype<f16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
   return launch_dtype<float>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
@@ -618,6 +684,9 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
     }
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // algorithmic bytes: both operands once, the fp32 sink read and written
+  GemmTimerScope timed(st, dtype * 8 + D2R_GEMM_TN * 2 + 1, 2.0 * count * M * N * (double)K,
+                       (double)count * (((double)K * M + (double)K * N) * es + 2.0 * M * N * 4.0));
   if (dtype == D2R_BF16) return launch_grouped_tn<bf16_t>(a, h_A, h_B, h_C, h_dbias, count, st);
   if (dtype == D2R_F16) return launch_grouped_tn<f16_t>(a, h_A, h_B, h_C, h_dbias, count, st);
   return launch_grouped_tn<float>(a, h_A, h_B, h_C, h_dbias, count, st);

@@ -56,14 +56,22 @@ def shard_batch(batch, rank: int, world: int):
 
 
 class FlatGradReducer:
-    """Bucketed SUM all-reduce of a flat fp32 gradient buffer."""
+    """Bucketed SUM all-reduce of a flat fp32 gradient buffer.  ``comm_dtype=torch.bfloat16`` sends every bucket as bf16
+    (half the bytes on the xGMI links; the sum over ranks is then formed in bf16 by the collective, the fp32 buffer gets the
+    rounded result) - an optional trade of gradient precision for link time, off by default."""
 
-    def __init__(self, flat_g: torch.Tensor, bucket_elems: int, group=None):
+    def __init__(self, flat_g: torch.Tensor, bucket_elems: int, group=None, comm_dtype: torch.dtype = torch.float32):
         self.flat_g, self.group = flat_g, group
         n = flat_g.numel()
         self.bounds = [(a, min(n, a + bucket_elems)) for a in range(0, n, bucket_elems)]
         self.handles = []
         self.comm_stream = torch.cuda.Stream() if flat_g.is_cuda else None
+        assert comm_dtype in (torch.float32, torch.bfloat16)
+        self.comm_dtype = comm_dtype
+        # one staging buffer per bucket (buckets are in flight together when the reduction overlaps with backward)
+        self.staging = ([torch.empty(b - a, dtype=comm_dtype, device=flat_g.device) for a, b in self.bounds]
+                        if comm_dtype != torch.float32 else None)
+        self._unstage = []
 
     def launch_bucket(self, i: int):
         a, b = self.bounds[i]
@@ -77,9 +85,18 @@ class FlatGradReducer:
             for st in list(F._COMPUTE_STREAMS) + F.wgrad_streams():
                 self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
-                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._issue(i, view)
         else:
+            self._issue(i, view)
+
+    def _issue(self, i: int, view: torch.Tensor):
+        if self.staging is None:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        buf = self.staging[i]
+        buf.copy_(view)  # fp32 -> bf16 on the communication stream
+        self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._unstage.append((view, buf))
 
     def reduce_all(self):
         # reverse order = roughly reverse execution order (head and routing modules first)
@@ -88,21 +105,48 @@ class FlatGradReducer:
         self.finish()
 
     def finish(self):
-        for h in self.handles:
-            h.wait()
+        if self.comm_stream is not None and self._unstage:
+            with torch.cuda.stream(self.comm_stream):
+                for h in self.handles:
+                    h.wait()
+                for view, buf in self._unstage:
+                    view.copy_(buf)
+        else:
+            for h in self.handles:
+                h.wait()
+            for view, buf in self._unstage:
+                view.copy_(buf)
         self.handles.clear()
+        self._unstage.clear()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
 class DataParallel:
     def __init__(self, store: ParamStore, optimizer, model: torch.nn.Module, bucket_mb: int = 128, group=None,
-                 overlap: bool = False, bucket_elems: Optional[int] = None):
+                 overlap: bool = False, bucket_elems: Optional[int] = None, grad_comm_dtype: torch.dtype = torch.float32,
+                 shard_optimizer: bool = False):
+        """grad_comm_dtype: torch.bfloat16 sends the gradient buckets as bf16 (see FlatGradReducer).
+        shard_optimizer: reduce-scatter + all-gather instead of all-reduce - every rank receives the summed gradients of ITS
+        1/world slice of the flat buffer only, runs the fused AdamW on that slice (1/world of the optimiser's 30 bytes per
+        parameter of HBM traffic) and the updated fp32 weights are all-gathered; same bytes on the links as the all-reduce.
+        Not combined with overlap (the whole buffer is scattered after backward)."""
         self.store, self.opt, self.model, self.group = store, optimizer, model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.reducer = FlatGradReducer(store.flat_g, bucket_elems or bucket_mb * (1 << 20) // 4, group) if self.world > 1 else None
+        self.shard_optimizer = bool(shard_optimizer) and self.world > 1
+        if self.shard_optimizer and overlap:
+            raise ValueError("shard_optimizer=True reduces the whole buffer after backward: use overlap=False")
+        self.reducer = (FlatGradReducer(store.flat_g, bucket_elems or bucket_mb * (1 << 20) // 4, group, grad_comm_dtype)
+                        if self.world > 1 else None)
         optimizer.grad_scale = 1.0 / self.world
+        if self.shard_optimizer:
+            n = store.flat_g.numel()
+            per = n // (self.world * 4) * 4  # 16-byte aligned slices; the tail (< 4 * world elements) is all-reduced and updated by all
+            self.shard = (self.rank * per, (self.rank + 1) * per)
+            self.shard_body = per * self.world
+            optimizer.element_range = self.shard if per > 0 else (0, 0)
+            optimizer.element_tail = (self.shard_body, n)
         self.overlap = overlap and self.world > 1
         self._pending: List[int] = []
         self._bucket_of = {}
@@ -154,7 +198,34 @@ class DataParallel:
                 self._count0[i] += 1
             self._bucket_of[id(p)] = (bi, be)
             p._d2r_ready_cb = self._ready
-            p.register_post_accumulate_grad_hook(self._ready)
+        # Autograd's post-accumulate hooks are registered LAZILY, from a forward pre-hook of the module that owns the tensor,
+        # i.e. under the HIP stream that module runs on.  Registering a hook creates the tensor's AccumulateGrad node, and the
+        # node accumulates on the stream that was current at its creation: registered here (launching stream), the in-place
+        # `grad += piece` of a parameter produced on a branch stream would run on the launching stream, unordered against a
+        # second piece that a sink-writing kernel adds on the branch stream - a read-modify-write race on the flat gradient
+        # buffer (seen as an intermittent difference between overlapped and plain runs of the two-rank rehearsal).
+        owner = {}
+        for mod in (self.model.modules() if self.model is not None else ()):
+            for t in mod.parameters(recurse=False):
+                owner.setdefault(id(t), mod)
+            for fz in (getattr(mod, "_fused", None) or {}).values():
+                owner.setdefault(id(fz.weight), mod)
+                owner.setdefault(id(fz.bias), mod)
+        per_module = {}
+        for p, _, _ in self.store.units():
+            mod = owner.get(id(p))
+            if mod is None:  # a tensor no module owns (unit tests drive the reducer with bare tensors): single-stream use
+                p.register_post_accumulate_grad_hook(self._ready)
+                continue
+            per_module.setdefault(mod, []).append(p)
+        self._hook_handles = []
+        for mod, tensors in per_module.items():
+            def once(m, args, tensors=tensors, box=[]):
+                if not box:
+                    box.append(True)
+                    for t in tensors:
+                        t.register_post_accumulate_grad_hook(self._ready)
+            self._hook_handles.append(mod.register_forward_pre_hook(once))
         self._expect = None  # id(parameter) -> reports per step, learnt in the first overlapped step
         from . import functional as F
         F.EARLY_FLUSH = True  # queued weight gradients of the routing modules go out before the encoders' backward
@@ -192,6 +263,9 @@ class DataParallel:
     def reduce_gradients(self):
         if self.world == 1:
             return
+        if self.shard_optimizer:
+            self._reduce_scatter()
+            return
         if self.overlap:
             if self._expect is None:
                 self._expect = dict(self._got)
@@ -203,3 +277,29 @@ class DataParallel:
             self.reducer.finish()
         else:
             self.reducer.reduce_all()
+
+    # -- sharded optimiser: reduce-scatter the gradients, all-gather the updated weights ----------------------------------
+    def _reduce_scatter(self):
+        from . import functional as F
+        cur = torch.cuda.current_stream() if self.store.flat_g.is_cuda else None
+        if cur is not None:
+            for st in list(F._COMPUTE_STREAMS) + F.wgrad_streams():
+                cur.wait_stream(st)
+        g, (a, b), body = self.store.flat_g, self.shard, self.shard_body
+        if body > 0:
+            if dist.get_backend(self.group) == "gloo":  # gloo has no reduce-scatter: the rehearsal sums everything and keeps its slice
+                dist.all_reduce(g[:body], op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.reduce_scatter_tensor(g[a:b], g[:body], op=dist.ReduceOp.SUM, group=self.group)
+        if body < g.numel():
+            dist.all_reduce(g[body:], op=dist.ReduceOp.SUM, group=self.group)
+
+    def gather_parameters(self):
+        """After optimizer.step() of a sharded step: every rank publishes its updated slice of the fp32 weights; the 16-bit
+        shadow is re-derived locally."""
+        if not self.shard_optimizer:
+            return
+        w, (a, b), body = self.store.flat_w, self.shard, self.shard_body
+        if body > 0:
+            dist.all_gather_into_tensor(w[:body], w[a:b].clone(), group=self.group)
+        self.store.refresh_lowp()

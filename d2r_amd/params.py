@@ -184,6 +184,9 @@ class FusedAdamW:
         self.grad_scale = 1.0  # 1/world_size under data parallelism (gradients are SUM-reduced)
         self.loss_scale = 1.0  # > 1 after enable_loss_scaling() (fp16 compute dtype)
         self._scaler = None
+        # sharded data parallelism (d2r_amd.dp, shard_optimizer=True): this rank updates [element_range) and the common tail only
+        self.element_range = None
+        self.element_tail = None
         names = {0: "other", 1: "text", 2: "vision", 3: "fc"}
         self.param_groups = []
         for g, (a, b) in sorted(store.group_ranges.items()):
@@ -237,6 +240,21 @@ class FusedAdamW:
         sc["event"] = torch.cuda.Event()
         sc["event"].record()
 
+    def _owned(self, rng):
+        """The parts of a parameter group's element range this rank updates: all of it, or (sharded optimiser) its
+        intersections with the rank's slice and with the common tail."""
+        a, b = rng
+        if b <= a:
+            return []
+        if self.element_range is None:
+            return [(a, b)]
+        out = []
+        for lo, hi in (self.element_range, self.element_tail):
+            x, y = max(a, lo), min(b, hi)
+            if y > x:
+                out.append((x, y))
+        return out
+
     def step(self):
         from .functional import wgrad_join
         wgrad_join()
@@ -248,13 +266,11 @@ class FusedAdamW:
         self.step_count += 1
         st = self.store
         for pg in self.param_groups:
-            a, b = pg["range"]
-            if b <= a:
-                continue
-            lp = None if st.flat_lp is None else st.flat_lp.data_ptr() + 2 * a
-            _lib.call("d2r_adamw_step", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
-                      self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, st.lp_dtype, b - a, pg["lr"], self.betas[0],
-                      self.betas[1], self.eps, pg["weight_decay"], self.step_count, self.grad_scale / used, skip, _stream())
+            for a, b in self._owned(pg["range"]):
+                lp = None if st.flat_lp is None else st.flat_lp.data_ptr() + 2 * a
+                _lib.call("d2r_adamw_step", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
+                          self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, st.lp_dtype, b - a, pg["lr"], self.betas[0],
+                          self.betas[1], self.eps, pg["weight_decay"], self.step_count, self.grad_scale / used, skip, _stream())
         if self._scaler is not None:
             self._scaler_after_step()
 

@@ -78,6 +78,8 @@ def build_parser():
     p.add_argument("--eval_samples", default=128, type=int)
     p.add_argument("--num_workers", default=4, type=int)
     p.add_argument("--dp_overlap", action="store_true")
+    p.add_argument("--dp_grad_comm", default="f32", choices=["f32", "bf16"], help="dtype of the gradient buckets on the links")
+    p.add_argument("--dp_shard_optimizer", action="store_true", help="reduce-scatter + all-gather, AdamW on 1/world of the buffer")
     p.add_argument("--cleanup_output", action="store_true", help="reference behaviour: rmtree('./output') at the end")
     return p
 

@@ -88,8 +88,11 @@ class MSDTrainer:
         self.optimizer = FusedAdamW(self.store, lr=self.args.lr, fc_lr=5e-2, weight_decay=1e-2)
         if dtype == torch.float16:  # fp16 activation gradients need a scaled loss (AMP's GradScaler, here inside the optimiser)
             self.optimizer.enable_loss_scaling()
+        shard = bool(getattr(self.args, "dp_shard_optimizer", False))
         self.dp = DataParallel(self.store, self.optimizer, self.model,
-                               overlap=bool(getattr(self.args, "dp_overlap", False)))
+                               overlap=bool(getattr(self.args, "dp_overlap", False)) and not shard,
+                               grad_comm_dtype=torch.bfloat16 if getattr(self.args, "dp_grad_comm", "f32") == "bf16" else torch.float32,
+                               shard_optimizer=shard)
         self.dp.broadcast_parameters()
         if self.train_data is not None:
             self.scheduler = LinearWarmupSchedule(self.optimizer, self.args.warmup_ratio * self.train_num_steps,
@@ -141,6 +144,7 @@ class MSDTrainer:
                 self.optimizer.scale_loss(loss).backward()
                 self.dp.reduce_gradients()
                 self.optimizer.step()
+                self.dp.gather_parameters()  # (sharded optimiser only: publish this rank's slice of the updated weights)
                 self.scheduler.step()
                 self.optimizer.zero_grad()
                 if self.step > warm:

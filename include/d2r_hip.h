@@ -112,6 +112,14 @@ int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, int64_t ldb
 /* tuning switches for A/B measurements (tests/bench_gemm.py): LDS buffers (1|2), vectorised bf16 epilogue (0|1),
  * forced tile (-1 auto, 1: 64x64, 2: 128x64, 3: 128x128).  Defaults are the measured winners. */
 void d2r_gemm_tuning(int nbuf, int vepi, int tile);
+/* Measurement aid (bench.py's roofline leg; NOT part of the drop-in surface, not thread-safe against concurrent reads):
+ * while on, d2r_gemm and d2r_gemm_tn_grouped - including the calls made inside the whole-layer / whole-module entry points -
+ * bracket each launch with HIP events on the launching stream.  d2r_gemm_timer(1) clears and arms, d2r_gemm_timer(0)
+ * disarms; d2r_gemm_timer_read waits for the recorded events and returns per launch: family = dtype * 8 + layout * 2 +
+ * grouped, flops, algorithmic bytes (operands once, output once, twice when accumulated), milliseconds.  Returns the
+ * number of records copied (or, with family == NULL, the number pending, which it discards). */
+int d2r_gemm_timer(int on);
+int d2r_gemm_timer_read(int* family, double* flops, double* bytes, float* ms, int capacity);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels (fp32 statistics, wave-shuffle reductions)

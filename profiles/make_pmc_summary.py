@@ -17,22 +17,34 @@ from collections import defaultdict
 
 
 def family(name: str):
+    """Kernel name -> (family, counts as a launch).  rocprofv3 leaves names with a __bf16 / _Float16 template argument mangled
+    (_Z16gemm_glds_kernelIDF16bLi2ELi128E...) or demangles them wrongly ("<bool _Accum, int, E, 64, ...>" for <__bf16, 1, 64, ...>)."""
     if "splitk_reduce" in name:
         return "gemm_bf16_TN", False
-    m = re.search(r"gemm_kernelIDF16bLi(\d)E", name)
+    lay = ("NT", "NN", "TN")
+    m = re.search(r"gemm_glds_kernelIDF16[b_]Li(\d)ELi\d+ELi\dELi\dELb([01])E", name)  # <E, LAYOUT, BN, NWN, PIPE, WGRAD>
     if m:
-        return "gemm_bf16_" + ("NT", "NN", "TN")[int(m.group(1))], True
-    if "gemm_kernel<bool _Accum" in name:  # llvm-cxxfilt's rendering of gemm_kernel<__bf16, 1 (NN), ...>
+        return "gemm_bf16_" + lay[int(m.group(1))] + ("_grouped" if m.group(2) == "1" else ""), True
+    m = re.search(r"gemm_glds_kernel<[^,]*, (\d), \d+, \d, \d, (true|false)>", name)
+    if m:
+        return "gemm_bf16_" + lay[int(m.group(1))] + ("_grouped" if m.group(2) == "true" else ""), True
+    if "gemm_glds_kernel<bool _Accum, int, E," in name:  # the garbled rendering of <__bf16, 1 (NN), ...>
         return "gemm_bf16_NN", True
-    m = re.search(r"gemm_glds_kernel<(\d)", name)
+    m = re.search(r"gemm_glds_kernel<(\d)", name)  # (round-1 spelling without the element type)
     if m:
-        return "gemm_bf16_" + ("NT", "NN", "TN")[int(m.group(1))], True
+        return "gemm_bf16_" + lay[int(m.group(1))], True
+    m = re.search(r"gemm_kernelIDF16[b_]Li(\d)ELi\d+ELi\d+ELi\dELi\dELi\dELb([01])E", name)  # <T, LAYOUT, BM, BN, WM, WN, NBUF, GROUPED>
+    if m:
+        return "gemm_bf16_" + lay[int(m.group(1))] + ("_grouped" if m.group(2) == "1" else ""), True
+    if "gemm_kernel<bool _Accum" in name:
+        return "gemm_bf16_NN", True
     m = re.search(r"gemm_kernel<float, (\d)", name)
     if m:
-        return "gemm_f32_" + ("NT", "NN", "TN")[int(m.group(1))], True
-    for key, fam in (("mha_fwd", "mha_core_fwd"), ("mha_bwd", "mha_core_bwd"), ("adamw", "d2r_adamw_step"),
+        return "gemm_f32_" + lay[int(m.group(1))], True
+    for key, fam in (("mha_long", "mha_core_long"), ("mha_fwd", "mha_core_fwd"), ("mha_bwd", "mha_core_bwd"), ("adamw", "d2r_adamw_step"),
+                     ("xattn2_fwd", "xattn_core_fwd"), ("xattn_bwd", "xattn_core_bwd"), ("xattn_fwd", "xattn_core_fwd"),
                      ("agg_fwd", "route_aggregate_fwd"), ("agg_bwd", "route_aggregate_bwd"), ("meanpool_fwd", "d2r_meanpool_fwd"),
-                     ("layernorm_bwd", "d2r_layernorm_bwd"), ("layernorm_fwd", "d2r_layernorm_fwd")):
+                     ("layernorm_bwd", "d2r_layernorm_bwd"), ("ln_sum_partials", "d2r_layernorm_bwd_sum"), ("layernorm_fwd", "d2r_layernorm_fwd")):
         if key in name:
             return fam, True
     return None, False

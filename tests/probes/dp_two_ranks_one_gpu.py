@@ -24,7 +24,8 @@ full = (ids, torch.ones(4, 16, dtype=torch.long), torch.zeros(4, 16, dtype=torch
         torch.randn(4, 3, 64, 64, generator=g))
 batch = tuple(t.to(dev) for t in shard_batch(full, rank, world))
 results = {}
-for overlap in (False, True):
+MODES = {False: {}, True: dict(overlap=True), "shard": dict(shard_optimizer=True), "bf16": dict(grad_comm_dtype=torch.bfloat16)}
+for overlap, kw in MODES.items():
     torch.manual_seed(100 + rank)  # different replicas on purpose: broadcast_parameters must make them identical
     tc = TextConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     vc = VisionConfig(num_hidden_layers=2, image_size=64, patch_size=32)
@@ -33,9 +34,10 @@ for overlap in (False, True):
     store = ParamStore(model, torch.bfloat16)
     opt = FusedAdamW(store, lr=1e-3)
     sched = LinearWarmupSchedule(opt, 0, 12)
-    dp = DataParallel(store, opt, model, bucket_mb=32, overlap=overlap)
+    dp = DataParallel(store, opt, model, bucket_mb=32, **kw)
     assert dp.world == 2 and opt.grad_scale == 0.5
     dp.broadcast_parameters()
+    w_start = store.flat_w.detach().cpu().clone()  # (identical in every mode: same seeds, same broadcast)
     losses = []
     for _ in range(3):  # (overlap: the first step calibrates the per-parameter report counts)
         dp.begin_step()
@@ -43,6 +45,7 @@ for overlap in (False, True):
         loss.backward()
         dp.reduce_gradients()
         opt.step()
+        dp.gather_parameters()
         sched.step()
         opt.zero_grad()
         losses.append(float(loss))
@@ -50,7 +53,7 @@ for overlap in (False, True):
     results[overlap] = (losses, store.flat_w.detach().cpu().clone())
     entries = [(n, o, k) for n, _, o, k, _ in store.entries]
     bounds = dp.reducer.bounds
-    if overlap:
+    if overlap is True:
         multi = sum(1 for v in dp._expect.values() if v > 1)
         print(f"rank {rank}: {len(dp._expect)} reporting parameters, {multi} of them in more than one piece", flush=True)
         if rank == 0 and os.environ.get("D2R_PROBE_VERBOSE"):
@@ -69,7 +72,10 @@ ne = results[False][1] != results[True][1]
 csum = torch.cat([torch.zeros(1, dtype=torch.int64), ne.to(torch.int64).cumsum(0)])  # differing elements before each offset
 count = lambda a, b: int(csum[b] - csum[a])
 bad = [(n, count(o, o + k)) for n, o, k in entries if count(o, o + k)]
-torch.save({"losses": results[True][0], "losses_plain": results[False][0], "same_modes": same_modes, "same_ranks": same_ranks,
+upd = lambda key: (results[key][1] - w_start).double()
+cos_bf16 = float((upd("bf16") @ upd(False)) / (upd("bf16").norm() * upd(False).norm()))
+torch.save({"same_shard": bool(torch.equal(results[False][1], results["shard"][1])), "cos_bf16": cos_bf16, "losses_bf16": results["bf16"][0],
+            "losses": results[True][0], "losses_plain": results[False][0], "same_modes": same_modes, "same_ranks": same_ranks,
             "n_diff": int(ne.sum()), "bad": bad[:40], "n_bad": len(bad), "bounds": bounds,
             "bad_buckets": [(i, count(a, b)) for i, (a, b) in enumerate(bounds) if count(a, b)],
             "max_abs_diff": float((results[False][1] - results[True][1]).abs().max()),

@@ -42,6 +42,8 @@ class _FakeStore:
 
 class _FakeOpt:
     grad_scale = 1.0
+    element_range = None
+    element_tail = None
 
 
 def _overlap_readiness(rank):
@@ -83,6 +85,46 @@ def _overlap_readiness(rank):
     step(extra_piece=True)
 
 
+def _bf16_buckets_and_sharded_optimizer(rank, world):
+    """(i) gradient buckets sent as bf16: the fp32 buffer receives the bf16-rounded sum; (ii) the sharded optimiser's control
+    flow: after the scatter a rank holds the summed gradients of its slice (and of the common tail), updates exactly those
+    elements, and the all-gather leaves every rank with the same, fully updated weights."""
+    from d2r_amd.dp import DataParallel, FlatGradReducer
+    from d2r_amd.params import FusedAdamW
+    flat = (torch.arange(1003, dtype=torch.float32) / 7.0) * (rank + 1)
+    want = (torch.arange(1003, dtype=torch.float32) / 7.0).bfloat16().float() + (torch.arange(1003, dtype=torch.float32) / 7.0 * 2).bfloat16().float()
+    red = FlatGradReducer(flat, bucket_elems=256, comm_dtype=torch.bfloat16)
+    red.reduce_all()
+    assert float((flat - want.bfloat16().float()).abs().max()) <= 2.0 ** -7 * float(want.abs().max()), "bf16 bucket sum"
+
+    class Store(_FakeStore):
+        def __init__(self):
+            super().__init__()
+            self.flat_g = torch.zeros(303)  # 303 = 2 x 148 + 7: slices of 148 elements and a tail of 7
+            self.flat_w = torch.arange(303, dtype=torch.float32).clone()
+
+        def refresh_lowp(self):
+            self.refreshed = True
+
+    store, opt = Store(), _FakeOpt()
+    dp = DataParallel(store, opt, None, shard_optimizer=True)
+    assert dp.shard == (148 * rank, 148 * (rank + 1)) and dp.shard_body == 296
+    assert opt.element_range == dp.shard and opt.element_tail == (296, 303) and opt.grad_scale == 0.5
+    store.flat_g += (rank + 1)
+    dp.reduce_gradients()
+    a, b = dp.shard
+    assert torch.equal(store.flat_g[a:b], torch.full((148,), 3.0)) and torch.equal(store.flat_g[296:], torch.full((7,), 3.0))
+    owned = FusedAdamW._owned(opt, (100, 300))  # a parameter group's range against this rank's slice and the tail
+    assert owned == ([(100, 148), (296, 300)] if rank == 0 else [(148, 296), (296, 300)]), owned
+    assert FusedAdamW._owned(opt, (0, 0)) == []
+    for x, y in FusedAdamW._owned(opt, (0, 303)):  # a stand-in optimiser: w -= grad_scale * g on the owned elements only
+        store.flat_w[x:y] -= opt.grad_scale * store.flat_g[x:y]
+    dp.gather_parameters()
+    assert store.refreshed and torch.equal(store.flat_w, torch.arange(303, dtype=torch.float32) - 1.5)
+    with pytest.raises(ValueError):
+        DataParallel(Store(), _FakeOpt(), None, shard_optimizer=True, overlap=True)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -111,6 +153,7 @@ def _worker(rank, world, port, q):
         with pytest.raises(ValueError):
             shard_batch((torch.zeros(3, 2),), rank, world)
         _overlap_readiness(rank)
+        _bf16_buckets_and_sharded_optimizer(rank, world)
     finally:
         dist.barrier()
         dist.destroy_process_group()
