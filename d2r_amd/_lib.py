@@ -44,7 +44,8 @@ class EncoderLayerDesc(C.Structure):
                                      "gln2_g", "gln2_b", "x", "y", "qkv", "ctx", "h1", "n1", "f_pre", "f", "h2", "lse",
                                      "mean1", "rstd1", "mean2", "rstd2", "dy", "dx", "scratch")]
                 + [("scratch_bytes", sz), ("splitk_ws", vp), ("splitk_bytes", sz), ("wgrad_stream", vp),
-                   ("defer_wgrad", i32), ("o_dy", vp * 4)])
+                   ("defer_wgrad", i32), ("o_dy", vp * 4), ("p_attn", f32), ("p_hidden", f32), ("seed_attn", C.c_uint64),
+                   ("seed_hidden", C.c_uint64 * 2)])
 
 
 RL_NAMES = ("R0", "R2", "IMRC_QKV", "IMRC_FC1", "IMRC_FC2", "GLAC_Q", "GLAC_KV", "GLAC_LOC", "GLAC_FC1", "GLAC_TPOOL", "GLAC_IPOOL",
@@ -82,9 +83,9 @@ SIGNATURES = {
     "d2r_softmax_bwd": (i32, [i32, i32, vp, vp, vp, i64, i64, i32, f32, vp]),
     "d2r_mha_supported": (i32, [i32, i32, i32, i32]),
     "d2r_mha_fwd": (i32, [i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,
-                          i32, i32, i32, i32, i32, f32, vp]),
+                          i32, i32, i32, i32, i32, f32, f32, C.c_uint64, vp]),
     "d2r_mha_bwd": (i32, [i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp,
-                          vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, vp]),
+                          vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, f32, C.c_uint64, vp]),
     "d2r_xattn_supported": (i32, [i32, i32, i32, i32]),
     "d2r_xattn_fwd": (i32, [i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,
                             i32, i32, i32, i32, f32, vp]),

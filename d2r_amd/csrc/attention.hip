@@ -64,17 +64,17 @@ typedef f16_t E;
 extern "C" int d2r_mha_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                            const void* v, int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob,
                            const void* residual, int64_t ldr, int64_t srb, const float* mask, float* lse, int B, int H,
-                           int Lq, int Lk, int head_dim, float scale, void* stream) {
+                           int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, void* stream) {
   return D2R_BY_DTYPE(dtype, mha_fwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, H, Lq,
-                                         Lk, head_dim, scale, stream));
+                                         Lk, head_dim, scale, p_drop, seed, stream));
 }
 extern "C" int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                            const void* v, int64_t ldv, int64_t svb, const void* dO, int64_t ldg, int64_t sgb,
                            const float* mask, const float* lse, float* dsum, void* dq, int64_t lddq, int64_t sdqb, void* dk,
                            int64_t lddk, int64_t sdkb, void* dv, int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk,
-                           int head_dim, float scale, void* stream) {
+                           int head_dim, float scale, float p_drop, uint64_t seed, void* stream) {
   return D2R_BY_DTYPE(dtype, mha_bwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, dO, ldg, sgb, mask, lse, dsum, dq, lddq, sdqb, dk, lddk,
-                                         sdkb, dv, lddv, sdvb, B, H, Lq, Lk, head_dim, scale, stream));
+                                         sdkb, dv, lddv, sdvb, B, H, Lq, Lk, head_dim, scale, p_drop, seed, stream));
 }
 extern "C" int d2r_xattn_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                              const void* v, int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob,

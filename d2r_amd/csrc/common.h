@@ -112,4 +112,15 @@ __device__ __forceinline__ float act_grad(int act, float r) {
   }
 }
 
+// ---- counter-based dropout mask (shared by d2r_dropout and the fused attention cores) ---------------------------------
+// 24-bit uniform from (seed, element index): splitmix64 finaliser.  keep(i) <=> d2r_rand24(seed, i) >= p * 2^24.
+__device__ __forceinline__ uint32_t d2r_rand24(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 40);
+}
+static inline uint32_t d2r_drop_threshold(float p) { return (uint32_t)((double)p * 16777216.0); }
+
 static inline int d2r_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

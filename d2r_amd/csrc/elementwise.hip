@@ -166,13 +166,6 @@ extern "C" int d2r_add(int dtype, const void* a, const void* b, void* out, int64
 // nn.Dropout of the BERT path (models/modeling_unimo.py:330,388,413,468): y = keep(i) ? x / (1 - p) : 0 (+ add).
 // keep(i) comes from a counter-based generator (splitmix64 finaliser of seed and element index), so the backward
 // pass regenerates the mask from (seed, index) instead of storing it: dx = d2r_dropout(dy) with the same seed.
-__device__ __forceinline__ uint32_t d2r_rand24(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 40);
-}
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ y,
                                                       int64_t n, uint32_t thresh, float scale, uint64_t seed, int vec_ok) {
@@ -203,7 +196,7 @@ extern "C" int d2r_dropout(int dtype, const void* x, const void* add, void* y, i
                            void* stream) {
   D2R_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f, "d2r_dropout: bad arguments (0 <= p < 1)");
   if (n == 0) return D2R_OK;
-  const uint32_t thresh = (uint32_t)((double)p * 16777216.0);  // drop when the 24-bit uniform is below p * 2^24
+  const uint32_t thresh = d2r_drop_threshold(p);  // drop when the 24-bit uniform is below p * 2^24
   const float scale = 1.f / (1.f - p);
   const int vec_ok = d2r_aligned16(x) && d2r_aligned16(y) && d2r_aligned16(add);
   const int64_t work = n / (dtype != D2R_F32 ? 8 : 4) + 1;

@@ -90,7 +90,7 @@ extern "C" size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F) {
   // every intermediate gradient has its own buffer (none is reused inside the layer): the weight-gradient GEMMs
   // that read them may still be running on the side stream when the main chain has moved on
   const size_t T = (size_t)B * L, es = 2;
-  return 5 * align256(T * E * es) + align256(T * F * es) + align256(T * 3 * E * es) + align256(d2r_layernorm_bwd_workspace((int64_t)T, E)) +
+  return 7 * align256(T * E * es) + align256(T * F * es) + align256(T * 3 * E * es) + align256(d2r_layernorm_bwd_workspace((int64_t)T, E)) +
          align256(T * (size_t)(E / 32) * sizeof(float));  // + D scratch of the long-sequence attention backward (<= E/32 heads)
 }
 
@@ -100,6 +100,7 @@ static int check_desc(const d2r_encoder_layer_desc* L, const char* fn) {
   D2R_REQUIRE(L->B >= 1 && L->L >= 1 && L->E >= 8 && L->H >= 1 && L->F >= 8 && L->E % L->H == 0, "%s: bad shape", fn);
   D2R_REQUIRE(d2r_mha_supported(L->dtype, L->L, L->L, L->E / L->H), "%s: attention shape unsupported by the fused core", fn);
   D2R_REQUIRE(L->act == D2R_ACT_GELU || L->act == D2R_ACT_QUICK_GELU, "%s: activation must be gelu or quick_gelu", fn);
+  D2R_REQUIRE(L->p_attn >= 0.f && L->p_attn < 1.f && L->p_hidden >= 0.f && L->p_hidden < 1.f, "%s: dropout probabilities must be in [0, 1)", fn);
   D2R_REQUIRE(L->w_qkv && L->w_o && L->w_1 && L->w_2 && L->b_qkv && L->b_o && L->b_1 && L->b_2 && L->ln1_g && L->ln1_b &&
                   L->ln2_g && L->ln2_b, "%s: null parameter", fn);
   D2R_REQUIRE(L->x && L->y && L->qkv && L->ctx && L->h1 && L->n1 && L->f_pre && L->f && L->h2 && L->lse && L->mean1 &&
@@ -119,16 +120,27 @@ extern "C" int d2r_encoder_layer_fwd(const d2r_encoder_layer_desc* L, void* stre
   }
   D2R_TRY(linear_fwd(L, T, 3 * E, E, attn_in, L->w_qkv, L->b_qkv, L->qkv, D2R_ACT_NONE, nullptr, nullptr, stream));
   D2R_TRY(d2r_mha_fwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, L->ctx, E,
-                      (int64_t)L->L * E, nullptr, 0, 0, L->mask, L->lse, L->B, L->H, L->L, L->L, dh, L->scale, stream));
-  D2R_TRY(linear_fwd(L, T, E, E, L->ctx, L->w_o, L->b_o, L->h1, D2R_ACT_NONE, L->x, nullptr, stream));
+                      (int64_t)L->L * E, nullptr, 0, 0, L->mask, L->lse, L->B, L->H, L->L, L->L, dh, L->scale, L->p_attn, L->seed_attn,
+                      stream));
+  // dense output in front of its residual add: out = dropout(dense(.)) + residual.  Without dropout the residual rides in the
+  // GEMM epilogue; with it the GEMM writes the dense output and one elementwise pass applies the mask and adds the residual
+  // in place (the mask is a function of the element index, so the pass needs no extra buffer).
+  const bool drop = L->p_hidden > 0.f;
+  const int64_t TE = (int64_t)T * E;
+  auto dense_res = [&](int N_, int K_, const void* in, const void* w, const float* b, void* out, const void* res, uint64_t seed) -> int {
+    if (!drop) return linear_fwd(L, T, N_, K_, in, w, b, out, D2R_ACT_NONE, res, nullptr, stream);
+    if (int rc = linear_fwd(L, T, N_, K_, in, w, b, out, D2R_ACT_NONE, nullptr, nullptr, stream)) return rc;
+    return d2r_dropout(L->dtype, out, res, out, TE, L->p_hidden, seed, stream);
+  };
+  D2R_TRY(dense_res(E, E, L->ctx, L->w_o, L->b_o, L->h1, L->x, L->seed_hidden[0]));
   if (L->pre_ln) {
     D2R_TRY(d2r_layernorm_fwd(L->dtype, L->h1, L->ln2_g, L->ln2_b, L->eps, T, E, L->h2, L->mean2, L->rstd2, stream));
     D2R_TRY(linear_fwd(L, T, F, E, L->h2, L->w_1, L->b_1, L->f, L->act, nullptr, L->f_pre, stream));
-    D2R_TRY(linear_fwd(L, T, E, F, L->f, L->w_2, L->b_2, L->y, D2R_ACT_NONE, L->h1, nullptr, stream));
+    D2R_TRY(dense_res(E, F, L->f, L->w_2, L->b_2, L->y, L->h1, L->seed_hidden[1]));
   } else {
     D2R_TRY(d2r_layernorm_fwd(L->dtype, L->h1, L->ln1_g, L->ln1_b, L->eps, T, E, L->n1, L->mean1, L->rstd1, stream));
     D2R_TRY(linear_fwd(L, T, F, E, L->n1, L->w_1, L->b_1, L->f, L->act, nullptr, L->f_pre, stream));
-    D2R_TRY(linear_fwd(L, T, E, F, L->f, L->w_2, L->b_2, L->h2, D2R_ACT_NONE, L->n1, nullptr, stream));
+    D2R_TRY(dense_res(E, F, L->f, L->w_2, L->b_2, L->h2, L->n1, L->seed_hidden[1]));
     D2R_TRY(d2r_layernorm_fwd(L->dtype, L->h2, L->ln2_g, L->ln2_b, L->eps, T, E, L->y, L->mean2, L->rstd2, stream));
   }
   return D2R_OK;
@@ -150,36 +162,51 @@ extern "C" int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* L, void* stream) {
   void* a2 = take((size_t)T * E);
   void* a3 = take((size_t)T * E);
   void* a4 = take((size_t)T * E);
+  void* a5 = take((size_t)T * E);  // with dropout: the masked copies of the two dense-output gradients
+  void* a6 = take((size_t)T * E);
   void* df = take((size_t)T * F);  // d f / d f_pre (in place)
   char* dqkv = (char*)take((size_t)T * 3 * E);
   void* lnws = p;
   const size_t lnws_bytes = d2r_layernorm_bwd_workspace(T, E);
   float* dsum = reinterpret_cast<float*>(p + align256(lnws_bytes));
   const char* qkv = (const char*)L->qkv;
+  // gradient entering a dense layer whose output was dropped: mask(g) / (1-p); the unmasked g still feeds the skip connection
+  const bool drop = L->p_hidden > 0.f;
+  auto masked = [&](const void* g, void* buf, uint64_t seed, const void** out) -> int {
+    *out = g;
+    if (!drop) return D2R_OK;
+    *out = buf;
+    return d2r_dropout(L->dtype, g, nullptr, buf, (int64_t)T * E, L->p_hidden, seed, stream);
+  };
+  const void *g_ffn = nullptr, *g_att = nullptr;
   if (!L->pre_ln) {
-    // y = LN2(h2), h2 = n1 + ffn(n1), n1 = LN1(h1), h1 = x + attn(x)
+    // y = LN2(h2), h2 = n1 + drop(ffn(n1)), n1 = LN1(h1), h1 = x + drop(attn(x))
     void *d_h2 = a0, *d_n1 = a1, *d_h1 = a2, *d_ctx = a3;
     (void)a4;
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, L->dy, L->h2, L->ln2_g, L->mean2, L->rstd2, T, E, d_h2, nullptr, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));
-    D2R_TRY(linear_bwd(L, 3, T, E, F, d_h2, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
+    D2R_TRY(masked(d_h2, a5, L->seed_hidden[1], &g_ffn));
+    D2R_TRY(linear_bwd(L, 3, T, E, F, g_ffn, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
     D2R_TRY(linear_bwd(L, 2, T, F, E, df, L->n1, L->w_1, d_n1, d_h2, L->gw_1, L->gb_1, stream));  // ffn path + skip
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, d_h1, nullptr, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));
-    D2R_TRY(linear_bwd(L, 1, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
+    D2R_TRY(masked(d_h1, a6, L->seed_hidden[0], &g_att));
+    D2R_TRY(linear_bwd(L, 1, T, E, E, g_att, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
     D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
                         L->mask, L->lse, dsum, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
-                        L->L, L->L, dh, L->scale, stream));
+                        L->L, L->L, dh, L->scale, L->p_attn, L->seed_attn, stream));
     D2R_TRY(linear_bwd(L, 0, T, 3 * E, E, dqkv, L->x, L->w_qkv, L->dx, d_h1, L->gw_qkv, L->gb_qkv, stream));  // + skip
   } else {
     // y = h1 + ffn(h2), h2 = LN2(h1), h1 = x + attn(n1), n1 = LN1(x)
     void *d_h2 = a0, *d_h1 = a1, *d_ctx = a2, *d_n1 = a3;
     (void)a4;
-    D2R_TRY(linear_bwd(L, 3, T, E, F, L->dy, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
+    D2R_TRY(masked(L->dy, a5, L->seed_hidden[1], &g_ffn));
+    D2R_TRY(linear_bwd(L, 3, T, E, F, g_ffn, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
     D2R_TRY(linear_bwd(L, 2, T, F, E, df, L->h2, L->w_1, d_h2, nullptr, L->gw_1, L->gb_1, stream));
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_h2, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, d_h1, L->dy, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // + skip
-    D2R_TRY(linear_bwd(L, 1, T, E, E, d_h1, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
+    D2R_TRY(masked(d_h1, a6, L->seed_hidden[0], &g_att));
+    D2R_TRY(linear_bwd(L, 1, T, E, E, g_att, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
     D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
                         L->mask, L->lse, dsum, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
-                        L->L, L->L, dh, L->scale, stream));
+                        L->L, L->L, dh, L->scale, L->p_attn, L->seed_attn, stream));
     D2R_TRY(linear_bwd(L, 0, T, 3 * E, E, dqkv, L->n1, L->w_qkv, d_n1, nullptr, L->gw_qkv, L->gb_qkv, stream));
     D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->x, L->ln1_g, L->mean1, L->rstd1, T, E, L->dx, d_h1, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // + skip
   }

@@ -292,7 +292,7 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     const char* qkv = (const char*)L.qkv;
     TRY(lin(c, T, 3 * E, E, x, E, lp[D2R_RL_IMRC_QKV], L.qkv));
     TRY(d2r_mha_fwd(c.dt, qkv, 3 * E, (int64_t)d.Lq * 3 * E, qkv + E * d.es, 3 * E, (int64_t)d.Lq * 3 * E, qkv + 2 * E * d.es, 3 * E,
-                    (int64_t)d.Lq * 3 * E, L.y, E, TEe, x, E, TEe, nullptr, L.lse_i, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), c.st));
+                    (int64_t)d.Lq * 3 * E, L.y, E, TEe, x, E, TEe, nullptr, L.lse_i, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
     TRY(lin(c, T, d.hidi, E, L.y, E, lp[D2R_RL_IMRC_FC1], L.f1, D2R_ACT_RELU));
     TRY(lin(c, T, E, d.hidi, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2], L.e2, D2R_ACT_NONE, L.y));
   }
@@ -522,7 +522,7 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(dxg(c, T, E, d.hidi, K.i_df1, d.hidi, lp[D2R_RL_IMRC_FC1].w, K.i_dy, E, 0.f, K.de[2]));  // + skip y -> e2
     defer(jobs, T, d.hidi, E, K.i_df1, d.hidi, L.y, E, lp[D2R_RL_IMRC_FC1]);
     TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, K.i_dsum, dqkv, E3, sb3,
-                    dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), c.st));
+                    dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
     TRY(dxg(c, T, E, 3 * E, dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
     TRY(dwg(c, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]));
   }

@@ -529,21 +529,23 @@ FUSED_XATTN = os.environ.get("D2R_FUSED_XATTN", "1") != "0"
 
 def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device, p_drop=0.0):
     """q, k, v: (data_ptr, row stride, batch stride) in elements of `dtype`; geo = (B, Lq, Lk, E).  Returns (o, P, seed).
-    p_drop > 0 (training-time attention-probability dropout, models/modeling_unimo.py:204,388) takes the three-launch
-    path: P is saved BEFORE dropout, the mask is regenerated from the seed."""
+    p_drop > 0 (training-time attention-probability dropout, models/modeling_unimo.py:204,388): the fused multi-head core
+    applies the mask in registers (same counter-based generator and element indexing as the three-launch path, where P is
+    saved BEFORE dropout); either way the backward regenerates the mask from the seed."""
     B, Lq, Lk, E = geo
     d = E // H
     Lkp = (Lk + 7) // 8 * 8
     dt = _dt_of(dtype)
     tag = "xattn_core_fwd" if H == 1 else "mha_core_fwd"
-    if p_drop <= 0.0 and FUSED_MHA and H > 1 and _lib.load().d2r_mha_supported(dt, Lq, Lk, d):
+    if FUSED_MHA and H > 1 and _lib.load().d2r_mha_supported(dt, Lq, Lk, d):
         # one launch, scores/probabilities stay in registers; the saved state is the row log-sum-exp, not P
         o = torch.empty(B, Lq, E, dtype=dtype, device=device)
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=device)
+        seed = _next_dropout_seed() if p_drop > 0.0 else 0
         _lib.call("d2r_mha_fwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], o.data_ptr(), E, Lq * E,
-                  _ptr(residual), E, Lq * E, _ptr(mask), lse.data_ptr(), B, H, Lq, Lk, d, scale, _stream(),
+                  _ptr(residual), E, Lq * E, _ptr(mask), lse.data_ptr(), B, H, Lq, Lk, d, scale, p_drop, seed, _stream(),
                   meta=dict(group=tag, algo_bytes=float(B * (2 * Lq + 2 * Lk) * E * 2)))
-        return o, lse, 0
+        return o, lse, seed
     if p_drop <= 0.0 and FUSED_XATTN and H == 1 and _lib.load().d2r_xattn_supported(dt, Lq, Lk, E):
         o = torch.empty(B, Lq, E, dtype=dtype, device=device)
         lse = torch.empty(B, 1, Lq, dtype=torch.float32, device=device)
@@ -595,7 +597,7 @@ def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None
         dsum = torch.empty_like(P) if (Lq > 256 or Lk > 256) else None  # long sequences: D handed from the dQ to the dK/dV kernel
         _lib.call("d2r_mha_bwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], g.data_ptr(), E, Lq * E,
                   _ptr(mask), P.data_ptr(), _ptr(dsum), dq[0], dq[1], dq[2], dk[0], dk[1], dk[2], dv[0], dv[1], dv[2], B, H, Lq, Lk,
-                  d, scale, _stream(), meta=dict(group=tag, algo_bytes=float(2 * B * (2 * Lq + 2 * Lk) * E * 2)))
+                  d, scale, p_drop, seed, _stream(), meta=dict(group=tag, algo_bytes=float(2 * B * (2 * Lq + 2 * Lk) * E * 2)))
         return
     Lkp = P.shape[-1]
     sP, sG = (H * Lq * Lkp, Lq * Lkp), (Lq * E, d)
@@ -781,7 +783,7 @@ def _layer_scratch(nbytes: int, device) -> torch.Tensor:
 
 class _EncoderLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, bundle, mask):
+    def forward(ctx, x, anchor, bundle, mask, p_attn, p_hidden):
         x = x.contiguous()
         B, L, E = x.shape
         T, Fi, H = B * L, bundle.F, bundle.H
@@ -789,6 +791,14 @@ class _EncoderLayer(torch.autograd.Function):
         C.memmove(C.byref(d), C.byref(bundle.template), C.sizeof(d))
         d.B, d.L = B, L
         d.mask = _ptr(mask)
+        # training-time dropout: seeds drawn in the order the op-by-op path draws them (probabilities, attention output, FFN
+        # output), so that both paths see the same masks under the same torch.manual_seed
+        d.p_attn, d.p_hidden = p_attn, p_hidden
+        if p_attn > 0.0:
+            d.seed_attn = _next_dropout_seed()
+        if p_hidden > 0.0:
+            d.seed_hidden[0] = _next_dropout_seed()
+            d.seed_hidden[1] = _next_dropout_seed()
         acts = torch.empty(T * (7 * E + 2 * Fi), dtype=x.dtype, device=x.device)  # qkv ctx h1 n1 h2 | f_pre f
         stats = torch.empty(B * H * L + 4 * T, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
@@ -853,12 +863,13 @@ class _EncoderLayer(torch.autograd.Function):
             cb = getattr(p, "_d2r_ready_cb", None)
             if cb is not None:
                 cb(p)
-        return dx, None, None, None
+        return dx, None, None, None, None, None
 
 
-def encoder_layer(x, bundle: LayerBundle, mask=None):
-    """One whole BertLayer / CLIPEncoderLayer (bf16) as a single autograd node and a single C call each way."""
-    return _EncoderLayer.apply(x, bundle.params[0], bundle, mask)
+def encoder_layer(x, bundle: LayerBundle, mask=None, p_attn: float = 0.0, p_hidden: float = 0.0):
+    """One whole BertLayer / CLIPEncoderLayer (16-bit compute dtype) as a single autograd node and a single C call each way;
+    p_attn / p_hidden: training-time dropout on the attention probabilities / on the two dense outputs."""
+    return _EncoderLayer.apply(x, bundle.params[0], bundle, mask, float(p_attn), float(p_hidden))
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -602,13 +602,13 @@ class BertLayer(D2RModule):
 
     def forward(self, x, key_mask=None):
         sa = self.attention.self
-        # training-time dropout (models/modeling_unimo.py:388,413,468) runs op by op; without it the whole layer
-        # is one C call
+        # the whole layer is one C call, training-time dropout (models/modeling_unimo.py:388,413,468) included: the
+        # probabilities are masked inside the fused attention core, the two dense outputs by one in-place pass each
         p_att = sa.p_drop if self.training else 0.0
         p_hid = self.p_hidden if self.training else 0.0
-        bundle = _layer_bundle(self, x) if (p_att == 0.0 and p_hid == 0.0) else None
+        bundle = _layer_bundle(self, x)
         if bundle is not None:
-            return F.encoder_layer(x, bundle, key_mask)
+            return F.encoder_layer(x, bundle, key_mask, p_att, p_hid)
         H = sa.num_attention_heads
         scale = 1.0 / math.sqrt(x.shape[-1] // H)
         fz = sa._fused_linear()
@@ -668,9 +668,9 @@ class CLIPEncoderLayer(D2RModule):
     def forward(self, x):
         at = self.self_attn
         p_att = at.p_drop if self.training else 0.0  # attention_dropout (models/modeling_unimo.py:204), 0 by default
-        bundle = _layer_bundle(self, x) if p_att == 0.0 else None
+        bundle = _layer_bundle(self, x)
         if bundle is not None:
-            return F.encoder_layer(x, bundle)
+            return F.encoder_layer(x, bundle, None, p_att, 0.0)
         h = self.layer_norm1(x)
         d = x.shape[-1] // at.num_heads
         fz = at._fused_linear()

@@ -267,16 +267,21 @@ int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, const float* 
  * NULL.  lse: fp32 [B,H,Lq] row log-sum-exp written by fwd and read by bwd.  dsum (bwd): fp32 [B,H,Lq] scratch the
  * long-sequence backward hands from its dQ kernel to its dK/dV kernel; may be NULL when Lq, Lk <= 256.  Pointers 16-byte
  * aligned, strides multiples of 8 elements.  Deterministic.
+ * p_drop / seed: dropout on the probabilities (attention_probs_dropout_prob, models/modeling_unimo.py:388) inside the kernel:
+ * probability (b, h, q, key) is kept iff the counter-based generator of d2r_dropout, at element index
+ * ((b*H + h)*Lq + q)*lkp + key with lkp = Lk rounded up to 8, says so, and is then scaled by 1/(1-p); the backward
+ * regenerates the mask from the same (p_drop, seed).  p_drop = 0: no dropout.
  * ------------------------------------------------------------------------------------------------ */
 int d2r_mha_supported(int dtype, int Lq, int Lk, int head_dim);
 int d2r_mha_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                 const void* v, int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual,
                 int64_t ldr, int64_t srb, const float* mask, float* lse, int B, int H, int Lq, int Lk, int head_dim,
-                float scale, void* stream);
+                float scale, float p_drop, uint64_t seed, void* stream);
 int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                 const void* v, int64_t ldv, int64_t svb, const void* dO, int64_t ldg, int64_t sgb, const float* mask,
                 const float* lse, float* dsum, void* dq, int64_t lddq, int64_t sdqb, void* dk, int64_t lddk, int64_t sdkb,
-                void* dv, int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk, int head_dim, float scale, void* stream);
+                void* dv, int64_t lddv, int64_t sdvb, int B, int H, int Lq, int Lk, int head_dim, float scale, float p_drop,
+                uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K2 / K4 fused single-head attention over the full 768-wide feature (16-bit dtypes, D = 768, Lk <= 640)
@@ -299,7 +304,7 @@ int d2r_xattn_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void
                   int Lk, int D, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * K15 one transformer encoder layer per call (bf16): BertLayer.forward (models/modeling_unimo.py:473-512,
+ * K15 one transformer encoder layer per call (16-bit dtypes): BertLayer.forward (models/modeling_unimo.py:473-512,
  * post-LayerNorm, GELU) and CLIPEncoderLayer.forward (:222-268, pre-LayerNorm, quick_gelu), forward or backward.
  * Same kernels, same order as the single-op entry points; the 7 forward / ~16 backward launches are issued from
  * C++ in one call, skip-connection gradients ride in GEMM / LayerNorm epilogues, parameter gradients accumulate
@@ -309,7 +314,7 @@ int d2r_xattn_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void
  *   attn(a) = mha(a Wqkv^T + bqkv) Wo^T + bo ;  ffn(a) = act(a W1^T + b1) W2^T + b2
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
-  int dtype;                  /* D2R_BF16 */
+  int dtype;                  /* D2R_BF16 or D2R_F16 */
   int pre_ln;                 /* 0 post-LN (BERT), 1 pre-LN (CLIP ViT) */
   int act;                    /* D2R_ACT_GELU | D2R_ACT_QUICK_GELU */
   int B, L, E, H, F;          /* batch, tokens, hidden, heads, intermediate */
@@ -336,6 +341,13 @@ typedef struct {
   /* bwd, written by the call: the output gradients of the qkv / out / fc1 / fc2 linears ([T,3E] [T,E] [T,F] [T,E], inside
    * `scratch` or dy itself) — dW = o_dy^T x with x = x|n1, ctx, n1|h2, f. */
   const void* o_dy[4];
+  /* training-time dropout of the BERT layer (models/modeling_unimo.py:388 on the attention probabilities, :413 / :468 on
+   * the two dense outputs in front of their residual adds); 0 disables.  The masks are functions of (seed, element index)
+   * as in d2r_dropout: the probabilities use seed_attn inside the fused attention core, the dense outputs seed_hidden[0]
+   * (attention output) and seed_hidden[1] (FFN output) with the element index in the [B*L, E] tensor.  The backward
+   * call regenerates them from the same values. */
+  float p_attn, p_hidden;
+  uint64_t seed_attn, seed_hidden[2];
 } d2r_encoder_layer_desc;
 size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F);
 int d2r_encoder_layer_fwd(const d2r_encoder_layer_desc* d, void* stream);

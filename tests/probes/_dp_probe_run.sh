@@ -12,5 +12,5 @@ for r in (0,1):
     d = torch.load("/tmp/dpp$i/rank%d.pt" % r)
     print(r, {k: (v if k not in ("bounds",) else len(v)) for k, v in d.items()})
 PY
-  tail -2 $OUT/probe$i.log | cut -c1-600
+  tail -2 $OUT/probe$i.log | cut -c1-300; grep -o "first_grad_divergence.: .\{0,3000\}" $OUT/probe$i.log | head -1
 done

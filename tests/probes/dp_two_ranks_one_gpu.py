@@ -39,18 +39,22 @@ for overlap, kw in MODES.items():
     dp.broadcast_parameters()
     w_start = store.flat_w.detach().cpu().clone()  # (identical in every mode: same seeds, same broadcast)
     losses = []
+    gsnap = []  # reduced gradient buffer of every step (plain and overlapped mode only): localises a first divergence
     for _ in range(3):  # (overlap: the first step calibrates the per-parameter report counts)
         dp.begin_step()
         loss, _ = model(*batch)
         loss.backward()
         dp.reduce_gradients()
+        if overlap in (False, True) and os.environ.get("D2R_PROBE_GRADS", "1") != "0":
+            torch.cuda.synchronize()
+            gsnap.append(store.flat_g.detach().cpu().clone())
         opt.step()
         dp.gather_parameters()
         sched.step()
         opt.zero_grad()
         losses.append(float(loss))
     torch.cuda.synchronize()
-    results[overlap] = (losses, store.flat_w.detach().cpu().clone())
+    results[overlap] = (losses, store.flat_w.detach().cpu().clone(), gsnap)
     entries = [(n, o, k) for n, _, o, k, _ in store.entries]
     bounds = dp.reducer.bounds
     if overlap is True:
@@ -72,9 +76,19 @@ ne = results[False][1] != results[True][1]
 csum = torch.cat([torch.zeros(1, dtype=torch.int64), ne.to(torch.int64).cumsum(0)])  # differing elements before each offset
 count = lambda a, b: int(csum[b] - csum[a])
 bad = [(n, count(o, o + k)) for n, o, k in entries if count(o, o + k)]
+first = None
+for step_i, (ga, gb) in enumerate(zip(results[False][2], results[True][2])):
+    d = ga != gb
+    if bool(d.any()):
+        cs = torch.cat([torch.zeros(1, dtype=torch.int64), d.to(torch.int64).cumsum(0)])
+        cnt = lambda a, b: int(cs[b] - cs[a])
+        first = dict(step=step_i, n=int(d.sum()), max_abs=float((ga - gb).abs().max()),
+                     tensors=[(n, cnt(o, o + k), float((ga[o:o + k] - gb[o:o + k]).abs().max()), float(ga[o:o + k].abs().max()))
+                              for n, o, k in entries if cnt(o, o + k)][:60])
+        break
 upd = lambda key: (results[key][1] - w_start).double()
 cos_bf16 = float((upd("bf16") @ upd(False)) / (upd("bf16").norm() * upd(False).norm()))
-torch.save({"same_shard": bool(torch.equal(results[False][1], results["shard"][1])), "cos_bf16": cos_bf16, "losses_bf16": results["bf16"][0],
+torch.save({"first_grad_divergence": first, "same_shard": bool(torch.equal(results[False][1], results["shard"][1])), "cos_bf16": cos_bf16, "losses_bf16": results["bf16"][0],
             "losses": results[True][0], "losses_plain": results[False][0], "same_modes": same_modes, "same_ranks": same_ranks,
             "n_diff": int(ne.sum()), "bad": bad[:40], "n_bad": len(bad), "bounds": bounds,
             "bad_buckets": [(i, count(a, b)) for i, (a, b) in enumerate(bounds) if count(a, b)],

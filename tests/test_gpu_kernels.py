@@ -154,6 +154,43 @@ def test_attention(gpu, dtype, cfg):
     run_both(f, r, [q, k, v, res], dtype, gpu, wrt=[0, 1, 2] + ([3] if use_res else []), name=f"attention{cfg}")
 
 
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 128, 128, 12), (2, 197, 197, 12), (2, 50, 37, 16), (1, 300, 577, 12)], ids=lambda c: "x".join(map(str, c)))
+def test_fused_attention_dropout_matches_the_three_launch_path(gpu, lowp, cfg, monkeypatch):
+    """Attention-probability dropout (models/modeling_unimo.py:388) inside the fused multi-head core - short sequences and the
+    block loop above 256 tokens - against the unfused path (GEMM, softmax, d2r_dropout on the [B,H,Lq,Lkp] probabilities, GEMM)
+    with the SAME seed: one mask, so outputs and all three gradients agree to 16-bit rounding; and the mask has the
+    requested density."""
+    from d2r_amd import functional as F
+    B, Lq, Lk, H = cfg
+    E, p = 768, 0.1
+    scale = 1.0 / math.sqrt(E // H)
+    q, k, v = (rnd(B, L_, E, seed=i, scale=0.5).to(lowp).to(gpu) for i, L_ in enumerate((Lq, Lk, Lk)))
+    w = rnd(B, Lq, E, seed=9).to(gpu)
+    mask = torch.zeros(B, Lk, device=gpu)
+    mask[0, Lk - 5:] = -10000.0
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(F, "FUSED_MHA", fused)
+        monkeypatch.setattr(F, "_next_dropout_seed", lambda: 424242)
+        qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o = F.attention(qg, kg, vg, H, scale, mask=mask, p_drop=p)
+        assert (type(o.grad_fn).__name__ == "_AttentionBackward")
+        (o.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        out[fused] = (o.detach().float(), qg.grad.float(), kg.grad.float(), vg.grad.float())
+    tol_ = {torch.bfloat16: 2e-2, torch.float16: 3e-3}[lowp]
+    for name, a, b in zip(("o", "dq", "dk", "dv"), out[True], out[False]):
+        err, sc = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= tol_ * sc, f"{name}: fused vs three-launch with one seed differ by {err:.3e} (scale {sc:.3e})"
+    # density of the mask: with v = 1 the output row is the sum of the kept, rescaled probabilities -> mean 1
+    monkeypatch.setattr(F, "FUSED_MHA", True)
+    ones = torch.ones_like(v)
+    with torch.no_grad():
+        o1 = F.attention(q, k, ones, H, scale, p_drop=p).float()
+    assert abs(float(o1.mean()) - 1.0) < 2e-2 and float(o1.std()) > 1e-3, (float(o1.mean()), float(o1.std()))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cfg", [(2, 128, 12, True), (2, 197, 12, False), (2, 37, 16, False)])
 def test_attention_packed_qkv_and_kv(gpu, dtype, cfg):
@@ -405,17 +442,21 @@ def test_ops_refuse_cpu_tensors():
 
 
 @pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
-@pytest.mark.parametrize("kind", ["bert", "clip"])
-def test_encoder_layer_one_call_matches_op_by_op(gpu, kind, lowp):
+@pytest.mark.parametrize("kind", ["bert", "clip", "bert-dropout"])
+def test_encoder_layer_one_call_matches_op_by_op(gpu, kind, lowp, monkeypatch):
     """d2r_encoder_layer_fwd/bwd (one C call per layer and direction) against the op-by-op path built from the same
     kernels: the forward is bit-identical; the backward differs only where a skip-connection gradient is now added in
-    fp32 inside a GEMM / LayerNorm epilogue instead of by a separate bf16 add."""
+    fp32 inside a GEMM / LayerNorm epilogue instead of by a separate bf16 add.  "bert-dropout": train mode with the
+    bert-base dropout of 0.1 on the attention probabilities and on both dense outputs - the same seeds give the same masks
+    on both paths (the one-call path masks the probabilities inside the fused attention core)."""
+    from d2r_amd import functional as F
     from d2r_amd import modules as M
     from d2r_amd.config import TextConfig, VisionConfig
     from d2r_amd.params import ParamStore
     torch.manual_seed(3)
-    if kind == "bert":
-        layer = M.BertLayer(TextConfig(num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    if kind.startswith("bert"):
+        pd = 0.1 if kind == "bert-dropout" else 0.0
+        layer = M.BertLayer(TextConfig(num_hidden_layers=1, hidden_dropout_prob=pd, attention_probs_dropout_prob=pd))
         B, L = 3, 37
     else:
         layer = M.CLIPEncoderLayer(VisionConfig(num_hidden_layers=1, image_size=64, patch_size=32))
@@ -440,10 +481,12 @@ def test_encoder_layer_one_call_matches_op_by_op(gpu, kind, lowp):
     res = {}
     for composite in (False, True):
         M.COMPOSITE_LAYERS = composite
+        seeds = iter(range(7000, 7100))  # both paths draw: probabilities, attention output, FFN output
+        monkeypatch.setattr(F, "_next_dropout_seed", lambda: next(seeds))
         try:
             store.zero_grad()
             x = x0.clone().requires_grad_(True)
-            y = layer(x, mask) if kind == "bert" else layer(x)
+            y = layer(x, mask) if kind.startswith("bert") else layer(x)
             assert (type(y.grad_fn).__name__ == "_EncoderLayerBackward") == composite
             y.backward(gy)
             torch.cuda.synchronize()
@@ -452,6 +495,11 @@ def test_encoder_layer_one_call_matches_op_by_op(gpu, kind, lowp):
             M.COMPOSITE_LAYERS = True
     (y0, dx0, g0), (y1, dx1, g1) = res[False], res[True]
     assert torch.equal(y0, y1), "forward differs"
+    if kind == "bert-dropout":  # the masks really were applied: the eval-mode output differs
+        layer.eval()
+        with torch.no_grad():
+            assert not torch.equal(layer(x0, mask), y1)
+        layer.train()
     rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
     assert rel(dx1, dx0) < 1e-2, rel(dx1, dx0)
     for n, p, o, k, _ in store.entries:
