@@ -31,6 +31,10 @@ for overlap, kw in MODES.items():
     vc = VisionConfig(num_hidden_layers=2, image_size=64, patch_size=32)
     model = M.UnimoModelF(default_args(DR_step=3), vc, tc).to(dev)
     model.set_compute_dtype(torch.bfloat16).train()
+    # One compute stream: with the two branch streams an open, timing-dependent last-bits difference in the router gradients of the
+    # middle routing layer (tests/probes/determinism_probe.py, DESIGN.md "known issues") would make a bit-for-bit comparison of
+    # the communication modes flaky for reasons that have nothing to do with the collectives under test here.
+    model.model.use_streams = os.environ.get("D2R_PROBE_STREAMS", "0") == "1"
     store = ParamStore(model, torch.bfloat16)
     opt = FusedAdamW(store, lr=1e-3)
     sched = LinearWarmupSchedule(opt, 0, 12)
