@@ -483,7 +483,9 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     // the bias-gradient side product stay on the generic kernel
     // wide outputs (N >= 1536: FFN up-projection, fused q|k|v, FFN dX): the 128x128 tile on eight waves fetches a third
     // less from L2 per flop (NT 6304x3072x768: 561 vs 526, NN: 515 vs 452 TFLOP/s); narrow outputs keep the 128x64 tile
-    else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN) bn = a.N >= 1536 ? 129 : 64;
+    // (a deep reduction amortises the wider tile's longer prologue also for narrow outputs: NT 6304x768x3072 722 vs 671 TFLOP/s,
+    //  tests/probes/gemm_variants.py; not so in the NN direction, 616 vs 654)
+    else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN) bn = (a.N >= 1536 || (LAYOUT == D2R_GEMM_NT && a.K >= 2048 && a.N >= 128)) ? 129 : 64;
     if (a.dbias) bn = 0;
     if (bn) {
       GemmArgs b = a;
