@@ -110,7 +110,9 @@ int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, int64_t ldb
                         const void* const* h_B, float* const* h_C, float* const* h_dbias, int count, float beta,
                         void* stream);
 /* tuning switches for A/B measurements (tests/bench_gemm.py): LDS buffers (1|2), vectorised bf16 epilogue (0|1),
- * forced tile (-1 auto, 1: 64x64, 2: 128x64, 3: 128x128).  Defaults are the measured winners. */
+ * forced tile (-1 auto, 1: 64x64, 2: 128x64, 3: 128x128, 4..9 / 100..101: LDS-DMA variants).  Defaults are the measured
+ * winners.  Debug aid: the setting (like the D2R_GEMM_* environment switches read at load time) is PROCESS-GLOBAL and not
+ * thread-safe; the rest of the ABI carries no state between calls. */
 void d2r_gemm_tuning(int nbuf, int vepi, int tile);
 /* Measurement aid (bench.py's roofline leg; NOT part of the drop-in surface, not thread-safe against concurrent reads):
  * while on, d2r_gemm and d2r_gemm_tn_grouped - including the calls made inside the whole-layer / whole-module entry points -
