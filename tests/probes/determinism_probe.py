@@ -39,6 +39,59 @@ if os.environ.get('HOOKS'):
     F.matmul_nt = _mm
     M.F.matmul_nt = _mm
 cap_hist = []
+snaps = []  # per step: [(tag, device clone of the forward arena / input gradients as the module's backward finds them)]
+if os.environ.get("SNAP"):
+    _orig_bwd2 = F._Interaction.backward
+
+    def _bwd2(ctx, d_out, d_paths):
+        cur = snaps[-1]
+        tag = len(cur) // 3
+        cur.append((f"arena{tag}", ctx.keep.clone()))
+        cur.append((f"d_out{tag}", d_out.clone() if d_out is not None else None))
+        cur.append((f"d_paths{tag}", d_paths.clone() if d_paths is not None else None))
+        return _orig_bwd2(ctx, d_out, d_paths)
+
+    F._Interaction.backward = staticmethod(_bwd2)
+if os.environ.get("WAIT_ALL"):  # experiment: a module's backward first waits (on the GPU) for everything queued on the other compute streams
+    _orig_bwd3 = F._Interaction.backward
+
+    def _bwd3(ctx, d_out, d_paths):
+        cur = torch.cuda.current_stream()
+        which = os.environ.get("WAIT_WHICH", "all")
+        cands = list(F._COMPUTE_STREAMS) if which in ("all", "side") else []
+        cands += [torch.cuda.default_stream()] if which in ("all", "main") else []
+        for st in cands:
+            if st != cur:
+                cur.wait_stream(st)
+        res = _orig_bwd3(ctx, d_out, d_paths)
+        if os.environ.get("WAIT_ALL") == "2":  # ... and the others wait for it
+            for st in list(F._COMPUTE_STREAMS):
+                if st != cur:
+                    st.wait_stream(cur)
+        return res
+
+    F._Interaction.backward = staticmethod(_bwd3)
+held = []
+if os.environ.get("HOLD"):  # experiment: nothing the module's backward touched is returned to the allocator before the step ends
+    _orig_bwd4 = F._Interaction.backward
+    _orig_empty = torch.empty
+
+    def _bwd4(ctx, d_out, d_paths):
+        held.extend([d_out, d_paths, ctx.keep] + list(ctx.saved_tensors))
+        if os.environ.get("HOLD") == "2":  # ... including the scratch buffers allocated inside
+            def _empty(*a, **k):
+                t = _orig_empty(*a, **k)
+                held.append(t)
+                return t
+            torch.empty = _empty
+        try:
+            res = _orig_bwd4(ctx, d_out, d_paths)
+        finally:
+            torch.empty = _orig_empty
+        held.extend([r for r in res if r is not None])
+        return res
+
+    F._Interaction.backward = staticmethod(_bwd4)
 if os.environ.get("RECORD_ALL"):  # experiment: every tensor entering / leaving an interaction module's backward is marked as used on all streams
     _orig_bwd = F._Interaction.backward
 
@@ -60,6 +113,7 @@ for streams in (True,):
             for k, v in model.named_buffers():
                 v.copy_(bufs0[k])
         store.zero_grad()
+        snaps.append([])
         loss, _ = model(*batch)
         if os.environ.get("SYNC_FB"):
             torch.cuda.synchronize()
@@ -68,6 +122,13 @@ for streams in (True,):
         wgrad_join()
         torch.cuda.synchronize()
         grads.append(store.flat_g.detach().cpu().clone())
+        held.clear()
+        if os.environ.get("SNAP") and rep > 0:
+            for (tag, a0), (_, a1) in zip(snaps[0] if streams else snaps[0], snaps[-1]):
+                if a0 is not None and not torch.equal(a0, a1):
+                    nz = torch.nonzero((a0.view(torch.uint8) != a1.view(torch.uint8)).flatten())
+                    print(f"streams={streams} rep {rep}: SNAPSHOT {tag} differs in {nz.numel()} bytes of {a0.numel() * a0.element_size()}, first {int(nz[0])} last {int(nz[-1])}", flush=True)
+            snaps[-1] = None if rep > 0 else snaps[-1]
         cap_hist.append(dict(captured))
         captured.clear()
         if rep > 0:
