@@ -142,6 +142,7 @@ SIGNATURES = {
     "d2r_adamw_step": (i32, [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, f32, i64, f32, vp, vp]),
     "d2r_adamw_step_dev": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, f32, f32, f32, f32, vp, vp]),
     "d2r_grad_nonfinite": (i32, [vp, i64, vp, vp]),
+    "d2r_copy_rows": (i32, [vp, i64, vp, i64, i64, i64, vp]),
     "d2r_gemm_timer": (i32, [i32]),
     "d2r_gemm_timer_read": (i32, [vp, vp, vp, vp, i32]),
 }

@@ -269,6 +269,38 @@ extern "C" int d2r_cast(int src_dtype, const void* src, int dst_dtype, void* dst
   return d2r_check_launch("d2r_cast");
 }
 
+// ---- strided row copy: dst[r][0..width) = src[r][0..width) for r < rows (byte pitches) -------------------------------------
+// (hipMemcpy2DAsync device-to-device is issued by the runtime as one blit kernel PER ROW for these shapes: 148 launches of
+//  3 us per training step for the three gathers / scatters of a routing layer; this is one launch each.)
+__global__ __launch_bounds__(256) void copy_rows_kernel(unsigned char* __restrict__ dst, int64_t dpitch, const unsigned char* __restrict__ src,
+                                                        int64_t spitch, int64_t width, int64_t rows, int vec) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const int64_t per_row = width / 16, total = per_row * rows;
+    for (int64_t i = tid; i < total; i += nthreads) {
+      const int64_t r = i / per_row, c = i - r * per_row;
+      *reinterpret_cast<uint4*>(dst + r * dpitch + c * 16) = *reinterpret_cast<const uint4*>(src + r * spitch + c * 16);
+    }
+  } else {
+    const int64_t total = width * rows;
+    for (int64_t i = tid; i < total; i += nthreads) {
+      const int64_t r = i / width, c = i - r * width;
+      dst[r * dpitch + c] = src[r * spitch + c];
+    }
+  }
+}
+extern "C" int d2r_copy_rows(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width, int64_t rows, void* stream) {
+  D2R_REQUIRE(dst && src && width >= 0 && rows >= 0 && dst_pitch >= width && src_pitch >= width, "d2r_copy_rows: bad arguments");
+  if (width == 0 || rows == 0) return D2R_OK;
+  const int vec = d2r_aligned16(dst) && d2r_aligned16(src) && dst_pitch % 16 == 0 && src_pitch % 16 == 0 && width % 16 == 0;
+  const int64_t work = (vec ? width / 16 : width) * rows;
+  int blocks = (int)((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)dst, dst_pitch, (const unsigned char*)src,
+                     src_pitch, width, rows, vec);
+  return d2r_check_launch("d2r_copy_rows");
+}
+
 // ---- K14 AdamW over a flat fp32 range (modules/train.py:287-322; torch.optim.AdamW semantics) -----------
 template <typename H>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,

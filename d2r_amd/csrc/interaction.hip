@@ -209,9 +209,7 @@ int flush_jobs(const Ctx& c, Jobs& jobs) {
 }
 
 int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, void* st) {
-  hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)st);
-  if (e != hipSuccess) return d2r_fail(D2R_ERR_LAUNCH, "d2r_interaction: hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
-  return D2R_OK;
+  return d2r_copy_rows(dst, (int64_t)dpitch, src, (int64_t)spitch, (int64_t)width, (int64_t)height, st);
 }
 
 // single-head attention over the 768-wide feature: forward

@@ -350,7 +350,8 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
     if (nc > 5) ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
     for (int l = l0 + rg; l < l1; l += RG) {
       const int64_t off = ((int64_t)b * L + l) * D + pk * VEC;
-      float dv[6][VEC], x0[VEC], e[VEC], o[VEC];
+      // all ten 16-byte loads of the token row are issued before the first use (one memory latency per row, not four)
+      float dv[6][VEC], x0[VEC], ek[3][VEC], o[VEC];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         if (i < nc) {
@@ -360,8 +361,17 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
           for (int j = 0; j < VEC; ++j) dv[i][j] = 0.f;
         }
       }
-      // cell 0 (RIC): emb = relu(x0)
       ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, x0);
+#pragma unroll
+      for (int k = 2; k <= 4; ++k) {
+        if (k < nc) {
+          ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, ek[k - 2]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) ek[k - 2][j] = 0.f;
+        }
+      }
+      // cell 0 (RIC): emb = relu(x0)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float r = fmaxf(x0[j], 0.f);
@@ -378,13 +388,12 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
 #pragma unroll
       for (int k = 2; k <= 4; ++k) {
         if (k >= nc) break;
-        ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, e);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           float t = 0.f;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
-            dots[i * 6 + k] += dv[i][j] * e[j];
+            dots[i * 6 + k] += dv[i][j] * ek[k - 2][j];
             t += c[i][k] * dv[i][j];
           }
           o[j] = t;

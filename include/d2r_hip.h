@@ -456,6 +456,9 @@ int d2r_adamw_step(float* w, const float* g, float* m, float* v, void* w16 /*or 
 int d2r_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16 /*or NULL*/, int w16_dtype, int64_t n,
                        const float* d_hyper, float beta1, float beta2, float eps, float weight_decay,
                        const int* d_skip /*or NULL*/, void* stream);
+/* dst[r][0..width) = src[r][0..width) for r < rows; pitches and width in BYTES (16-byte vector path when everything is 16-byte
+ * aligned).  One launch - the runtime's device-to-device hipMemcpy2DAsync issues one blit kernel per row for these shapes. */
+int d2r_copy_rows(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width, int64_t rows, void* stream);
 /* *d_flag |= 1 when g[0..n) holds an inf or a NaN (d_flag is device memory the caller zeroes; one pass over g). */
 int d2r_grad_nonfinite(const float* g, int64_t n, int* d_flag, void* stream);
 

@@ -434,6 +434,22 @@ def test_adamw_matches_torch(gpu):
         assert int(skip) == 0
 
 
+def test_copy_rows(gpu):
+    """d2r_copy_rows: strided row gather / scatter in one launch (16-byte vector path and the byte path), checked against slicing."""
+    from d2r_amd import _lib
+    from d2r_amd.functional import _stream
+    src = torch.arange(40 * 4096, dtype=torch.int32, device=gpu).view(40, 4096).to(torch.uint8)  # values mod 256
+    for (rows, width, sp, dp, so, do) in ((32, 1536, 4096, 2048, 0, 0), (7, 1536 * 5, 1536 * 6, 1536 * 5, 1536, 0), (5, 37, 100, 64, 3, 1)):
+        s_ = src.flatten()[: rows * sp + so + 64].clone()
+        dst = torch.full((rows * dp + do + 64,), 255, dtype=torch.uint8, device=gpu)
+        _lib.call("d2r_copy_rows", dst.data_ptr() + do, dp, s_.data_ptr() + so, sp, width, rows, _stream())
+        torch.cuda.synchronize()
+        want = dst.clone().fill_(255)
+        for r in range(rows):
+            want[do + r * dp: do + r * dp + width] = s_[so + r * sp: so + r * sp + width]
+        assert torch.equal(dst, want), (rows, width, sp, dp, so, do)
+
+
 def test_ops_refuse_cpu_tensors():
     from d2r_amd import functional as F
     from d2r_amd import D2RError

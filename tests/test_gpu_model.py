@@ -314,26 +314,31 @@ def test_all_gradients_vs_live_oracle_fp64(gpu, case_name):
     print(f"[{case_name}] worst gradient rel-L2 vs fp64 oracle: {worst:.2e}")
 
 
-@pytest.mark.parametrize("shape", [(32, 128, 197, 3, "C2"), (8, 256, 577, 3, "C4"), (4, 512, 197, 8, "C5")], ids=lambda s: s[4])
+@pytest.mark.parametrize("shape", [(32, 128, 197, 3, 6, torch.bfloat16, "C2"), (8, 256, 577, 3, 6, torch.bfloat16, "C4"),
+                                   (16, 512, 197, 8, 4, torch.float16, "C5")], ids=lambda s: s[6])
 def test_forward_is_deterministic_and_shardable(gpu, shape):
-    """Size-independent properties at the BASELINE routing shapes — C2 (B=32, L=128, 197 image tokens), C4 (L=256, 577
-    tokens; batch reduced 64 -> 8) and C5 (L=512, DR_step 8; batch reduced 128 -> 4), both branches:
+    """Size-independent properties at the BASELINE routing shapes and at the batch ONE GPU holds — C2 (B=32, L=128, 197 image
+    tokens, bf16), C4 (L=256, 577 image tokens, bf16; 64 samples over 8 GPUs = 8 per GPU) and C5 (L=512, 8 routing layers, 4
+    cells per layer, fp16; 128 over 8 GPUs = 16 per GPU), both branches, on the fused attention cores and the whole-module calls:
     (1) two runs are bit-identical (fixed reduction order, no atomics in forward);
     (2) samples are independent in eval mode, so sharding the batch over ranks (data parallel) reproduces the
         full-batch result per sample."""
     from d2r_amd import modules as M
     from d2r_amd.config import default_args
-    B, L, Li, dr, _ = shape
+    B, L, Li, dr, ncell, lowp, _ = shape
     torch.manual_seed(0)
     for cls in (M.InteractionModule, M.Reversed_InteractionModule):
-        mod = cls(default_args(DR_step=dr), num_layer_routing=dr, num_cells=6, path_hid=128).to(gpu)
-        mod.set_compute_dtype(torch.bfloat16).eval()
+        mod = cls(default_args(DR_step=dr, num_cells=ncell), num_layer_routing=dr, num_cells=ncell, path_hid=128).to(gpu)
+        mod.set_compute_dtype(lowp).eval()
         with torch.no_grad():
             for n, p in mod.named_parameters():  # open about half of the paths
                 if n.endswith("router.mlp.2.bias"):
                     p.normal_()
-            text = torch.randn(B, L, 768, device=gpu).bfloat16()
-            image = torch.randn(B, Li, 768, device=gpu).bfloat16()
+        from d2r_amd.params import ParamStore
+        store = ParamStore(mod, lowp)  # flat buffers + 16-bit shadow: the module runs as ONE C call (d2r_interaction_fwd)
+        with torch.no_grad():
+            text = torch.randn(B, L, 768, device=gpu).to(lowp)
+            image = torch.randn(B, Li, 768, device=gpu).to(lowp)
             (e1,), s1 = mod(text, image)
             (e2,), s2 = mod(text, image)
             assert torch.equal(e1, e2) and torch.equal(s1, s2), "forward is not bit-reproducible"
@@ -343,7 +348,7 @@ def test_forward_is_deterministic_and_shardable(gpu, shape):
             assert torch.equal(torch.cat([ea, eb]), e1), "per-sample results depend on the batch composition"
             assert torch.isfinite(e1.float()).all()
             assert e1.shape == ((B, Li, 768) if cls is M.Reversed_InteractionModule else (B, L, 768))
-        del mod
+        del mod, store
 
 
 def test_closed_router_is_skip_connection(gpu):
