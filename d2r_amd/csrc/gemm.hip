@@ -467,8 +467,97 @@ static void launch_tile(const GemmArgs& a, int gz, hipStream_t st) {
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st);  // gemm_glds.hip
 static int g_glds = env_int("D2R_GEMM_GLDS", 1);
 
+// ---- skinny fp32 GEMM: M <= 32 rows (router MLPs, poolers, Block head: per-sample vectors, batch-size rows) ------------------
+// C[M,N] = act(alpha * A[M,K] op(B) + bias) (+ R) (+ beta * C), fp32 in and out, NT (B [N,K]) or NN (B [K,N]), batched.
+// These products are latency chains, not throughput problems (2.4 MB of weights, 38 MFLOP): the tiled kernel walks 48 k-tiles
+// of 16 with a barrier each and needs split-K slabs + a reduce launch to occupy the chip (22 + 6 us).  Here a workgroup owns
+// 16 output columns; its four waves split K, every wave issues ALL its loads before the first MFMA (one memory latency),
+// both 16-row tiles share the B fragments, and the four partial tiles are summed through LDS in a fixed order.
+// k-slot mapping of v_mfma_f32_16x16x4_f32: lane group g = lane / 16 feeds k-slot g; a lane loads 4 consecutive k (one float4 per
+// operand row) and uses element j in the j-th of four MFMAs, i.e. MFMA j covers k0 + {j, 4+j, 8+j, 12+j}: a permutation of
+// the 16 k of the step, the same for both operands.
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
+  constexpr int MAXS = 12;  // steps of 64 k per pass (4 waves x 16): K = 768 in one pass
+  __shared__ float red[4][2][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int z = blockIdx.z, zb = z / g.nh, zh = z - zb * g.nh;
+  const float* A = reinterpret_cast<const float*>(g.A) + zb * g.sAb + zh * g.sAh;
+  const float* B = reinterpret_cast<const float*>(g.B) + zb * g.sBb + zh * g.sBh;
+  const int n0 = blockIdx.x * 16;
+  const int col = min(n0 + fr, g.N - 1);               // clamped: the matching outputs are not stored
+  const int r0 = min(fr, g.M - 1), r1 = min(16 + fr, g.M - 1);
+  const bool two = g.M > 16;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int ksteps = g.K / 64;                         // per wave: K / 4 in steps of 16
+  for (int s0 = 0; s0 < ksteps; s0 += MAXS) {
+    const int ns = min(MAXS, ksteps - s0);
+    f32x4 a0[MAXS], a1[MAXS], b[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < ns) {
+        const int k = (wave * ksteps + s0 + s) * 16 + fq * 4;
+        a0[s] = *reinterpret_cast<const f32x4*>(A + (int64_t)r0 * g.lda + k);
+        if (two) a1[s] = *reinterpret_cast<const f32x4*>(A + (int64_t)r1 * g.lda + k);
+        if constexpr (LAYOUT == D2R_GEMM_NT) {
+          b[s] = *reinterpret_cast<const f32x4*>(B + (int64_t)col * g.ldb + k);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[s][j] = B[(int64_t)(k + j) * g.ldb + col];
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < ns) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s][j], b[s][j], acc0, 0, 0, 0);
+          if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s][j], b[s][j], acc1, 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[wave][0][fq * 4 + r][fr] = acc0[r];
+    red[wave][1][fq * 4 + r][fr] = acc1[r];
+  }
+  __syncthreads();
+  const int64_t cz = zb * g.sCb + zh * g.sCh, rz = zb * g.sRb + zh * g.sRh;
+  float* C = reinterpret_cast<float*>(g.C);
+  float* P = reinterpret_cast<float*>(g.P);
+  const float* R = reinterpret_cast<const float*>(g.R);
+  for (int e = tid; e < 512; e += 256) {
+    const int mt = e >> 8, row = (e >> 4) & 15, c = e & 15;
+    const int m = mt * 16 + row, n = n0 + c;
+    if (m >= g.M || n >= g.N) continue;
+    float v = (red[0][mt][row][c] + red[1][mt][row][c]) + (red[2][mt][row][c] + red[3][mt][row][c]);
+    v = g.alpha * v + (g.bias ? g.bias[zb * g.sBiasB + n] : 0.f);
+    const int64_t ci = cz + (int64_t)m * g.ldc + n;
+    if (P) P[ci] = v;
+    v = act_apply_cold(g.act, v);
+    if (R) v += R[rz + (int64_t)m * g.ldr + n];
+    if (g.beta != 0.f) v += g.beta * C[ci];
+    C[ci] = v;
+  }
+}
+
+static int g_skinny = env_int("D2R_GEMM_SKINNY", 1);
+template <int LAYOUT>
+static bool skinny_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
+  if (!g_skinny || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 64 != 0 || a.c_dtype != D2R_F32 || a.G || a.dbias || !a.vecA) return false;
+  if (LAYOUT == D2R_GEMM_NT && !a.vecB) return false;
+  hipLaunchKernelGGL((gemm_skinny_f32_kernel<LAYOUT>), dim3(d2r_cdiv(a.N, 16), 1, batch), dim3(256), 0, st, a);
+  return true;
+}
+
 template <typename T, int LAYOUT>
 static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t ws_bytes) {
+  if constexpr (sizeof(T) == 4 && LAYOUT != D2R_GEMM_TN) {
+    if (skinny_f32_try<LAYOUT>(a, batch, st)) return d2r_check_launch("d2r_gemm(skinny)");
+  }
   if constexpr (sizeof(T) == 2) {
     // large bf16 shapes: LDS-DMA pipelined 128xBN kernel (forced with tile 4 = 128x128, 5 = 128x64 for A/B runs)
     int bn = 0;

@@ -434,6 +434,38 @@ def test_adamw_matches_torch(gpu):
         assert int(skip) == 0
 
 
+@pytest.mark.parametrize("cfg", [("NT", 32, 768, 768, 1), ("NT", 2, 768, 768, 1), ("NT", 17, 100, 128, 6), ("NT", 32, 1600, 768, 1), ("NT", 1, 1, 768, 1),
+                                 ("NN", 32, 768, 768, 1), ("NN", 3, 768, 128, 6), ("NN", 32, 50, 1600, 1)], ids=lambda c: "-".join(map(str, c)))
+def test_skinny_fp32_gemm(gpu, cfg):
+    """The fp32 kernel for products with at most 32 rows (router MLPs, poolers, Block head; K a multiple of 64): plain, batched
+    with per-batch bias rows, with activation + saved pre-activation, residual and accumulation, against fp64."""
+    from d2r_amd import functional as F
+    from d2r_amd._lib import F32, GEMM_NN, GEMM_NT, ACT_TANH_RELU, ACT_NONE
+    lay, M, N, K, nb = cfg
+    layout = GEMM_NT if lay == "NT" else GEMM_NN
+    a = rnd(nb, M, K, seed=1).to(gpu)
+    b = (rnd(nb, N, K, seed=2, scale=0.1) if lay == "NT" else rnd(nb, K, N, seed=2, scale=0.1)).to(gpu)
+    bias = rnd(nb, N, seed=3).to(gpu)
+    res = rnd(nb, M, N, seed=4).to(gpu)
+    c0 = rnd(nb, M, N, seed=5).to(gpu)
+    prod = a.double() @ (b.double().transpose(1, 2) if lay == "NT" else b.double())
+    ldb = K if lay == "NT" else N
+    # plain
+    c = torch.empty(nb, M, N, device=gpu)
+    F.gemm(layout, M, N, K, a.data_ptr(), K, b.data_ptr(), ldb, c.data_ptr(), N, dtype=F32, c_dtype=F32, nb=nb, sA=(M * K, 0), sB=(N * K, 0),
+           sC=(M * N, 0))
+    assert float((c.double() - prod).abs().max()) <= 2e-5 * float(prod.abs().max()) + 1e-6
+    # bias (one row per batch) + relu(tanh) + saved pre-activation + residual + accumulate onto old C
+    c, pre = c0.clone(), torch.empty(nb, M, N, device=gpu)
+    F.gemm(layout, M, N, K, a.data_ptr(), K, b.data_ptr(), ldb, c.data_ptr(), N, dtype=F32, c_dtype=F32, nb=nb, sA=(M * K, 0), sB=(N * K, 0),
+           sC=(M * N, 0), alpha=0.5, beta=1.0, bias=bias.data_ptr(), s_bias=N, act=ACT_TANH_RELU, residual=res.data_ptr(), ldr=N, sR=(M * N, 0),
+           preact=pre.data_ptr())
+    want_pre = 0.5 * prod + bias.double()[:, None, :]
+    want = torch.relu(torch.tanh(want_pre)) + res.double() + c0.double()
+    assert float((pre.double() - want_pre).abs().max()) <= 2e-5 * float(want_pre.abs().max()) + 1e-6
+    assert float((c.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+
+
 def test_copy_rows(gpu):
     """d2r_copy_rows: strided row gather / scatter in one launch (16-byte vector path and the byte path), checked against slicing."""
     from d2r_amd import _lib
