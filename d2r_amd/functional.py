@@ -523,6 +523,7 @@ def matmul_nt(a, b):
 # ------------------------------------------------------------------------------------------------------
 # attention: O = softmax(scale * Q K^T + mask) V (+ residual), H heads; logits kept fp32
 # ------------------------------------------------------------------------------------------------------
+DETERMINISTIC = os.environ.get("D2R_DETERMINISTIC", "0") == "1"  # serialise the two routing modules' backward passes (bit-reproducible steps)
 FUSED_MHA = os.environ.get("D2R_FUSED_MHA", "1") != "0"  # 0: three-launch path (the only one for fp32)
 FUSED_XATTN = os.environ.get("D2R_FUSED_XATTN", "1") != "0"
 
@@ -950,6 +951,14 @@ class _Interaction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_paths):
         _ensure_backward_join()
+        if DETERMINISTIC:
+            # bit-reproducible steps with the two branch streams on: this module's backward first waits (on the GPU, no host
+            # synchronisation) for what is queued on the other compute streams - the two whole-module backward passes then
+            # no longer overlap (an open timing-dependent last-bits difference otherwise)
+            cur = torch.cuda.current_stream()
+            for st in _COMPUTE_STREAMS:
+                if st != cur:
+                    cur.wait_stream(st)
         own, other, out = ctx.saved_tensors
         d, bundle = ctx.d, ctx.bundle
         lib = _lib.load()

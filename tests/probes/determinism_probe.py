@@ -8,6 +8,8 @@ from d2r_amd.config import TextConfig, VisionConfig, default_args
 from d2r_amd.params import ParamStore
 
 dev = torch.device("cuda:0")
+from d2r_amd import functional as _F
+_F.DETERMINISTIC = os.environ.get("D2R_DETERMINISTIC", "0") == "1"
 M.COMPOSITE_ROUTING = os.environ.get("CR", "1") != "0"
 M.COMPOSITE_LAYERS = os.environ.get("CL", "1") != "0"
 N = int(os.environ.get("REPS", "8"))
@@ -105,6 +107,23 @@ if os.environ.get("RECORD_ALL"):  # experiment: every tensor entering / leaving 
         return res
 
     F._Interaction.backward = staticmethod(_bwd)
+if os.environ.get("REV_ON_T"):  # experiment: the image-branch module runs on the TEXT stream (both whole-module calls on one stream)
+    inner = model.model
+    _orig_rev = inner.Reversed_itr_module.forward
+
+    def _rev(*a, **k):
+        if inner._streams is None or not inner.use_streams:
+            return _orig_rev(*a, **k)
+        sT, sV = inner._streams
+        sT.wait_stream(sV)
+        with torch.cuda.stream(sT):
+            out = _orig_rev(*a, **k)
+        sV.wait_stream(sT)
+        for t in (out[0][0], out[1]):
+            t.record_stream(sV)
+        return out
+
+    inner.Reversed_itr_module.forward = _rev
 for streams in (True,):
     model.model.use_streams = streams
     grads = []
