@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=32, help="batch of the CPU baseline (BASELINE.md section 3: the benchmark batch)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the batch-2 measurement of the host's enqueue cost per step")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short fp32-path timing reported next to the headline")
     ap.add_argument("--overlap", action="store_true", help="(default at N > 1) overlap the bucketed grad all-reduce with backward")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce the whole gradient buffer after backward")
@@ -298,6 +299,34 @@ def main():
         "fwd_bwd_only": {"ms_per_step_per_rank": round(fb_ms, 3), "samples_per_s": round(world * args.batch / fb_ms * 1e3, 2),
                          "note": "no optimiser step, no gradient all-reduce; measured on rank 0's clock"},
     }
+
+    if rank == 0 and world == 1 and not args.graph and not args.no_host_leg:
+        # What the HOST needs to enqueue one step, separated from the GPU: the same model and step at batch 2 - the GPU drains its
+        # queue long before the host refills it, so the loop time is host time (launch calls, autograd, Python).  The
+        # host_enqueue figure above is taken at the benchmark batch, where the host mostly waits for room in the launch queue.
+        try:
+            small = synthetic_batch(2, args.seq, args.image_size, dev, seed=7)
+
+            def small_step():
+                loss, _ = model(*small)
+                opt.scale_loss(loss).backward()
+                opt.step()
+                opt.zero_grad()
+
+            for _ in range(3):
+                small_step()
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(10):
+                small_step()
+            h_ms = (time.perf_counter() - th) / 10 * 1e3
+            torch.cuda.synchronize()
+            out["host_only_ms_per_step"] = round(h_ms, 2)
+            out["host_only_note"] = "same model and step at batch 2: loop time without synchronisation = host time per step"
+            log(f"host-only leg: {h_ms:.2f} ms/step")
+        except Exception as e:
+            out["host_only_ms_per_step"] = None
+            out["host_only_note"] = repr(e)
 
     if rank == 0 and not args.no_roofline:
         # Per-kernel durations: the same step, but launched op by op on ONE stream (whole-layer C calls and the
