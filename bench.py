@@ -372,16 +372,48 @@ def main():
         cap = 1 << 15
         fam, fl, by, ms = (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), (C.c_float * cap)()
         n_rec = lib.d2r_gemm_timer_read(fam, fl, by, ms, cap)
+        # What one event bracket adds to a launch (the record commands are barriers in the queue: the next kernel cannot start
+        # under the tail of the previous one): the same tiny kernel timed as a train of 200 launches inside ONE bracket and as
+        # 200 individually bracketed launches; the difference per launch is subtracted from every bracketed duration below.
+        from d2r_amd import functional as F_
+        one = torch.zeros(8, device=dev)
+        tiny = lambda: _lib.call("d2r_axpby", 0, 1.0, one.data_ptr(), 1.0, one.data_ptr(), 8, F_._stream())
+        for _ in range(20):
+            tiny()
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        a0, a1 = ev(), ev()
+        a0.record()
+        for _ in range(200):
+            tiny()
+        a1.record()
+        pairs = []
+        for _ in range(200):
+            p0, p1 = ev(), ev()
+            p0.record()
+            tiny()
+            p1.record()
+            pairs.append((p0, p1))
+        torch.cuda.synchronize()
+        each = sorted(p0.elapsed_time(p1) for p0, p1 in pairs)[100]
+        bracket_ms = max(each - a0.elapsed_time(a1) / 200.0, 0.0)
+        out["event_bracket_overhead_us"] = round(bracket_ms * 1e3, 2)
+        for r in summ.values():  # the op-by-op pass (KernelTimer) used the same brackets
+            r["ms"] = max(r["ms"] - bracket_ms * r["calls"], 0.25 * r["ms"])
         summ = {k: v for k, v in summ.items() if not k.startswith("gemm_")}
         per_family = {}
+        VARIANT = {0: "tiles", 1: "ldsdma128x64", 2: "ldsdma128x128w4", 3: "ldsdma128x128w8", 11: "ldsdma128x64p", 12: "ldsdma128x128w4p",
+                   13: "ldsdma128x128w8p", 20: "ldsdma128x128", 21: "tiles64x64", 30: "skinny"}
         for i in range(n_rec):
-            name = "gemm_%s_%s%s" % (("f32", "bf16", "f16")[fam[i] // 8], ("NT", "NN", "TN")[(fam[i] % 8) // 2], "_grouped" if fam[i] & 1 else "")
+            var, base = fam[i] // 100, fam[i] % 100
+            # one row per KERNEL (template instance family), e.g. gemm_bf16_TN_grouped_ldsdma128x128 = gemm_glds_kernel<__bf16, TN, 128, 2, 1, true>
+            name = "gemm_%s_%s%s_%s" % (("f32", "bf16", "f16")[base // 8], ("NT", "NN", "TN")[(base % 8) // 2], "_grouped" if base & 1 else "",
+                                        VARIANT.get(var, str(var)))
             per_family.setdefault(name, []).append((ms[i], fl[i], by[i]))
         for name, recs in per_family.items():
             ts = sorted(t for t, _, _ in recs)
             med = ts[len(ts) // 2]
             clip = lambda t: med if (t > 8.0 * med and t > 0.2) else t  # a host hiccup between the two events is not kernel time
-            summ[name] = dict(calls=len(recs), ms=sum(clip(t) for t, _, _ in recs), flops=sum(f for _, f, _ in recs),
+            summ[name] = dict(calls=len(recs), ms=sum(max(clip(t) - bracket_ms, 0.25 * clip(t)) for t, _, _ in recs), flops=sum(f for _, f, _ in recs),
                               bytes=sum(b for _, _, b in recs), algo_bytes=0.0, outliers=sum(1 for t in ts if t > 8.0 * med and t > 0.2))
         kernels = []
         for name, r in summ.items():
@@ -417,7 +449,8 @@ def main():
                 pmc_file = cands[-1] if cands else None
                 if pmc_file:
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                        per_step = json.load(f).get(dom["kernel"], {}).get("hbm_bytes_per_step")
+                        pm = json.load(f)
+                    per_step = pm.get(dom["kernel"], {}).get("hbm_bytes_per_step")  # rows are per kernel, named as here
                     if per_step:
                         traffic = round(per_step / max(dom["launches_per_step"], 1))
             except OSError:

@@ -394,8 +394,10 @@ static int g_wgrad_glds = env_int("D2R_WGRAD_GLDS", 1);
 // a Python-side event bracket cannot see them.  When enabled, d2r_gemm and d2r_gemm_tn_grouped bracket each launch with a pair
 // of HIP events on the launching stream and remember (family, flops, algorithmic bytes); d2r_gemm_timer_read resolves them.
 // Measurement aid: off by default, one mutex acquisition per GEMM when off is avoided by the plain flag test.
+thread_local int d2r_gemm_variant_tl = 0;
+
 struct GemmTimerRec {
-  int family;  // dtype * 8 + layout * 2 + grouped
+  int family;  // dtype * 8 + layout * 2 + grouped + 100 * kernel variant (d2r_gemm_variant_tl)
   double flops, bytes;
   hipEvent_t e0, e1;
 };
@@ -408,6 +410,7 @@ struct GemmTimerScope {
   GemmTimerRec rec;
   hipStream_t st;
   GemmTimerScope(hipStream_t stream, int family, double flops, double bytes) : st(stream) {
+    d2r_gemm_variant_tl = 0;
     if (!g_timer_on) return;
     rec.family = family, rec.flops = flops, rec.bytes = bytes;
     if (hipEventCreate(&rec.e0) != hipSuccess) return;
@@ -417,6 +420,7 @@ struct GemmTimerScope {
   }
   ~GemmTimerScope() {
     if (!armed) return;
+    rec.family += 100 * d2r_gemm_variant_tl;
     (void)hipEventRecord(rec.e1, st);
     std::lock_guard<std::mutex> lk(g_timer_mu);
     g_timer_recs.push_back(rec);
@@ -550,6 +554,7 @@ static bool skinny_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
   if (!g_skinny || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 64 != 0 || a.c_dtype != D2R_F32 || a.G || a.dbias || !a.vecA) return false;
   if (LAYOUT == D2R_GEMM_NT && !a.vecB) return false;
   hipLaunchKernelGGL((gemm_skinny_f32_kernel<LAYOUT>), dim3(d2r_cdiv(a.N, 16), 1, batch), dim3(256), 0, st, a);
+  d2r_gemm_variant_tl = 30;
   return true;
 }
 
@@ -678,7 +683,7 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   a.sAb = d->sAb; a.sAh = d->sAh; a.sBb = d->sBb; a.sBh = d->sBh;
   a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh; a.sBiasB = d->s_bias_b;
   a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype; a.dtype = d->dtype;
-  a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd;
+  a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd; a.band = 0;
   static const int g_dbg = env_int("D2R_GEMM_DBG", 0);
   a.dbg = g_dbg;
   D2R_REQUIRE(!d->dbias || (d->layout == D2R_GEMM_TN && d->nb * d->nh == 1), "d2r_gemm: dbias needs the TN layout and batch 1");
@@ -745,6 +750,7 @@ static int launch_grouped_tn(const GemmArgs& base, const void* const* A, const v
     // (1.5x the operand bytes fetched vs 4.5x), wrong for 48 (6.3x): there the plain round-robin order, which gives an
     // XCD every eighth tile column, fetches 2.5x.
     if (grid.x >= 24 && grid.x % 8 == 0) a.xcd = 0;
+    d2r_gemm_variant_tl = 21;
     hipLaunchKernelGGL((gemm_kernel<T, D2R_GEMM_TN, 64, 64, 2, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
     if (int rc = d2r_check_launch("d2r_gemm_tn_grouped")) return rc;
   }
@@ -761,7 +767,7 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
   const int64_t es = (int64_t)d2r_esize(dtype);
   GemmArgs a = {};
   a.M = M, a.N = N, a.K = K, a.nh = 1, a.splits = 1, a.lda = lda, a.ldb = ldb, a.ldc = ldc;
-  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.dtype = dtype, a.xcd = g_xcd, a.grouped = 1, a.dbg = 0;
+  a.alpha = 1.f, a.beta = beta, a.act = D2R_ACT_NONE, a.c_dtype = D2R_F32, a.dtype = dtype, a.xcd = g_xcd, a.grouped = 1, a.dbg = 0, a.band = 0;
   a.vecA = (lda * es) % 16 == 0, a.vecB = (ldb * es) % 16 == 0, a.vecC = 0;
   for (int i = 0; i < count; ++i) {
     D2R_REQUIRE(h_A[i] && h_B[i] && h_C[i] && (!h_dbias || h_dbias[i]), "d2r_gemm_tn_grouped: null operand in problem %d", i);

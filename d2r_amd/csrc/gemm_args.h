@@ -44,6 +44,11 @@ template <> struct H16<float> {  // placeholder so that `typename H16<T>::v8` pa
 template <typename T> struct Out16 { typedef T type; };
 template <> struct Out16<float> { typedef bf16_t type; };
 
+// Which kernel the last d2r_gemm / d2r_gemm_tn_grouped of this thread launched (read by the optional launch timer of gemm.hip):
+// 0 register-staged generic kernel, 1 LDS-DMA 128x64, 2 LDS-DMA 128x128 on four waves, 3 LDS-DMA 128x128 on eight waves
+// (+10: software-pipelined K-loop), 20 grouped LDS-DMA weight-gradient kernel, 21 grouped generic 64x64, 30 skinny fp32.
+extern thread_local int d2r_gemm_variant_tl;
+
 // Grouped mode (weight-gradient GEMMs of identical shape deferred and launched together): operand pointers of problem
 // z = blockIdx.z, passed by value so that the launch needs no host-to-device copy and can be captured into a hipGraph.
 constexpr int D2R_GEMM_GROUP_MAX = 32;
@@ -72,6 +77,7 @@ struct GemmArgs {
   float alpha, beta;
   int act, c_dtype, vecA, vecB, vecC, xcd;
   int dtype;  // element type of A and B
+  int band;   // xcd_tile: column-band width in n-tiles (0: n fastest over the whole output)
   int dbg;  // timing experiments (D2R_GEMM_DBG): 1 = no MFMA, 2 = no DMA issue, 3 = no epilogue stores
 };
 
@@ -92,12 +98,26 @@ __device__ __forceinline__ Pack<T, VEC> load_guard(const T* rowp, int c0, int cl
 // each with a private L2.  Remap the linear id so that every XCD owns a CONTIGUOUS run of tiles (n fastest): the
 // N-tiles that share an A row-panel then hit the same L2 instead of re-fetching it over the fabric 8 times.
 // Bijective for any grid size.  Speed only; placement is not guaranteed and nothing depends on it for correctness.
-__device__ __forceinline__ void xcd_tile(int enable, int& tile_m, int& tile_n) {
-  const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+// `band` > 0 (wide outputs): inside an XCD's run the tiles are walked in column BANDS of `band` n-tiles, m fastest across
+// bands - the B panels of one band (band x BN x K elements) stay resident in the XCD's 4 MB L2 while the row panels stream past
+// once.  With n fastest over a whole 3072-wide output every row of tiles sweeps a 4.7 MB B matrix that does not fit, and the
+// matrix is re-fetched past L2 for every row panel on every XCD (measured: 4.1x the algorithmic bytes for the 128x128 dX kernel).
+__device__ __forceinline__ void xcd_tile(int enable, int& tile_m, int& tile_n, int band = 0) {
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
   int id = blockIdx.y * gx + blockIdx.x;
   if (enable && gridDim.z == 1 && nwg >= 16) {
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  if (band > 0 && band < gx) {
+    const int per_band = gy * band;
+    const int b = id / per_band;
+    const int first = b * band;                       // first n-tile of the band
+    const int w = min(band, gx - first);              // the last band may be narrower
+    const int rem = id - b * per_band;                // (for the last band: rem < gy * w, because the bands tile the grid exactly)
+    tile_m = rem / w;
+    tile_n = first + rem - tile_m * w;
+    return;
   }
   tile_m = id / gx;
   tile_n = id - tile_m * gx;

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
   const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
   int tile_m, tile_n, z = 0;
   if constexpr (WGRAD) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
-  else xcd_tile(g.xcd, tile_m, tile_n);
+  else xcd_tile(g.xcd, tile_m, tile_n, g.band);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const E* A = reinterpret_cast<const E*>(g.A);
   const E* B = reinterpret_cast<const E*>(g.B);
@@ -405,10 +405,24 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
   const bool a_strided = layout == D2R_GEMM_TN, b_strided = layout != D2R_GEMM_NT;
   if ((a_strided && a.M % 8 != 0) || (b_strided && a.N % 8 != 0)) return 0;
   const bool f16 = a.dtype == D2R_F16;
+  GemmArgs ab = a;
+  {
+    // column bands for wide outputs: the B panels of a band (band x BN x K x 2 bytes) should take about a third of the 4 MB L2
+    const int bnw = (bn % 1000) == 64 ? 64 : 128;
+    const int gx = d2r_cdiv(a.N, bnw);
+    const int64_t panel = (int64_t)bnw * a.K * 2;
+    int band = (int)((int64_t)(1536 << 10) / (panel > 0 ? panel : 1));
+    if (band < 2) band = 2;
+    static const int band_on = getenv("D2R_GEMM_BAND") ? atoi(getenv("D2R_GEMM_BAND")) : 1;
+    // (deep reductions, K = 3072: alone on the GPU the banded order is 2-6 % slower - every band re-streams the large A row panels -
+    //  but it moves 40 % fewer bytes past L2 and the two-stream step is faster with it: 23.9 vs 24.1 ms)
+    ab.band = (band_on && gx > band && gx * panel > (3 << 20)) ? band : 0;
+  }
+  d2r_gemm_variant_tl = ((bn % 1000) == 64 ? 1 : (bn % 1000) == 128 ? 2 : 3) + (bn >= 1000 ? 10 : 0);
   switch (layout) {
-    case D2R_GEMM_NT: f16 ? launch_glds<f16_t, D2R_GEMM_NT>(a, bn, st) : launch_glds<bf16_t, D2R_GEMM_NT>(a, bn, st); break;
-    case D2R_GEMM_NN: f16 ? launch_glds<f16_t, D2R_GEMM_NN>(a, bn, st) : launch_glds<bf16_t, D2R_GEMM_NN>(a, bn, st); break;
-    case D2R_GEMM_TN: f16 ? launch_glds<f16_t, D2R_GEMM_TN>(a, bn, st) : launch_glds<bf16_t, D2R_GEMM_TN>(a, bn, st); break;
+    case D2R_GEMM_NT: f16 ? launch_glds<f16_t, D2R_GEMM_NT>(ab, bn, st) : launch_glds<bf16_t, D2R_GEMM_NT>(ab, bn, st); break;
+    case D2R_GEMM_NN: f16 ? launch_glds<f16_t, D2R_GEMM_NN>(ab, bn, st) : launch_glds<bf16_t, D2R_GEMM_NN>(ab, bn, st); break;
+    case D2R_GEMM_TN: f16 ? launch_glds<f16_t, D2R_GEMM_TN>(ab, bn, st) : launch_glds<bf16_t, D2R_GEMM_TN>(ab, bn, st); break;
     default: return 0;
   }
   return 1;
@@ -421,6 +435,7 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
 int d2r_gemm_glds_wgrad_try(const GemmArgs& a, const GemmGroup& grp, int n, hipStream_t st) {
   if (!d2r_is16(a.dtype) || a.K < 128 || a.M < 128 || a.N < 128 || !a.vecA || !a.vecB || a.M % 8 != 0 || a.N % 8 != 0) return 0;
   dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), n);
+  d2r_gemm_variant_tl = 20;
   if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
   else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
   return 1;

@@ -118,7 +118,8 @@ void d2r_gemm_tuning(int nbuf, int vepi, int tile);
  * while on, d2r_gemm and d2r_gemm_tn_grouped - including the calls made inside the whole-layer / whole-module entry points -
  * bracket each launch with HIP events on the launching stream.  d2r_gemm_timer(1) clears and arms, d2r_gemm_timer(0)
  * disarms; d2r_gemm_timer_read waits for the recorded events and returns per launch: family = dtype * 8 + layout * 2 +
- * grouped, flops, algorithmic bytes (operands once, output once, twice when accumulated), milliseconds.  Returns the
+ * grouped + 100 * kernel variant (0 generic tiles, 1 LDS-DMA 128x64, 2 / 3 LDS-DMA 128x128 on four / eight waves, 20 grouped
+ * LDS-DMA weight gradients, 21 grouped generic, 30 skinny fp32), flops, algorithmic bytes (operands once, output once, twice when accumulated), milliseconds.  Returns the
  * number of records copied (or, with family == NULL, the number pending, which it discards). */
 int d2r_gemm_timer(int on);
 int d2r_gemm_timer_read(int* family, double* flops, double* bytes, float* ms, int capacity);

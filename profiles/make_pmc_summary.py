@@ -8,7 +8,7 @@ pass on gfx950) of `bench.py --steps 2 --warmup 1` into per-kernel-family HBM tr
 Units / corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE
 counts 64 B per 128-B request of a wide coalesced read, i.e. HALF the bytes -> doubled here; WRITE_SIZE is exact for
 16-B-per-lane stores.  A d2r_gemm launch of the TN (weight-gradient) family is the GEMM kernel plus, when split-K is
-used, its splitk_reduce_kernel: both are attributed to the family and divided by the number of GEMM kernels."""
+used, its splitk_reduce_kernel, listed as its own row (gemm_splitk_reduce)."""
 import csv
 import json
 import re
@@ -17,30 +17,44 @@ from collections import defaultdict
 
 
 def family(name: str):
-    """Kernel name -> (family, counts as a launch).  rocprofv3 leaves names with a __bf16 / _Float16 template argument mangled
-    (_Z16gemm_glds_kernelIDF16bLi2ELi128E...) or demangles them wrongly ("<bool _Accum, int, E, 64, ...>" for <__bf16, 1, 64, ...>)."""
-    if "splitk_reduce" in name:
-        return "gemm_bf16_TN", False
+    """Kernel name -> (row name, counts as a launch).  GEMM rows are per KERNEL, named as bench.py names them:
+    gemm_<dtype>_<layout>[_grouped]_<variant>, variant = ldsdma128x64 | ldsdma128x128w4 | ldsdma128x128w8 (+p: pipelined K-loop) |
+    ldsdma128x128 (grouped weight gradients) | tiles (register-staged generic kernel; tiles64x64 when grouped) | skinny.
+    rocprofv3 leaves names with a __bf16 / _Float16 template argument mangled (_Z16gemm_glds_kernelIDF16bLi2ELi128E...) or
+    demangles them wrongly ("<bool _Accum, int, E, 64, ...>" for <__bf16, 1 (NN), 64, ...>)."""
     lay = ("NT", "NN", "TN")
-    m = re.search(r"gemm_glds_kernelIDF16[b_]Li(\d)ELi\d+ELi\dELi\dELb([01])E", name)  # <E, LAYOUT, BN, NWN, PIPE, WGRAD>
+
+    def glds(layout, bn, nwn, pipe, wgrad):
+        if wgrad:
+            return "gemm_bf16_TN_grouped_ldsdma128x128"
+        v = "ldsdma128x64" if bn == 64 else ("ldsdma128x128w4" if nwn == 2 else "ldsdma128x128w8")
+        return "gemm_bf16_%s_%s%s" % (lay[layout], v, "p" if pipe else "")
+
+    if "splitk_reduce" in name:
+        return "gemm_splitk_reduce", True
+    m = re.search(r"gemm_glds_kernelIDF16[b_]Li(\d)ELi(\d+)ELi(\d)ELi(\d)ELb([01])E", name)  # <E, LAYOUT, BN, NWN, PIPE, WGRAD>
     if m:
-        return "gemm_bf16_" + lay[int(m.group(1))] + ("_grouped" if m.group(2) == "1" else ""), True
-    m = re.search(r"gemm_glds_kernel<[^,]*, (\d), \d+, \d, \d, (true|false)>", name)
+        return glds(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), m.group(5) == "1"), True
+    m = re.search(r"gemm_glds_kernel<[^,]*, (\d), (\d+), (\d), (\d), (true|false)>", name)
     if m:
-        return "gemm_bf16_" + lay[int(m.group(1))] + ("_grouped" if m.group(2) == "true" else ""), True
-    if "gemm_glds_kernel<bool _Accum, int, E," in name:  # the garbled rendering of <__bf16, 1 (NN), ...>
-        return "gemm_bf16_NN", True
-    m = re.search(r"gemm_glds_kernel<(\d)", name)  # (round-1 spelling without the element type)
+        return glds(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), m.group(5) == "true"), True
+    m = re.search(r"gemm_glds_kernel<bool _Accum, int, E, (\d+), (\d), (\d), (true|false)>", name)  # garbled <__bf16, 1 (NN), ...>
     if m:
-        return "gemm_bf16_" + lay[int(m.group(1))], True
+        return glds(1, int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4) == "true"), True
+    m = re.search(r"gemm_glds_kernel<(\d), (\d+)", name)  # (round-1 spelling without the element type)
+    if m:
+        return "gemm_bf16_%s_ldsdma128x%s" % (lay[int(m.group(1))], m.group(2)), True
     m = re.search(r"gemm_kernelIDF16[b_]Li(\d)ELi\d+ELi\d+ELi\dELi\dELi\dELb([01])E", name)  # <T, LAYOUT, BM, BN, WM, WN, NBUF, GROUPED>
     if m:
-        return "gemm_bf16_" + lay[int(m.group(1))] + ("_grouped" if m.group(2) == "1" else ""), True
+        return "gemm_bf16_" + lay[int(m.group(1))] + ("_grouped_tiles64x64" if m.group(2) == "1" else "_tiles"), True
     if "gemm_kernel<bool _Accum" in name:
-        return "gemm_bf16_NN", True
-    m = re.search(r"gemm_kernel<float, (\d)", name)
+        return "gemm_bf16_NN_tiles", True
+    m = re.search(r"gemm_kernel<float, (\d), \d+, \d+, \d, \d, \d, (true|false)>", name)
     if m:
-        return "gemm_f32_" + lay[int(m.group(1))], True
+        return "gemm_f32_" + lay[int(m.group(1))] + ("_grouped_tiles64x64" if m.group(2) == "true" else "_tiles"), True
+    m = re.search(r"gemm_skinny_f32_kernel(?:ILi|<)(\d)", name)
+    if m:
+        return "gemm_f32_%s_skinny" % lay[int(m.group(1))], True
     for key, fam in (("mha_long", "mha_core_long"), ("mha_fwd", "mha_core_fwd"), ("mha_bwd", "mha_core_bwd"), ("adamw", "d2r_adamw_step"),
                      ("xattn2_fwd", "xattn_core_fwd"), ("xattn_bwd", "xattn_core_bwd"), ("xattn_fwd", "xattn_core_fwd"),
                      ("agg_fwd", "route_aggregate_fwd"), ("agg_bwd", "route_aggregate_bwd"), ("meanpool_fwd", "d2r_meanpool_fwd"),
