@@ -710,7 +710,8 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double cs_ = (double)d2r_esize(d->c_dtype);
   GemmTimerScope timed(st, d->dtype * 8 + d->layout * 2, 2.0 * batch * d->M * d->N * (double)d->K,
-                       (double)batch * (((double)d->M * d->K + (double)d->N * d->K) * es + (double)d->M * d->N * cs_ * (d->beta != 0.f ? 2 : 1)));
+                       (double)batch * (((double)d->M * d->K + (double)d->N * d->K) * es +
+                                        (double)d->M * d->N * cs_ * (1 + (d->beta != 0.f) + (d->residual != nullptr) + (d->grad_ref != nullptr) + (d->preact != nullptr))));
   if (d->dtype == D2R_BF16) return launch_dtype<bf16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
   if (d->dtype == D2R_F16) return launch_dtype<f16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
   return launch_dtype<float>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);

@@ -414,9 +414,9 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
     int band = (int)((int64_t)(1536 << 10) / (panel > 0 ? panel : 1));
     if (band < 2) band = 2;
     static const int band_on = getenv("D2R_GEMM_BAND") ? atoi(getenv("D2R_GEMM_BAND")) : 1;
-    // (deep reductions, K = 3072: alone on the GPU the banded order is 2-6 % slower - every band re-streams the large A row panels -
-    //  but it moves 40 % fewer bytes past L2 and the two-stream step is faster with it: 23.9 vs 24.1 ms)
-    ab.band = (band_on && gx > band && gx * panel > (3 << 20)) ? band : 0;
+    // (not for deep reductions: at K = 3072 every band re-streams A row panels as large as the B band itself - measured 2-6 % slower
+    //  alone on the GPU and +2 GB per step past L2 for the 128x64 dX kernel)
+    ab.band = (band_on && a.K <= 1536 && gx > band && gx * panel > (3 << 20)) ? band : 0;
   }
   d2r_gemm_variant_tl = ((bn % 1000) == 64 ? 1 : (bn % 1000) == 128 ? 2 : 3) + (bn >= 1000 ? 10 : 0);
   switch (layout) {

@@ -285,7 +285,7 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cc, ldc, *, dtype, c_dtype, nb=1, nh=1
         z, es, cs = nb * nh, (4 if dtype == F32 else 2), (4 if c_dtype == F32 else 2)
         meta = dict(group=tag or f"gemm_{_DT_NAME[dtype]}_{('NT', 'NN', 'TN')[layout]}",
                     flops=2.0 * M * N * K * z,
-                    bytes=float(z) * ((M * K + N * K) * es + M * N * cs * (2 if (beta != 0.0 or residual) else 1)))
+                    bytes=float(z) * ((M * K + N * K) * es + M * N * cs * (1 + (beta != 0.0) + bool(residual) + bool(preact))))
     _lib.call("d2r_gemm", C.byref(d), _stream() if stream is None else stream, meta=meta)
 
 
