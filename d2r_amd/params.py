@@ -233,6 +233,12 @@ class FusedAdamW:
         st = self.store
         sc["flag"].zero_()
         _lib.call("d2r_grad_nonfinite", st.flat_g.data_ptr(), st.n, sc["flag"].data_ptr(), _stream())
+        if self.element_range is not None:
+            # sharded optimiser: a rank holds the REDUCED gradients of its own slice only - an overflow in another rank's slice
+            # must drop the step here too, or the replicas diverge
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(sc["flag"], op=dist.ReduceOp.MAX)
 
     def _scaler_after_step(self):
         sc = self._scaler
