@@ -21,6 +21,10 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
+# per-file additions to FLAGS
+EXTRA_FLAGS = {"routing.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -39,7 +43,7 @@ def _digest(path: str) -> str:
     for dep in deps:
         with open(dep, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(os.path.basename(path), [])).encode())
     return h.hexdigest()[:16]
 
 
@@ -50,7 +54,7 @@ def _compile_one(src: str, verbose: bool) -> str:
     for old in os.listdir(BUILD_DIR):
         if old.startswith(os.path.basename(src)[:-4] + ".") and old.endswith(".o"):
             os.remove(os.path.join(BUILD_DIR, old))
-    cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-I", INCLUDE, "-c", src, "-o", obj]
     if verbose:
         print("[d2r build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -136,11 +136,15 @@ __device__ __forceinline__ void st_f(T* p, const float (&o)[VEC]) {
   st_pack<T, VEC>(p, k);
 }
 
+__device__ __forceinline__ float uniform_f(float v) {  // block-uniform value kept in a scalar register
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* __restrict__ gates, int B, int L, int D,
                                                        int nc, MPtrs8 outs, float* __restrict__ probs, int64_t ldp) {
   constexpr int VEC = PackOf<T>::N;
-  __shared__ float c[6][6];
+  __shared__ float csh[6][6];
   const int b = blockIdx.y, tid = threadIdx.x;
   if (tid < 6) {
     const int i = tid;
@@ -154,29 +158,33 @@ __global__ __launch_bounds__(256) void agg_fwd6_kernel(Ptrs8 embs, const float* 
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const float ph = g[j] / (S + EPS_NORM);
-      c[i][j] = ph + (j == 0 ? skip : 0.f);
+      csh[i][j] = ph + (j == 0 ? skip : 0.f);
       if (blockIdx.x == 0 && i < nc && j < nc) probs[(int64_t)b * ldp + i * nc + j] = ph;
     }
   }
   __syncthreads();
+  float c[6][6];  // the sample's 36 coefficients, in scalar registers
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c[i][k] = uniform_f(csh[i][k]);
   const int npk = D / VEC;
   const int total = L * npk;
   for (int idx = blockIdx.x * 256 + tid; idx < total; idx += gridDim.x * 256) {
     const int l = idx / npk, pk = idx - l * npk;
     const int64_t off = ((int64_t)b * L + l) * D + pk * VEC, boff = (int64_t)b * D + pk * VEC;
     float e[6][VEC];
-    ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, e[0]);
+    // six loads issued together (absent cells of a declared subset: the host passes a stand-in pointer, the value is
+    // zeroed by a select; a branch around a load would put a full wait after each)
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + ((k == 1 || k == 5) ? boff : off), e[k]);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) e[0][j] = fmaxf(e[0][j], 0.f);
 #pragma unroll
-    for (int k = 1; k < 6; ++k) {  // (absent cells of a declared subset: zero coefficient, nothing read; block-uniform)
-      if (k < nc) {
-        ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + ((k == 1 || k == 5) ? boff : off), e[k]);
-      } else {
+    for (int k = 1; k < 6; ++k)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) e[k][j] = 0.f;
-      }
-    }
+      for (int j = 0; j < VEC; ++j) e[k][j] = k < nc ? e[k][j] : 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i >= nc) break;
@@ -279,6 +287,7 @@ extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, con
   dim3 grid(agg_chunks(L, D, VEC), B), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (P != 1) {
+    for (int k = ncell; k < 6; ++k) e.p[k] = (k == 1 || k == 5) ? e.p[1] : e.p[0];  // stand-ins for absent cells (read, then zeroed)
     if (dtype == D2R_BF16) hipLaunchKernelGGL((agg_fwd6_kernel<bf16_t>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs, ld_probs);
     else if (dtype == D2R_F16) hipLaunchKernelGGL((agg_fwd6_kernel<f16_t>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs, ld_probs);
     else hipLaunchKernelGGL((agg_fwd6_kernel<float>), grid, block, 0, st, e, gates, B, L, D, ncell, o, probs, ld_probs);
@@ -298,25 +307,32 @@ extern "C" int d2r_route_aggregate_fwd(int dtype, const void* const* h_embs, con
 #define AGG_LC 8  /* token rows per block */
 
 template <int N>
-__device__ __forceinline__ void block_reduce_store(float (&acc)[N], float* sh /*[4][N]*/, float* dst) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void block_reduce_store(float (&acc)[N], float* sh /*[waves][N]*/, float* dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const float t = wave_sum(acc[k]);
     if (lane == 0) sh[wave * N + k] = t;
   }
   __syncthreads();
-  if (threadIdx.x < N) dst[threadIdx.x] = sh[threadIdx.x] + sh[N + threadIdx.x] + sh[2 * N + threadIdx.x] + sh[3 * N + threadIdx.x];
+  if (threadIdx.x < N) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += sh[w * N + threadIdx.x];
+    dst[threadIdx.x] = t;
+  }
   __syncthreads();
 }
 
-template <typename T>
+// One block = AGG_LC token rows of one sample; blockDim = RG * (D / VEC) threads (RG row groups of D/VEC column packs).
+// VEC = 4 elements per thread (8-byte loads for the 16-bit types): the 36 dot accumulators, the six incoming gradients
+// and the four embeddings of a row then fit 128 registers (four waves per SIMD; the 8-wide version needed all 512 and
+// ran one), and the 36 path coefficients of the sample sit in scalar registers.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* __restrict__ gates, Ptrs8 douts, int B,
                                                        int L, int D, int nc, MPtrs8 dembs, float* __restrict__ ws_dots,
                                                        float* __restrict__ ws_bc) {
-  constexpr int VEC = PackOf<T>::N;
   extern __shared__ float dsh[];  // [RG][2][D] broadcast partials, then reused for the dot reduction
-  __shared__ float c[6][6];
+  __shared__ float csh[6][6];
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, tid = threadIdx.x;
   if (tid < 6) {
     const int i = tid;
@@ -329,12 +345,17 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
     const float skip = (i < nc && S < TH_GATE) ? 1.f : 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      c[i][j] = g[j] / (S + EPS_NORM) + (j == 0 ? skip : 0.f);  // (absent output i >= nc: all zero)
+      csh[i][j] = g[j] / (S + EPS_NORM) + (j == 0 ? skip : 0.f);  // (absent output i >= nc: all zero)
     }
   }
   __syncthreads();
+  float c[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c[i][k] = uniform_f(csh[i][k]);
   const int npk = D / VEC;
-  const int RG = 256 / npk;  // row groups per block (>= 1, checked on the host)
+  const int RG = blockDim.x / npk;  // row groups per block (>= 1, checked on the host)
   const int pk = tid % npk, rg = tid / npk;
   const bool active = rg < RG;
   float dots[36];
@@ -350,27 +371,24 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
     if (nc > 5) ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
     for (int l = l0 + rg; l < l1; l += RG) {
       const int64_t off = ((int64_t)b * L + l) * D + pk * VEC;
-      // all ten 16-byte loads of the token row are issued before the first use (one memory latency per row, not four)
+      // all ten loads of the token row are issued before the first use (one memory latency per row).  Holding the next
+      // row's packs in flight as well costs 30 registers (two waves per SIMD instead of three) and measured slower.
       float dv[6][VEC], x0[VEC], ek[3][VEC], o[VEC];
+      // (absent cells: the host passes a valid stand-in pointer, the values are zeroed by a select - a branch around a
+      // load would put a full wait after each of them)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        if (i < nc) {
-          ld_f<T, VEC>(reinterpret_cast<const T*>(douts.p[i]) + off, dv[i]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) dv[i][j] = 0.f;
-        }
-      }
+      for (int i = 0; i < 6; ++i) ld_f<T, VEC>(reinterpret_cast<const T*>(douts.p[i]) + off, dv[i]);
       ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, x0);
 #pragma unroll
-      for (int k = 2; k <= 4; ++k) {
-        if (k < nc) {
-          ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, ek[k - 2]);
-        } else {
+      for (int k = 2; k <= 4; ++k) ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, ek[k - 2]);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) ek[k - 2][j] = 0.f;
-        }
-      }
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dv[i][j] = i < nc ? dv[i][j] : 0.f;
+#pragma unroll
+      for (int k = 2; k <= 4; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ek[k - 2][j] = k < nc ? ek[k - 2][j] : 0.f;
       // cell 0 (RIC): emb = relu(x0)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -423,7 +441,7 @@ __global__ __launch_bounds__(256) void agg_bwd6_kernel(Ptrs8 embs, const float* 
   }
   __syncthreads();
   float* wb = ws_bc + ((int64_t)b * nchunk + chunk) * 2 * D;
-  for (int cidx = tid; cidx < 2 * D; cidx += 256) {
+  for (int cidx = tid; cidx < 2 * D; cidx += blockDim.x) {
     float t = 0.f;
     for (int r = 0; r < RG; ++r) t += dsh[r * 2 * D + cidx];
     wb[cidx] = t;
@@ -524,37 +542,45 @@ __global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
 #pragma unroll
   for (int j = 0; j < VEC; ++j) bs[j] = e1[j] = e5[j] = 0.f;
   const int l0 = chunk * AGG_LC, l1 = min(L, l0 + AGG_LC);
+  const float cg0 = uniform_f(cg[0]);
+  float cgk[3], csk[6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cgk[k] = uniform_f(cg[k + 2]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) csk[k] = uniform_f(cs[k]);
   if (active) {
     const int64_t boff = (int64_t)b * D + pk * VEC;
     ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[1]) + boff, e1);
     if (nc > 5) ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[5]) + boff, e5);
     for (int l = l0 + rg; l < l1; l += RG) {
       const int64_t off = ((int64_t)b * L + l) * D + pk * VEC;
-      float dv[VEC], e[VEC], o[VEC];
+      // the six loads of the token row are issued before the first store (absent cells: stand-in pointer, zeroed by a select)
+      float dv[VEC], eo[VEC], x0[VEC], ek[3][VEC], o[VEC];
       ld_f<T, VEC>(dout + off, dv);
-      ld_f<T, VEC>(out + off, e);
+      ld_f<T, VEC>(out + off, eo);
+      ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, x0);  // x0 = ref_0
+#pragma unroll
+      for (int k = 2; k <= 4; ++k) ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, ek[k - 2]);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        dots[6] += dv[j] * e[j];
+        dots[6] += dv[j] * eo[j];
         dots[1] += dv[j] * e1[j];
         dots[5] += dv[j] * e5[j];
         bs[j] += dv[j];
       }
-      ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[0]) + off, e);  // x0 = ref_0
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        dots[0] += dv[j] * fmaxf(e[j], 0.f);
-        o[j] = e[j] > 0.f ? cg[0] * dv[j] : 0.f;
+        dots[0] += dv[j] * fmaxf(x0[j], 0.f);
+        o[j] = x0[j] > 0.f ? cg0 * dv[j] : 0.f;
       }
       st_f<T, VEC>(reinterpret_cast<T*>(dembs.p[0]) + off, o);
 #pragma unroll
       for (int k = 2; k <= 4; ++k) {
         if (k >= nc) break;
-        ld_f<T, VEC>(reinterpret_cast<const T*>(embs.p[k]) + off, e);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          dots[k] += dv[j] * e[j];
-          o[j] = cg[k] * dv[j];
+          dots[k] += dv[j] * ek[k - 2][j];
+          o[j] = cgk[k - 2] * dv[j];
         }
         st_f<T, VEC>(reinterpret_cast<T*>(dembs.p[k]) + off, o);
       }
@@ -562,7 +588,7 @@ __global__ __launch_bounds__(256) void agg_bwd1_kernel(Ptrs8 embs, Ptrs8 refs, c
       for (int k = 0; k < 6; ++k) {
         if (k >= nc) break;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o[j] = cs[k] * dv[j];
+        for (int j = 0; j < VEC; ++j) o[j] = csk[k] * dv[j];
         st_f<T, VEC>(reinterpret_cast<T*>(drefs.p[k]) + off, o);
       }
     }
@@ -667,23 +693,30 @@ extern "C" int d2r_route_aggregate_bwd(int dtype, const void* const* h_embs, con
     dv.p[i] = h_douts[i];
     D2R_REQUIRE(dv.p[i] && d2r_aligned16(dv.p[i]), "d2r_route_aggregate_bwd: dout %d null or unaligned", i);
   }
+  // stand-ins for absent cells (read, then ignored by the kernels)
+  for (int i = P; i < 6 && P != 1; ++i) dv.p[i] = dv.p[0];
+  for (int k = ncell; k <= 4; ++k) e.p[k] = e.p[0];
   const int nchunk = (L + AGG_LC - 1) / AGG_LC;
   const int RG = 256 / (D / VEC);
+  constexpr int V6 = 4;  // elements per thread of the P = ncell kernel (see agg_bwd6_kernel)
+  const int npk6 = D / V6, RG6 = npk6 <= 256 ? 256 / npk6 : 0;
   float* ws_dots = (float*)workspace;
   float* ws_bc = ws_dots + (size_t)B * nchunk * (P != 1 ? 36 : 8);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nchunk, B), block(256);
   if (P != 1) {
-    size_t shmem = (size_t)RG * 2 * D * sizeof(float);
+    D2R_REQUIRE(D % V6 == 0 && RG6 >= 1, "d2r_route_aggregate_bwd: D=%d (multiple of 4, at most 1024)", D);
+    const dim3 block6((RG6 * npk6 + 63) / 64 * 64);
+    size_t shmem = (size_t)RG6 * 2 * D * sizeof(float);
     if (shmem < 4 * 36 * sizeof(float)) shmem = 4 * 36 * sizeof(float);
     if (dtype == D2R_BF16) {
-      hipLaunchKernelGGL((agg_bwd6_kernel<bf16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd6_kernel<bf16_t, V6>), grid, block6, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
       hipLaunchKernelGGL((agg_bwd6_finish_kernel<bf16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (bf16_t*)de.p[1], (bf16_t*)de.p[5], d_gates);
     } else if (dtype == D2R_F16) {
-      hipLaunchKernelGGL((agg_bwd6_kernel<f16_t>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd6_kernel<f16_t, V6>), grid, block6, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
       hipLaunchKernelGGL((agg_bwd6_finish_kernel<f16_t>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (f16_t*)de.p[1], (f16_t*)de.p[5], d_gates);
     } else {
-      hipLaunchKernelGGL((agg_bwd6_kernel<float>), grid, block, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
+      hipLaunchKernelGGL((agg_bwd6_kernel<float, V6>), grid, block6, shmem, st, e, gates, dv, B, L, D, ncell, de, ws_dots, ws_bc);
       hipLaunchKernelGGL((agg_bwd6_finish_kernel<float>), dim3(B, d2r_cdiv(2 * D, 256)), block, 0, st, gates, d_probs, ws_dots, ws_bc, B, D, nchunk, ncell, ld_dprobs, (float*)de.p[1], (float*)de.p[5], d_gates);
     }
   } else {
