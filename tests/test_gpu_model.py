@@ -351,6 +351,47 @@ def test_forward_is_deterministic_and_shardable(gpu, shape):
         del mod, store
 
 
+def test_training_step_is_bit_reproducible_with_the_two_branch_streams(gpu):
+    """One fwd+bwd from identical weights and inputs, repeated: every repetition leaves the same bits in the flat gradient
+    buffer, with the text / vision branches on their own HIP streams (the default).  No atomics anywhere, fixed-order
+    reductions; the round-2 regression this pins: one accumulator of route_aggregate_bwd went wrong in 16 lanes of one
+    wave in ~15 % of the steps while the other module's backward ran concurrently - 24
+    repetitions catch that rate with probability 0.98."""
+    from d2r_amd import modules as M
+    from d2r_amd import functional as F
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1000, 30000, (2, 16), generator=g)
+    ids[:, 0] = 101
+    batch = tuple(t.to(gpu) for t in (ids, torch.ones(2, 16, dtype=torch.long), torch.zeros(2, 16, dtype=torch.long),
+                                      torch.randint(0, 3, (2,), generator=g), torch.randn(2, 3, 64, 64, generator=g)))
+    torch.manual_seed(100)
+    tc = TextConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vc = VisionConfig(num_hidden_layers=2, image_size=64, patch_size=32)
+    model = M.UnimoModelF(default_args(DR_step=3), vc, tc).to(gpu)
+    model.set_compute_dtype(torch.bfloat16).train()
+    store = ParamStore(model, torch.bfloat16)
+    assert model.model.use_streams, "the two branch streams are the default"
+    buffers = {k: v.clone() for k, v in model.named_buffers()}
+    ref = None
+    for rep in range(24):
+        with torch.no_grad():
+            for k, v in model.named_buffers():  # BatchNorm running statistics back to their start
+                v.copy_(buffers[k])
+        store.zero_grad()
+        loss, _ = model(*batch)
+        loss.backward()
+        F.wgrad_join()
+        torch.cuda.synchronize()
+        cur = store.flat_g.detach().clone()
+        if ref is None:
+            ref = cur
+            assert torch.isfinite(ref).all() and float(ref.abs().sum()) > 0
+        else:
+            assert torch.equal(cur, ref), f"repetition {rep}: {int((cur != ref).sum())} gradient elements differ from repetition 0"
+
+
 def test_closed_router_is_skip_connection(gpu):
     """With every path closed the module degenerates to relu skip connections: out = relu(relu(relu(x)))=relu(x)
     through layers 0..n-1 and x_ref/(6) * 6 in the final layer (models/DynamicInteraction.py:104-117)."""
