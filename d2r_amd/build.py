@@ -39,7 +39,7 @@ def sources():
 def _digest(path: str) -> str:
     h = hashlib.sha256()
     deps = [path, os.path.join(INCLUDE, "d2r_hip.h")] + sorted(
-        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
     for dep in deps:
         with open(dep, "rb") as f:
             h.update(f.read())
