@@ -14,12 +14,14 @@ M.COMPOSITE_ROUTING = os.environ.get("CR", "1") != "0"
 M.COMPOSITE_LAYERS = os.environ.get("CL", "1") != "0"
 N = int(os.environ.get("REPS", "8"))
 g = torch.Generator().manual_seed(3)
-ids = torch.randint(1000, 30000, (2, 16), generator=g); ids[:, 0] = 101
-batch = tuple(t.to(dev) for t in (ids, torch.ones(2, 16, dtype=torch.long), torch.zeros(2, 16, dtype=torch.long), torch.randint(0, 3, (2,), generator=g),
-                                 torch.randn(2, 3, 64, 64, generator=g)))
+C2 = os.environ.get("SHAPE") == "C2"  # the benchmark shape (batch 32, 128 text tokens, 197 image tokens, 12 + 12 encoder layers)
+Bp, Lp, img, nl = (32, 128, 224, 12) if C2 else (2, 16, 64, 2)
+ids = torch.randint(1000, 30000, (Bp, Lp), generator=g); ids[:, 0] = 101
+batch = tuple(t.to(dev) for t in (ids, torch.ones(Bp, Lp, dtype=torch.long), torch.zeros(Bp, Lp, dtype=torch.long), torch.randint(0, 3, (Bp,), generator=g),
+                                 torch.randn(Bp, 3, img, img, generator=g)))
 torch.manual_seed(100)
-tc = TextConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-vc = VisionConfig(num_hidden_layers=2, image_size=64, patch_size=32)
+tc = TextConfig(num_hidden_layers=nl, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+vc = VisionConfig(num_hidden_layers=nl, image_size=img, patch_size=16 if C2 else 32)
 model = M.UnimoModelF(default_args(DR_step=3), vc, tc).to(dev)
 model.set_compute_dtype(torch.bfloat16).train()
 store = ParamStore(model, torch.bfloat16)
@@ -140,6 +142,13 @@ for streams in (True,):
         from d2r_amd.functional import wgrad_join
         wgrad_join()
         torch.cuda.synchronize()
+        if C2:  # 1.4 GB of gradients per repetition: compared on the device against repetition 0
+            if rep == 0:
+                ref_dev = store.flat_g.detach().clone()
+            else:
+                nd = int((store.flat_g != ref_dev).sum())
+                print(f"C2 shape rep {rep}: {'identical' if nd == 0 else str(nd) + ' gradient elements differ'}", flush=True)
+            continue
         grads.append(store.flat_g.detach().cpu().clone())
         held.clear()
         if os.environ.get("SNAP") and rep > 0:
@@ -163,8 +172,8 @@ for streams in (True,):
         else:
             print(f"streams={streams} rep {rep}: forward loss equal {cur[0] == fw0[0]}, emb_text {torch.equal(cur[1], fw0[1])}, emb_image "
                   f"{torch.equal(cur[2], fw0[2])}, sim {torch.equal(cur[3], fw0[3])}, rev_sim {torch.equal(cur[4], fw0[4])}", flush=True)
-    ref = grads[0]
-    for rep in range(1, N):
+    ref = grads[0] if grads else None
+    for rep in range(1, N if grads else 0):
         d = grads[rep] != ref
         if bool(d.any()):
             cs = torch.cat([torch.zeros(1, dtype=torch.int64), d.to(torch.int64).cumsum(0)])
