@@ -174,12 +174,18 @@ __global__ __launch_bounds__(256) void ln_sum_partials_kernel(const float* __res
   const int c = blockIdx.x * 16 + l, stride = 2 * D;
   float a0 = 0.f, a1 = 0.f;
   if (c < stride) {
-    int p = grp;
-    for (; p + 16 < nparts; p += 32) {
-      a0 += ws[(int64_t)p * stride + c];
-      a1 += ws[(int64_t)(p + 16) * stride + c];
+    // eight partial rows per trip, loaded before the first add (rows past the end read row `grp` again, times zero):
+    // the walk is a latency chain of L2 hits, not a bandwidth problem
+    for (int p = grp; p < nparts; p += 128) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = p + u * 16;
+        t[u] = ws[(int64_t)(q < nparts ? q : grp) * stride + c] * (q < nparts ? 1.f : 0.f);
+      }
+      a0 += (t[0] + t[2]) + (t[4] + t[6]);
+      a1 += (t[1] + t[3]) + (t[5] + t[7]);
     }
-    if (p < nparts) a0 += ws[(int64_t)p * stride + c];
   }
   sh[grp][l] = a0 + a1;
   __syncthreads();
@@ -206,18 +212,32 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   if (row >= rows) return;
   const int npk = D / VEC;
   const T* x = X + row * D;
-  float v[MAXP][VEC];
+  float v[MAXP][VEC], gm[MAXP][VEC], bt[MAXP][VEC];
   float s = 0.f;
+  // every load of the row (x, gamma, beta) is issued before the first reduction: lanes past the row read pack 0 and are
+  // masked by a select (a branch around a load costs a full memory wait per load; the parameter loads used to start after
+  // the two wave reductions)
+  Pack<T, VEC> px[MAXP];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
-    const int pk = lane + i * 64;
-    if (pk < npk) {
-      Pack<T, VEC> p = ld_pack<T, VEC>(x + pk * VEC);
+    const int pk = lane + i * 64, pc = pk < npk ? pk : 0;
+    px[i] = ld_pack<T, VEC>(x + pc * VEC);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        v[i][j] = to_f<T>(p.v[j]);
-        s += v[i][j];
-      }
+    for (int j = 0; j < VEC; j += 4) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + pc * VEC + j);
+      const float4 b4 = *reinterpret_cast<const float4*>(beta + pc * VEC + j);
+      gm[i][j] = g4.x, gm[i][j + 1] = g4.y, gm[i][j + 2] = g4.z, gm[i][j + 3] = g4.w;
+      bt[i][j] = b4.x, bt[i][j + 1] = b4.y, bt[i][j + 2] = b4.z, bt[i][j + 3] = b4.w;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // all loads of the row are issued before anything is converted
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const float mk = lane + i * 64 < npk ? 1.f : 0.f;  // (a multiply, not a select: a select lets the compiler sink the load under a branch)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      v[i][j] = to_f<T>(px[i].v[j]);
+      s += v[i][j] * mk;
     }
   }
   const float mu = wave_sum(s) / D;
@@ -245,10 +265,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     if (pk < npk) {
       Pack<T, VEC> o;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const int c = pk * VEC + j;
-        o.v[j] = from_f<T>((v[i][j] - mu) * rs * gamma[c] + beta[c]);
-      }
+      for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>((v[i][j] - mu) * rs * gm[i][j] + bt[i][j]);
       st_pack<T, VEC>(y + pk * VEC, o);
     }
   }
