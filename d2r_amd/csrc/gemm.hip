@@ -365,7 +365,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   }
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     float s = 0.f;
-    for (int k = 0; k < g.splits; ++k) s += g.ws[(int64_t)k * total + idx];
+    // eight slabs per trip, loaded before the first add (slabs past the last are slab 0 times zero; same order of additions):
+    // a load per trip with a wait behind it made the walk a chain of up to sixteen memory latencies
+    for (int k0 = 0; k0 < g.splits; k0 += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u;
+        t[u] = g.ws[(int64_t)(k < g.splits ? k : 0) * total + idx] * (k < g.splits ? 1.f : 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
     const int m = (int)(idx / g.N), n = (int)(idx - (int64_t)m * g.N);
     const int64_t ci = (int64_t)m * g.ldc + n;
     float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f);
