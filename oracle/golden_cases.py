@@ -40,6 +40,9 @@ class ModelCase:
     router_bias: str
     train: bool = True
     seed: int = 0
+    # compact fixture (full-size cases): the images are regenerated from the seed (their checksums are stored) and only
+    # token 0 of the two routed embeddings is stored, so that the committed file stays far below 1 MB
+    compact: bool = False
 
     def cfg(self) -> OracleConfig:
         return small_cfg(self.layers, self.image_size, self.patch, self.DR_step)
@@ -62,4 +65,8 @@ MODEL_CASES = [
     ModelCase("m_l2_eval", 2, 64, 32, 3, 8, 3, "normal", train=False),
     ModelCase("m_l2_dr4", 2, 96, 32, 2, 12, 4, "normal", seed=1),
     ModelCase("m_l12", 12, 96, 32, 2, 16, 3, "normal", seed=2),
+    # BASELINE.json configs[0] ("C1") at FULL size: MVSA-Single as the reference's own run.py builds it - batch 4, max_seq 64,
+    # 224x224 images at patch 32 (49 patches + CLS = 50 image tokens), 12+12 encoder layers, DR_step 3 (run.py:70), default
+    # router initialisation (every path open), ragged text lengths
+    ModelCase("m_c1", 12, 224, 32, 4, 64, 3, "init", seed=5, compact=True),
 ]

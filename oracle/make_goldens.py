@@ -243,11 +243,19 @@ def run_model_case(case: ModelCase):
     o64 = _run_oracle_model(case, cfg, sd, torch.float64, batch)
     o32 = _run_oracle_model(case, cfg, sd, torch.float32, batch)
     ids, mask, tt, labels, images = batch
-    out = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=images)
+    out = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels)
+    if case.compact:  # regenerated by tests from the seed (d2r_oracle.synthetic_batch), checked against these sums
+        out["images_sum"], out["images_abs_sum"] = images.double().sum(), images.double().abs().sum()
+        out["images_probe"] = images[:, :, ::37, ::41].clone()
+    else:
+        out["images"] = images
     for k in OUT_KEYS:
         _check(k + " (fp64)", o64[k], r64[k], 1e-10, 1e-10)
         _check(k + " (fp32 vs fp32 ref)", o32[k], r32[k], 3e-5, 3e-4)
-        out[k] = r64[k]
+        if case.compact and k.startswith("emb_"):  # token 0 (what the poolers read) in full + the whole tensor's norm
+            out[k + "_tok0"], out[k + "_norm"] = r64[k][:, 0].clone(), r64[k].double().norm()
+        else:
+            out[k] = r64[k]
         out["noise/" + k] = _md(r32[k], r64[k])
     print("    fp32 reference vs fp64 truth: " + ", ".join(f"{k} {out['noise/' + k]:.1e}" for k in OUT_KEYS))
     names, norms, noise = _grad_report(r64["grads"], r32["grads"], o64["grads"], o32["grads"], O.is_dead_param)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import golden_batch, load_golden
 from oracle import d2r_oracle as O
 from oracle.golden_cases import MODEL_CASES, ROUTING_CASES
 
@@ -56,7 +56,7 @@ def test_oracle_routing_module_matches_reference_fixture(case):
         assert _err(st.updates["M." + key[9:]].double(), _t(g[key])) <= 1e-10, key
 
 
-@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c.layers <= 2], ids=lambda c: c.name)
+@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c.layers <= 2 or c.compact], ids=lambda c: c.name)
 def test_oracle_full_model_matches_reference_fixture(case):
     g = load_golden(case.name)
     cfg = case.cfg()
@@ -65,14 +65,18 @@ def test_oracle_full_model_matches_reference_fixture(case):
     assert abs(float(sd["model.text_embeddings.word_embeddings.weight"].double().sum()) - float(g["wsum/word_emb"])) < 1e-6
     osd = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running_" not in k else
                (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
-    batch = [_t(g[k]) for k in ("input_ids", "attention_mask", "token_type_ids", "labels", "images")]
+    batch = golden_batch(case, g)
     loss, logits, aux = O.forward(osd, cfg, batch[0], batch[1], batch[2], batch[3], batch[4].double(), train=case.train)
     loss.backward()
     assert _err(loss, _t(g["loss"])) <= 1e-10
     assert _err(logits, _t(g["logits"])) <= 1e-10
     assert _err(aux["js_loss"], _t(g["js_loss"])) <= 1e-10
     for k in ("emb_text", "emb_image"):
-        assert _err(aux[k], _t(g[k])) <= 1e-6 * max(1.0, float(np.abs(g[k]).max())), k  # fp32-stored fixture
+        if case.compact:  # token 0 of every sample (what the poolers read) + the whole tensor's norm
+            assert _err(aux[k][:, 0], _t(g[k + "_tok0"])) <= 1e-6 * max(1.0, float(np.abs(g[k + "_tok0"]).max())), k
+            assert abs(float(aux[k].double().norm()) - float(g[k + "_norm"])) <= 1e-9 * float(g[k + "_norm"]), k
+        else:
+            assert _err(aux[k], _t(g[k])) <= 1e-6 * max(1.0, float(np.abs(g[k]).max())), k  # fp32-stored fixture
     for k in ("sim_paths", "rev_sim_paths"):
         assert _err(aux[k], _t(g[k])) <= 1e-9 * max(1.0, float(np.abs(g[k]).max())), k
     names, norms = [str(k) for k in g["grad_names"]], g["grad_norms"]
