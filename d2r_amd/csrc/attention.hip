@@ -45,9 +45,11 @@ extern "C" int d2r_mha_supported(int dtype, int Lq, int Lk, int head_dim) {
 extern "C" int d2r_xattn_supported(int dtype, int Lq, int Lk, int D) {
   return d2r_is16(dtype) && D == 768 && Lq >= 1 && Lk >= 1 && Lk <= 640;
 }
-int d2r_xattn2_fwd_try(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb, const void* v,
-                       int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual, int64_t ldr, int64_t srb,
-                       const float* mask, float* lse, int B, int Lq, int Lk, float scale, hipStream_t st);  // xattn2.hip
+int d2r_xattn2_fwd_try(int dtype, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
+                       const void* const* v, int64_t ldv, int64_t svb, void* const* o, int64_t ldo, int64_t sob, const void* const* residual,
+                       int64_t ldr, int64_t srb, const float* mask, float* const* lse, int B, int Lq, int Lk, float scale, hipStream_t st);  // xattn2.hip
+int d2r_gemm_tn_batched16(int dtype, int M, int m_store, int N, int K, int64_t lda, int64_t sAb, int64_t ldb, int64_t sBb, int64_t ldc,
+                          int64_t sCb, const void* const* A, const void* const* B, void* const* C, int ngroups, int nb, void* stream);  // gemm.hip
 
 // one copy of the kernels per 16-bit element type
 namespace att_bf16 {
@@ -76,17 +78,51 @@ extern "C" int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, c
   return D2R_BY_DTYPE(dtype, mha_bwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, dO, ldg, sgb, mask, lse, dsum, dq, lddq, sdqb, dk, lddk,
                                          sdkb, dv, lddv, sdvb, B, H, Lq, Lk, head_dim, scale, p_drop, seed, stream));
 }
+extern "C" int d2r_xattn_fwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
+                                   int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, void* const* h_o, int64_t ldo, int64_t sob,
+                                   const void* const* h_residual, int64_t ldr, int64_t srb, const float* mask, float* const* h_lse, int B,
+                                   int Lq, int Lk, int D, float scale, void* stream) {
+  return D2R_BY_DTYPE(dtype, xattn_fwd_run(dtype, ncore, h_q, ldq, sqb, h_k, ldk, skb, h_v, ldv, svb, h_o, ldo, sob, h_residual, ldr, srb, mask,
+                                           h_lse, B, Lq, Lk, D, scale, stream));
+}
 extern "C" int d2r_xattn_fwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                              const void* v, int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob,
                              const void* residual, int64_t ldr, int64_t srb, const float* mask, float* lse, int B, int Lq,
                              int Lk, int D, float scale, void* stream) {
-  return D2R_BY_DTYPE(dtype, xattn_fwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, Lq,
-                                           Lk, D, scale, stream));
+  return d2r_xattn_fwd_multi(dtype, 1, &q, ldq, sqb, &k, ldk, skb, &v, ldv, svb, &o, ldo, sob, residual ? &residual : nullptr, ldr, srb, mask,
+                             &lse, B, Lq, Lk, D, scale, stream);
 }
 extern "C" int d2r_xattn_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb,
                              const void* v, int64_t ldv, int64_t svb, const void* dO, int64_t ldg, int64_t sgb,
                              const float* mask, const float* lse, void* dq, int64_t lddq, int64_t sdqb, void* P, void* dS,
                              int lkp, int B, int Lq, int Lk, int D, float scale, void* stream) {
-  return D2R_BY_DTYPE(dtype, xattn_bwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, dO, ldg, sgb, mask, lse, dq, lddq, sdqb, P, dS,
+  return D2R_BY_DTYPE(dtype, xattn_bwd_run(dtype, 1, &q, ldq, sqb, &k, ldk, skb, &v, ldv, svb, &dO, ldg, sgb, mask, &lse, &dq, lddq, sdqb, &P, &dS,
                                            lkp, B, Lq, Lk, D, scale, stream));
+}
+extern "C" int d2r_xattn_bwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
+                                   int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, const void* const* h_dO, int64_t ldg,
+                                   int64_t sgb, const float* mask, const float* const* h_lse, void* const* h_dq, int64_t lddq, int64_t sdqb,
+                                   void* const* h_dk, int64_t lddk, int64_t sdkb, void* const* h_dv, int64_t lddv, int64_t sdvb,
+                                   void* const* h_P, void* const* h_dS, int lkp, int B, int Lq, int Lk, int D, float scale, void* stream) {
+  D2R_REQUIRE(h_dk && h_dv && ncore >= 1 && ncore <= 4, "d2r_xattn_bwd_multi: null pointer array / 1..4 problems per launch");
+  if (int rc = D2R_BY_DTYPE(dtype, xattn_bwd_run(dtype, ncore, h_q, ldq, sqb, h_k, ldk, skb, h_v, ldv, svb, h_dO, ldg, sgb, mask, h_lse, h_dq, lddq,
+                                                 sdqb, h_P, h_dS, lkp, B, Lq, Lk, D, scale, stream)))
+    return rc;
+  // key side: dV = P^T dO and dK = dS^T Q of every sample and problem in ONE grouped, batched launch.  The two outputs may have
+  // different strides (k | v packed in one projection output have the same): one launch per distinct stride pair.
+  const void* A[8];
+  const void* Bm[8];
+  void* C[8];
+  if (lddk == lddv && sdkb == sdvb && ldg == ldq && sgb == sqb) {
+    for (int c = 0; c < ncore; ++c) {
+      D2R_REQUIRE(h_dk[c] && h_dv[c], "d2r_xattn_bwd_multi: null dk / dv");
+      A[2 * c] = h_P[c], Bm[2 * c] = h_dO[c], C[2 * c] = h_dv[c];
+      A[2 * c + 1] = h_dS[c], Bm[2 * c + 1] = h_q[c], C[2 * c + 1] = h_dk[c];
+    }
+    return d2r_gemm_tn_batched16(dtype, lkp, Lk, D, Lq, lkp, (int64_t)Lq * lkp, ldq, sqb, lddk, sdkb, A, Bm, C, 2 * ncore, B, stream);
+  }
+  for (int c = 0; c < ncore; ++c) A[c] = h_P[c], Bm[c] = h_dO[c], C[c] = h_dv[c];
+  if (int rc = d2r_gemm_tn_batched16(dtype, lkp, Lk, D, Lq, lkp, (int64_t)Lq * lkp, ldg, sgb, lddv, sdvb, A, Bm, C, ncore, B, stream)) return rc;
+  for (int c = 0; c < ncore; ++c) A[c] = h_dS[c], Bm[c] = h_q[c], C[c] = h_dk[c];
+  return d2r_gemm_tn_batched16(dtype, lkp, Lk, D, Lq, lkp, (int64_t)Lq * lkp, ldq, sqb, lddk, sdkb, A, Bm, C, ncore, B, stream);
 }

@@ -800,3 +800,39 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
   if (dtype == D2R_F16) return launch_grouped_tn<f16_t>(a, h_A, h_B, h_C, h_dbias, count, st);
   return launch_grouped_tn<float>(a, h_A, h_B, h_C, h_dbias, count, st);
 }
+
+
+// ---- grouped + batched TN products with a 16-bit output (internal: attention.hip's cross-attention backward) -----------------
+// C_g[b] (16-bit [m_store, N], ldc, batch stride sCb) = A_g[b]^T B_g[b],  A_g[b] [K, M] (lda, sAb), B_g[b] [K, N] (ldb, sBb) for
+// g < ngroups, b < nb in ONE launch of the LDS-DMA kernel (mode 2).  M is the multiple of 8 the A rows are loaded up to
+// (the padded key count of P / dS), m_store <= M the rows written.  K arbitrary.  Falls back to one batched d2r_gemm per group.
+int d2r_gemm_glds_batched_tn_try(const GemmArgs& a, const GemmGroup& grp, int ngroups, hipStream_t st);  // gemm_glds.hip
+int d2r_gemm_tn_batched16(int dtype, int M, int m_store, int N, int K, int64_t lda, int64_t sAb, int64_t ldb, int64_t sBb, int64_t ldc,
+                          int64_t sCb, const void* const* A, const void* const* B, void* const* C, int ngroups, int nb, void* stream) {
+  D2R_REQUIRE(d2r_is16(dtype) && A && B && C && ngroups >= 1 && ngroups <= D2R_GEMM_GROUP_MAX && nb >= 1, "d2r_gemm_tn_batched16: bad arguments");
+  D2R_REQUIRE(m_store >= 1 && m_store <= M && N >= 1 && K >= 1 && lda >= M && ldb >= N && ldc >= N, "d2r_gemm_tn_batched16: bad shape");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GemmArgs a = {};
+  a.M = M, a.m_store = m_store, a.N = N, a.K = K, a.nh = 1, a.splits = 1, a.lda = lda, a.ldb = ldb, a.ldc = ldc, a.sAb = sAb, a.sBb = sBb, a.sCb = sCb;
+  a.alpha = 1.f, a.beta = 0.f, a.act = D2R_ACT_NONE, a.c_dtype = dtype, a.dtype = dtype, a.xcd = g_xcd, a.grouped = 1, a.gbatch = nb;
+  auto ok16 = [](const void* p, int64_t ld, int64_t sb) { return d2r_aligned16(p) && (ld * 2) % 16 == 0 && (sb * 2) % 16 == 0; };
+  a.vecA = a.vecB = a.vecC = 1;
+  GemmGroup grp = {};
+  for (int i = 0; i < ngroups; ++i) {
+    D2R_REQUIRE(A[i] && B[i] && C[i], "d2r_gemm_tn_batched16: null operand in group %d", i);
+    a.vecA &= ok16(A[i], lda, sAb) ? 1 : 0, a.vecB &= ok16(B[i], ldb, sBb) ? 1 : 0, a.vecC &= ok16(C[i], ldc, sCb) ? 1 : 0;
+    grp.A[i] = A[i], grp.B[i] = B[i], grp.C[i] = C[i];
+  }
+  {
+    GemmTimerScope timed(st, dtype * 8 + D2R_GEMM_TN * 2 + 1, 2.0 * ngroups * nb * (double)m_store * N * K,
+                         (double)ngroups * nb * (((double)K * m_store + (double)K * N) * 2.0 + (double)m_store * N * 2.0));
+    if (g_glds && d2r_gemm_glds_batched_tn_try(a, grp, ngroups, st)) return d2r_check_launch("d2r_gemm_tn_batched16(glds)");
+  }
+  for (int i = 0; i < ngroups; ++i) {  // not eligible (alignment): the generic batched kernel, one launch per group
+    d2r_gemm_desc d = {};
+    d.dtype = d.c_dtype = dtype, d.layout = D2R_GEMM_TN, d.act = D2R_ACT_NONE, d.M = m_store, d.N = N, d.K = K, d.nb = nb, d.nh = 1, d.alpha = 1.f;
+    d.A = A[i], d.lda = lda, d.sAb = sAb, d.B = B[i], d.ldb = ldb, d.sBb = sBb, d.C = C[i], d.ldc = ldc, d.sCb = sCb;
+    if (int rc = d2r_gemm(&d, stream)) return rc;
+  }
+  return D2R_OK;
+}

@@ -78,6 +78,8 @@ struct GemmArgs {
   int act, c_dtype, vecA, vecB, vecC, xcd;
   int dtype;  // element type of A and B
   int band;   // xcd_tile: column-band width in n-tiles (0: n fastest over the whole output)
+  int gbatch;   // batched grouped mode of the LDS-DMA kernel: problems per group (blockIdx.z = group * gbatch + batch index)
+  int m_store;  // same mode: rows stored (<= M; M itself is the multiple of 8 the operand loads are clamped to)
   int dbg;  // timing experiments (D2R_GEMM_DBG): 1 = no MFMA, 2 = no DMA issue, 3 = no epilogue stores
 };
 

@@ -18,11 +18,17 @@
 // NWN waves along N (2: four waves, 4: eight waves per workgroup); a wave owns 64 rows x BN/NWN columns.
 // PIPE = 1: software-pipelined K-step (all fragment reads of the step issued up front behind counted lgkmcnt waits, the
 // closing barrier in the MIDDLE of the MFMA block, the DMA of tile t+2 issued right behind it: two tiles in flight).
-// WGRAD (TN only): grouped weight-gradient mode — blockIdx.z selects one of up to 16 same-shape problems (operand pointers in
+// MODE 1 (TN only): grouped weight-gradient mode — blockIdx.z selects one of up to 32 same-shape problems (operand pointers in
 // `grp`), the output is fp32 and ACCUMULATED (C += A^T B, 16-byte loads / stores), and the workgroups of the first tile column
 // also produce the bias gradient dbias[m] += sum_k A[k,m] (their A fragments times an all-ones fragment).
-template <typename E, int LAYOUT, int BN, int NWN = 2, int PIPE = 0, bool WGRAD = false>
+// MODE 2 (TN only): grouped AND batched products with a 16-bit output through the ordinary epilogue — blockIdx.z = group * g.gbatch
+// + batch index, operands at grp.A/B/C[group] + batch * g.sAb / sBb / sCb; the reduction length need not be a multiple of 64
+// (as in mode 1); rows are LOADED up to g.M (a multiple of 8) and STORED up to g.m_store.  Serves the key-side products of the
+// cross-attention backward (dV = P^T dO, dK = dS^T Q for every sample of up to four attention problems: one launch).
+template <typename E, int LAYOUT, int BN, int NWN = 2, int PIPE = 0, int MODE = 0>
 __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, GemmGroup grp) {
+  constexpr bool WGRAD = MODE == 1;        // fp32 accumulate epilogue + bias gradient
+  constexpr bool RAGGED = MODE != 0;       // grouped launch (3-D tile order), ragged reduction length
   typedef typename H16<E>::v8 h8;  // E: E or f16_t (same tiles and LDS images; the MFMA opcode differs)
   typedef typename H16<E>::v4 h4;
   constexpr int BM = 128, BK = 64, NW = 2 * NWN;
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
   int tile_m, tile_n, z = 0;
-  if constexpr (WGRAD) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
+  if constexpr (RAGGED) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
   else xcd_tile(g.xcd, tile_m, tile_n, g.band);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const E* A = reinterpret_cast<const E*>(g.A);
@@ -52,6 +58,13 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     B = reinterpret_cast<const E*>(grp.B[z]);
     g.C = grp.C[z];
     g.dbias = grp.dbias[z];
+  }
+  if constexpr (MODE == 2) {
+    static_assert(LAYOUT == D2R_GEMM_TN, "the batched mode is a TN product");
+    const int zg = z / g.gbatch, zb = z - zg * g.gbatch;
+    A = reinterpret_cast<const E*>(grp.A[zg]) + zb * g.sAb;
+    B = reinterpret_cast<const E*>(grp.B[zg]) + zb * g.sBb;
+    g.C = reinterpret_cast<E*>(grp.C[zg]) + zb * g.sCb;
   }
   const bool do_bias = WGRAD && g.dbias != nullptr && tile_n == 0 && (wave % NWN) == 0;
   f32x4 acc_b[TM];
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     int64_t adjA = 0, adjB = 0;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      if constexpr (WGRAD) {
+      if constexpr (RAGGED) {
         const int krow = (wave + NW * i) * 4 + (lane >> 4);
         adjA = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.lda : 0;
       }
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      if constexpr (WGRAD) {
+      if constexpr (RAGGED) {
         const int krow = (wave + NW * i) * 4 + (lane >> 4);
         adjB = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.ldb : 0;
       }
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int nk = WGRAD ? nk_w : g.K / BK;
+  const int nk = RAGGED ? nk_w : g.K / BK;
   // fragments of K-substep kk (32 k) from the staged tile at bA / bB
   auto read_frags = [&](const unsigned char* bA, const unsigned char* bB, int kk, h8 (&af)[TM], h8 (&bfr)[TN]) {
 #pragma unroll
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       asm volatile("s_barrier" ::: "memory");  // tile t is visible to every wave
       const unsigned char* bA = smem + cur * BUF;
       const unsigned char* bB = bA + A_BYTES;
-      if constexpr (WGRAD) {
+      if constexpr (RAGGED) {
         if (t == nk - 1 && rem_w < BK) {  // rows past the reduction length: zero A (B holds clamped, finite rows) -> no contribution
           unsigned char* z0 = smem + cur * BUF + rem_w * (BM * 2);
           const int zbytes = (BK - rem_w) * (BM * 2);
@@ -314,6 +327,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
     return;
   }
   // ---- epilogue (same semantics as the generic kernel) ------------------------------------------------
+  if constexpr (MODE == 2) g.M = g.m_store;  // (operand loads are done: from here on M only guards the stores)
   if (g.c_dtype == H16<E>::DT && g.vecC) {
     constexpr int LDE = WN + 8;
     E* Cs = reinterpret_cast<E*>(smem) + wave * WM * LDE;
@@ -436,7 +450,20 @@ int d2r_gemm_glds_wgrad_try(const GemmArgs& a, const GemmGroup& grp, int n, hipS
   if (!d2r_is16(a.dtype) || a.K < 128 || a.M < 128 || a.N < 128 || !a.vecA || !a.vecB || a.M % 8 != 0 || a.N % 8 != 0) return 0;
   dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), n);
   d2r_gemm_variant_tl = 20;
-  if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
-  else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, true>), grid, dim3(256), 0, st, a, grp);
+  if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, 1>), grid, dim3(256), 0, st, a, grp);
+  else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, 1>), grid, dim3(256), 0, st, a, grp);
+  return 1;
+}
+
+
+// Grouped + batched TN products with a 16-bit output (mode 2 of the kernel): `ngroups` (<= 32) operand triples, `a.gbatch`
+// problems each at the batch strides a.sAb / sBb / sCb.  Returns 1 when taken.
+int d2r_gemm_glds_batched_tn_try(const GemmArgs& a, const GemmGroup& grp, int ngroups, hipStream_t st) {
+  if (!d2r_is16(a.dtype) || a.c_dtype != a.dtype || !a.vecA || !a.vecB || !a.vecC || a.M % 8 != 0 || a.N % 8 != 0 || a.M < 8 || a.N < 8 || a.K < 1) return 0;
+  if (ngroups < 1 || ngroups > D2R_GEMM_GROUP_MAX || a.gbatch < 1 || (int64_t)ngroups * a.gbatch > 65535) return 0;
+  dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), ngroups * a.gbatch);
+  d2r_gemm_variant_tl = 22;
+  if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, 2>), grid, dim3(256), 0, st, a, grp);
+  else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, 2>), grid, dim3(256), 0, st, a, grp);
   return 1;
 }

@@ -222,14 +222,12 @@ int xat_fwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t l
 int xat_bwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t ldk, const void* v, int64_t ldv, int Lk, const void* dO,
             const float* lse, void* dq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* P, void* dS, float scale) {
   const int lkp = (Lk + 7) / 8 * 8;
-  TRY(d2r_xattn_bwd(c.dt, q, E, (int64_t)d.Lq * E, k, ldk, (int64_t)Lk * ldk, v, ldv, (int64_t)Lk * ldv, dO, E, (int64_t)d.Lq * E, nullptr,
-                    lse, dq, E, (int64_t)d.Lq * E, P, dS, lkp, d.B, d.Lq, Lk, E, scale, c.st));
-  G gv(c.dt, c.dt, D2R_GEMM_TN, Lk, E, d.Lq, P, lkp, dO, E, dv, lddv);  // dV = P^T dO
-  gv.batch(d.B, (int64_t)d.Lq * lkp, (int64_t)d.Lq * E, (int64_t)Lk * lddv);
-  TRY(d2r_gemm(&gv.d, c.st));
-  G gk(c.dt, c.dt, D2R_GEMM_TN, Lk, E, d.Lq, dS, lkp, q, E, dk, lddk);  // dK = dS^T Q
-  gk.batch(d.B, (int64_t)d.Lq * lkp, (int64_t)d.Lq * E, (int64_t)Lk * lddk);
-  return d2r_gemm(&gk.d, c.st);
+  const void *qa[1] = {q}, *ka[1] = {k}, *va[1] = {v}, *ga[1] = {dO};
+  const float* la[1] = {lse};
+  void *dqa[1] = {dq}, *dka[1] = {dk}, *dva[1] = {dv}, *pa[1] = {P}, *dsa[1] = {dS};
+  return d2r_xattn_bwd_multi(c.dt, 1, qa, E, (int64_t)d.Lq * E, ka, ldk, (int64_t)Lk * ldk, va, ldv, (int64_t)Lk * ldv, ga, E, (int64_t)d.Lq * E,
+                             nullptr, la, dqa, E, (int64_t)d.Lq * E, dka, lddk, (int64_t)Lk * lddk, dva, lddv, (int64_t)Lk * lddv, pa, dsa, lkp,
+                             d.B, d.Lq, Lk, E, scale, c.st);
 }
 
 // ---- forward of one routing layer --------------------------------------------------------------------------

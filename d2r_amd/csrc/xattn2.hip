@@ -26,17 +26,29 @@
 
 namespace {
 
+constexpr int X2_MAXCORE = 4;  // attention problems ("cores") of one launch: same shapes and strides, own tensors
+
 template <typename E>
 struct X2Args {
-  const E *q, *k, *v, *res;
-  E* o;
+  const E *q[X2_MAXCORE], *k[X2_MAXCORE], *v[X2_MAXCORE], *res[X2_MAXCORE];
+  E* o[X2_MAXCORE];
+  float* lse[X2_MAXCORE];
   const float* mask;
-  float* lse;
   int64_t ldq, sqb, ldk, skb, ldv, svb, ldo, sob, ldr, srb;
-  int B, Lq, Lk, ntile;
+  int B, Lq, Lk, ntile, ncore;
   float scale;
   int dbg;  // timing experiments only (D2R_X2_DBG): 1 = no DMA issue, 2 = no score / PV arithmetic, 3 = no swizzle
 };
+
+// wave-uniform pick of a per-core kernel argument (a select chain: a run-time index into the by-value argument arrays
+// would be served from scratch)
+template <typename P>
+__device__ __forceinline__ P x2_pick(P const (&arr)[X2_MAXCORE], int core) {
+  P r = arr[0];
+#pragma unroll
+  for (int c = 1; c < X2_MAXCORE; ++c) r = core == c ? arr[c] : r;
+  return r;
+}
 
 constexpr int XE = 768, CH = 16, ROWB = XE * 2 /*1536*/, CB = CH * ROWB /*24576*/, NB = 4, NW = 8;
 
@@ -66,17 +78,18 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
-  // all query tiles of a sample on one XCD (blocks b and b+8 share an XCD): id -> (sample, tile)
+  // all query tiles of a (core, sample) on one XCD (blocks b and b+8 share an XCD): id -> (core, sample, tile)
   const int id = blockIdx.x, xcd = id & 7, rr = id >> 3;
-  int tile = rr % a.ntile, b = (rr / a.ntile) * 8 + xcd;
-  if (a.dbg == 4) {  // timing experiment: plain order (the tiles of a sample land on all eight XCDs)
-    b = id / a.ntile;
-    tile = id - b * a.ntile;
-  }
+  const int tile = rr % a.ntile, unit = rr / a.ntile;
+  const int core = unit % a.ncore, b = (unit / a.ncore) * 8 + xcd;
   if (b >= a.B) return;
   const int q0 = tile * QT;
-  const E* Kg = a.k + b * a.skb;
-  const E* Vg = a.v + b * a.svb;
+  const E* Qg = x2_pick(a.q, core) + b * a.sqb;
+  const E* Kg = x2_pick(a.k, core) + b * a.skb;
+  const E* Vg = x2_pick(a.v, core) + b * a.svb;
+  const E* Rg = x2_pick(a.res, core);
+  E* Og = x2_pick(a.o, core) + b * a.sob;
+  float* Lg = x2_pick(a.lse, core) + (int64_t)b * a.Lq;
   float* Sm = reinterpret_cast<float*>(smem + L::S);
   float* Sp = reinterpret_cast<float*>(smem + L::SPART);
   float* Ms = reinterpret_cast<float*>(smem + L::MS);
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
 #pragma unroll
   for (int t = 0; t < NQT; ++t) {
     const int qrow = min(q0 + t * 16 + fr, a.Lq - 1);
-    const E* qp = a.q + b * a.sqb + (int64_t)qrow * a.ldq + wave * 96 + fq * 8;
+    const E* qp = Qg + (int64_t)qrow * a.ldq + wave * 96 + fq * 8;
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) qf[t][kk] = *reinterpret_cast<const E8*>(qp + kk * 32);
   }
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
         const int key = lane + 64 * i;
         if (key < nkeys) Prow[key] = (E)(v[i] * inv);
       }
-      if (lane == 0 && q0 + row < a.Lq) a.lse[(int64_t)b * a.Lq + q0 + row] = mx + logf(sum);
+      if (lane == 0 && q0 + row < a.Lq) Lg[q0 + row] = mx + logf(sum);
     }
   }
   // (the lse store above is the only vector-memory op besides the DMA stream; it is older than nothing we wait for by count:
@@ -251,22 +264,25 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
     const int qrow = q0 + row;
     if (qrow >= a.Lq) continue;
     Pack<E, 8> v = ld_pack<E, 8>(Os + row * LDO + ch * 8);
-    if (a.res) {
-      const Pack<E, 8> rv = ld_pack<E, 8>(a.res + b * a.srb + (int64_t)qrow * a.ldr + ch * 8);
+    if (Rg) {
+      const Pack<E, 8> rv = ld_pack<E, 8>(Rg + b * a.srb + (int64_t)qrow * a.ldr + ch * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v.v[j] = (E)((float)v.v[j] + (float)rv.v[j]);
     }
-    st_pack<E, 8>(a.o + b * a.sob + (int64_t)qrow * a.ldo + ch * 8, v);
+    st_pack<E, 8>(Og + (int64_t)qrow * a.ldo + ch * 8, v);
   }
 }
 
 template <typename E>
-static int x2_launch(const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb, const void* v, int64_t ldv,
-                     int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual, int64_t ldr, int64_t srb, const float* mask,
-                     float* lse, int B, int Lq, int Lk, float scale, hipStream_t st) {
+static int x2_launch(int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
+                     const void* const* v, int64_t ldv, int64_t svb, void* const* o, int64_t ldo, int64_t sob, const void* const* residual,
+                     int64_t ldr, int64_t srb, const float* mask, float* const* lse, int B, int Lq, int Lk, float scale, hipStream_t st) {
   X2Args<E> a = {};
-  a.q = (const E*)q, a.k = (const E*)k, a.v = (const E*)v, a.res = (const E*)residual, a.o = (E*)o;
-  a.mask = mask, a.lse = lse;
+  for (int c = 0; c < ncore; ++c) {
+    a.q[c] = (const E*)q[c], a.k[c] = (const E*)k[c], a.v[c] = (const E*)v[c], a.o[c] = (E*)o[c], a.lse[c] = lse[c];
+    a.res[c] = residual ? (const E*)residual[c] : nullptr;
+  }
+  a.mask = mask, a.ncore = ncore;
   a.ldq = ldq, a.sqb = sqb, a.ldk = ldk, a.skb = skb, a.ldv = ldv, a.svb = svb, a.ldo = ldo, a.sob = sob, a.ldr = ldr, a.srb = srb;
   a.B = B, a.Lq = Lq, a.Lk = Lk, a.scale = scale;
   static const int dbg = getenv("D2R_X2_DBG") ? atoi(getenv("D2R_X2_DBG")) : 0;
@@ -275,28 +291,29 @@ static int x2_launch(const void* q, int64_t ldq, int64_t sqb, const void* k, int
   if (Lk <= 256) {
     // 32-query tiles halve the K / V re-reads; 16-query tiles double the workgroups: take 32 when that still fills the chip
     const int nt32 = (Lq + 31) / 32;
-    if (nt32 * B >= 192) {
+    if (nt32 * B * ncore >= 192) {
       a.ntile = nt32;
-      hipLaunchKernelGGL((xattn2_fwd_kernel<E, 2, 256>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
+      hipLaunchKernelGGL((xattn2_fwd_kernel<E, 2, 256>), dim3(bgrp * a.ntile * ncore), dim3(512), 0, st, a);
     } else {
       a.ntile = (Lq + 15) / 16;
-      hipLaunchKernelGGL((xattn2_fwd_kernel<E, 1, 256>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
+      hipLaunchKernelGGL((xattn2_fwd_kernel<E, 1, 256>), dim3(bgrp * a.ntile * ncore), dim3(512), 0, st, a);
     }
   } else {
     a.ntile = (Lq + 15) / 16;
-    hipLaunchKernelGGL((xattn2_fwd_kernel<E, 1, 640>), dim3(bgrp * a.ntile), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((xattn2_fwd_kernel<E, 1, 640>), dim3(bgrp * a.ntile * ncore), dim3(512), 0, st, a);
   }
   return 1;
 }
 
 }  // namespace
 
-// Host entry used by d2r_xattn_fwd (attention.hip).  Returns 1 when the launch was taken.
-int d2r_xattn2_fwd_try(int dtype, const void* q, int64_t ldq, int64_t sqb, const void* k, int64_t ldk, int64_t skb, const void* v,
-                       int64_t ldv, int64_t svb, void* o, int64_t ldo, int64_t sob, const void* residual, int64_t ldr, int64_t srb,
-                       const float* mask, float* lse, int B, int Lq, int Lk, float scale, hipStream_t st) {
-  if (Lk > 640 || Lk < 1 || Lq < 1) return 0;
+// Host entry used by d2r_xattn_fwd / d2r_xattn_fwd_multi (attention.hip): `ncore` (1..4) attention problems of identical shape and
+// strides in ONE launch (h_* are host arrays of device pointers; h_res may be NULL).  Returns 1 when the launch was taken.
+int d2r_xattn2_fwd_try(int dtype, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
+                       const void* const* v, int64_t ldv, int64_t svb, void* const* o, int64_t ldo, int64_t sob, const void* const* residual,
+                       int64_t ldr, int64_t srb, const float* mask, float* const* lse, int B, int Lq, int Lk, float scale, hipStream_t st) {
+  if (Lk > 640 || Lk < 1 || Lq < 1 || ncore < 1 || ncore > X2_MAXCORE) return 0;
   if (dtype == D2R_F16)
-    return x2_launch<f16_t>(q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, Lq, Lk, scale, st);
-  return x2_launch<bf16_t>(q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, Lq, Lk, scale, st);
+    return x2_launch<f16_t>(ncore, q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, Lq, Lk, scale, st);
+  return x2_launch<bf16_t>(ncore, q, ldq, sqb, k, ldk, skb, v, ldv, svb, o, ldo, sob, residual, ldr, srb, mask, lse, B, Lq, Lk, scale, st);
 }

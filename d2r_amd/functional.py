@@ -581,18 +581,15 @@ def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None
     d = E // H
     dt = _dt_of(dtype)
     tag = "xattn_core_bwd" if H == 1 else "mha_core_bwd"
-    if P.dim() == 3 and H == 1:  # fused single-head forward: dS, P and dQ in one launch, then the two key-side GEMMs
+    if P.dim() == 3 and H == 1:  # fused single-head forward: dS, P and dQ in one launch, then dV / dK as ONE grouped batched launch
         Lkp = (Lk + 7) // 8 * 8
         Pb = torch.empty(B, Lq, Lkp, dtype=dtype, device=device)
         dS = torch.empty(B, Lq, Lkp, dtype=dtype, device=device)
-        _lib.call("d2r_xattn_bwd", dt, q[0], q[1], q[2], k[0], k[1], k[2], v[0], v[1], v[2], g.data_ptr(), E, Lq * E,
-                  _ptr(mask), P.data_ptr(), dq[0], dq[1], dq[2], Pb.data_ptr(), dS.data_ptr(), Lkp, B, Lq, Lk, E, scale,
-                  _stream(), meta=dict(group=tag, algo_bytes=float(2 * B * (2 * Lq + 2 * Lk) * E * 2)))
-        sP = (Lq * Lkp, 0)
-        gemm(GEMM_TN, Lk, E, Lq, Pb.data_ptr(), Lkp, g.data_ptr(), E, dv[0], dv[1], dtype=dt, c_dtype=dt, nb=B,
-             sA=sP, sB=(Lq * E, 0), sC=(dv[2], 0), tag=tag)
-        gemm(GEMM_TN, Lk, E, Lq, dS.data_ptr(), Lkp, q[0], q[1], dk[0], dk[1], dtype=dt, c_dtype=dt, nb=B,
-             sA=sP, sB=(q[2], 0), sC=(dk[2], 0), tag=tag)
+        one = lambda x: _iparr([x])
+        _lib.call("d2r_xattn_bwd_multi", dt, 1, one(q[0]), q[1], q[2], one(k[0]), k[1], k[2], one(v[0]), v[1], v[2], one(g.data_ptr()), E, Lq * E,
+                  _ptr(mask), one(P.data_ptr()), one(dq[0]), dq[1], dq[2], one(dk[0]), dk[1], dk[2], one(dv[0]), dv[1], dv[2],
+                  one(Pb.data_ptr()), one(dS.data_ptr()), Lkp, B, Lq, Lk, E, scale, _stream(),
+                  meta=dict(group=tag, algo_bytes=float(2 * B * (2 * Lq + 2 * Lk) * E * 2)))
         return
     if P.dim() == 3:  # fused forward ran: recompute P from q, k and the log-sum-exp
         dsum = torch.empty_like(P) if (Lq > 256 or Lk > 256) else None  # long sequences: D handed from the dQ to the dK/dV kernel

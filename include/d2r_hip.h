@@ -306,6 +306,24 @@ int d2r_xattn_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void
                   const float* lse, void* dq, int64_t lddq, int64_t sdqb, void* P, void* dS, int lkp, int B, int Lq,
                   int Lk, int D, float scale, void* stream);
 
+/* Several attention problems ("cores") of IDENTICAL shape and strides in one launch: the three cross-modal alignment cores of a
+ * routing layer (GlobalLocalAlignmentCell, CrossModalRefinementCell, ContextRichCrossModalCell: models/Cells.py:147,85,238 all
+ * call the same softmax(100 q k^T / sqrt(768)) v on their own projections of the same two token tensors) give three times
+ * the workgroups of one - a single core leaves half of the 256 CUs idle at B = 32.  h_* are HOST arrays of `ncore` (1..4)
+ * device pointers; h_residual may be NULL (or hold NULLs).  d2r_xattn_bwd_multi also runs the key-side products
+ * dV = P^T dO and dK = dS^T Q of every sample and core (ONE grouped, batched launch of the LDS-DMA GEMM kernel when dk / dv
+ * share their strides, e.g. the two halves of a packed k|v gradient), so it returns dq, dk and dv; h_P / h_dS are scratch
+ * (16-bit [B, Lq, lkp] each, lkp = Lk rounded up to 8). */
+int d2r_xattn_fwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
+                        int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, void* const* h_o, int64_t ldo, int64_t sob,
+                        const void* const* h_residual, int64_t ldr, int64_t srb, const float* mask, float* const* h_lse, int B, int Lq,
+                        int Lk, int D, float scale, void* stream);
+int d2r_xattn_bwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
+                        int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, const void* const* h_dO, int64_t ldg, int64_t sgb,
+                        const float* mask, const float* const* h_lse, void* const* h_dq, int64_t lddq, int64_t sdqb, void* const* h_dk,
+                        int64_t lddk, int64_t sdkb, void* const* h_dv, int64_t lddv, int64_t sdvb, void* const* h_P, void* const* h_dS,
+                        int lkp, int B, int Lq, int Lk, int D, float scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K15 one transformer encoder layer per call (16-bit dtypes): BertLayer.forward (models/modeling_unimo.py:473-512,
  * post-LayerNorm, GELU) and CLIPEncoderLayer.forward (:222-268, pre-LayerNorm, quick_gelu), forward or backward.

@@ -737,3 +737,68 @@ def test_linear_many_rows(gpu, dtype, shape):
              name=f"linear gelu {shape}")
     run_both(lambda x, w, b, r: F.linear(x, w, b, lp(w, dtype), residual=r), lambda x, w, b, r: x @ w.t() + b + r,
              [x, w, b, r], dtype, gpu, name=f"linear+res {shape}")
+
+
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(5, 128, 197, 3), (9, 197, 128, 3), (3, 40, 250, 2), (2, 130, 577, 3), (32, 128, 197, 3)], ids=lambda c: "x".join(map(str, c)))
+def test_xattn_multi_launch_matches_single_launches(gpu, lowp, cfg):
+    """d2r_xattn_fwd_multi / d2r_xattn_bwd_multi (several attention problems of one shape in one launch: the three alignment
+    cores of a routing layer) give, per problem, exactly the bits of the single-problem entry points, and dk / dv (the grouped,
+    batched key-side launch; packed k|v layout as in the routing cells) match an fp64 expression of the same products."""
+    import ctypes as C
+    from d2r_amd import _lib
+    from d2r_amd import functional as F
+    B, Lq, Lk, nc = cfg
+    E, dt = 768, F._dt_of(lowp)
+    scale = 100.0 / math.sqrt(768)
+    lkp = (Lk + 7) // 8 * 8
+    st = torch.cuda.current_stream().cuda_stream
+    arr = lambda ts: F._iparr([t if isinstance(t, int) else t.data_ptr() for t in ts])
+    q = [rnd(B, Lq, E, seed=10 + c, scale=0.15).to(lowp).to(gpu) for c in range(nc)]
+    kv = [rnd(B, Lk, 2 * E, seed=20 + c, scale=0.15).to(lowp).to(gpu) for c in range(nc)]
+    dO = [rnd(B, Lq, E, seed=30 + c).to(lowp).to(gpu) for c in range(nc)]
+    es = 2
+
+    def fwd(multi):
+        o = [torch.empty(B, Lq, E, dtype=lowp, device=gpu) for _ in range(nc)]
+        lse = [torch.empty(B, Lq, dtype=torch.float32, device=gpu) for _ in range(nc)]
+        if multi:
+            _lib.call("d2r_xattn_fwd_multi", dt, nc, arr(q), E, Lq * E, arr(kv), 2 * E, Lk * 2 * E, arr([t.data_ptr() + E * es for t in kv]), 2 * E,
+                      Lk * 2 * E, arr(o), E, Lq * E, None, E, Lq * E, None, arr(lse), B, Lq, Lk, E, scale, st)
+        else:
+            for c in range(nc):
+                _lib.call("d2r_xattn_fwd", dt, q[c].data_ptr(), E, Lq * E, kv[c].data_ptr(), 2 * E, Lk * 2 * E, kv[c].data_ptr() + E * es, 2 * E,
+                          Lk * 2 * E, o[c].data_ptr(), E, Lq * E, None, E, Lq * E, None, lse[c].data_ptr(), B, Lq, Lk, E, scale, st)
+        return o, lse
+
+    o1, l1 = fwd(False)
+    o3, l3 = fwd(True)
+    for c in range(nc):
+        assert torch.equal(o1[c], o3[c]) and torch.equal(l1[c], l3[c]), f"forward of problem {c} differs between the multi and the single launch"
+
+    def bwd(ncore_per_call):
+        dq = [torch.empty(B, Lq, E, dtype=lowp, device=gpu) for _ in range(nc)]
+        dkv = [torch.empty(B, Lk, 2 * E, dtype=lowp, device=gpu) for _ in range(nc)]
+        P = [torch.empty(B, Lq, lkp, dtype=lowp, device=gpu) for _ in range(nc)]
+        dS = [torch.empty(B, Lq, lkp, dtype=lowp, device=gpu) for _ in range(nc)]
+        for c0 in range(0, nc, ncore_per_call):
+            sl = slice(c0, c0 + ncore_per_call)
+            n = len(q[sl])
+            _lib.call("d2r_xattn_bwd_multi", dt, n, arr(q[sl]), E, Lq * E, arr(kv[sl]), 2 * E, Lk * 2 * E, arr([t.data_ptr() + E * es for t in kv[sl]]),
+                      2 * E, Lk * 2 * E, arr(dO[sl]), E, Lq * E, None, arr(l1[sl]), arr(dq[sl]), E, Lq * E, arr(dkv[sl]), 2 * E, Lk * 2 * E,
+                      arr([t.data_ptr() + E * es for t in dkv[sl]]), 2 * E, Lk * 2 * E, arr(P[sl]), arr(dS[sl]), lkp, B, Lq, Lk, E, scale, st)
+        return dq, dkv, P, dS
+
+    a = bwd(1)
+    b = bwd(nc)
+    torch.cuda.synchronize()
+    for c in range(nc):
+        for name, x, y in zip(("dq", "dkv", "P", "dS"), [t[c] for t in a], [t[c] for t in b]):
+            assert torch.equal(x[..., :Lk] if name in ("P", "dS") else x, y[..., :Lk] if name in ("P", "dS") else y), f"{name} of problem {c} differs"
+    # dk / dv against fp64 from the kernel's own P / dS (isolates the grouped batched product)
+    for c in range(nc):
+        P64, dS64 = b[2][c][..., :Lk].double().cpu(), b[3][c][..., :Lk].double().cpu()
+        dv_ref = P64.transpose(1, 2) @ dO[c].double().cpu()
+        dk_ref = dS64.transpose(1, 2) @ q[c].double().cpu()
+        check(f"dv[{c}]", b[1][c][..., E:], dv_ref, lowp)
+        check(f"dk[{c}]", b[1][c][..., :E], dk_ref, lowp)
