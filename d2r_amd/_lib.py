@@ -68,7 +68,7 @@ class InteractionDesc(C.Structure):
                 ("heads_imrc", i32), ("hid_imrc", i32), ("train", i32), ("layers", C.POINTER(RoutingLayerParams)),
                 ("own", vp), ("other", vp), ("out", vp), ("paths", vp), ("arena", vp), ("arena_bytes", sz),
                 ("splitk_ws", vp), ("splitk_bytes", sz), ("d_out", vp), ("d_paths", vp), ("d_own", vp), ("d_other", vp),
-                ("scratch", vp), ("scratch_bytes", sz)]
+                ("scratch", vp), ("scratch_bytes", sz), ("kv_all", LinearParams)]
 
 
 # name -> (restype, argtypes); every symbol include/d2r_hip.h declares

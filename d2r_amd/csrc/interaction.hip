@@ -40,13 +40,19 @@ struct Arena {
 struct Dims {
   int B, Lq, Lk, nc, nl, hid, hidi, heads;
   int T, S, n, lkp, lqp;
+  int kvpl, nkv;   // alignment cells (GLAC, CMRC, CRCMC) per layer / in the module: each owns a 1536-column block of the k|v run
+  int64_t ldkv;    // row stride of the module-wide k|v projection of `other`: nkv * 1536
   size_t es;
 };
+
+// column block of (layer l, alignment cell which: 0 GLAC, 1 CMRC, 2 CRCMC) in the k|v run (layer-major, cells in this order)
+int kv_block(const Dims& d, int l, int which) { return l * d.kvpl + (which == 0 ? 0 : which == 1 ? (d.nc > 1) : (d.nc > 1) + (d.nc > 3)); }
 
 Dims make_dims(int B, int Lq, int Lk, int nc, int nl, int hid, int hidi, int heads) {
   Dims d;
   d.B = B, d.Lq = Lq, d.Lk = Lk, d.nc = nc, d.nl = nl, d.hid = hid, d.hidi = hidi, d.heads = heads;
   d.T = B * Lq, d.S = B * Lk, d.n = Lq + 1, d.lkp = (Lk + 7) / 8 * 8, d.lqp = (Lq + 7) / 8 * 8;
+  d.kvpl = (nc > 1) + (nc > 3) + (nc > 4), d.nkv = d.kvpl * nl, d.ldkv = (int64_t)d.nkv * 2 * E;
   d.es = 2;
   return d;
 }
@@ -66,14 +72,15 @@ struct LayerF {
   void* outs[6];
 };
 
-void plan_fwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerF& L) {
-  const size_t TE = (size_t)d.T * E * d.es, SE = (size_t)d.S * E * d.es, BE = (size_t)d.B * E * d.es;
+// kvall: the module-wide k|v projection [S, nkv*1536] (taken from the arena before the first layer); l: layer index
+void plan_fwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerF& L, char* kvall, int l) {
+  const size_t TE = (size_t)d.T * E * d.es, BE = (size_t)d.B * E * d.es;
   memset(&L, 0, sizeof(L));
   L.pooled = (float*)A.take((size_t)(first ? 1 : d.nc) * d.B * E * 4);
   L.h = (float*)A.take((size_t)d.B * d.nc * d.hid * 4);
   L.gates = (float*)A.take((size_t)d.B * d.nc * P * 4);
   if (d.nc > 1) {  // GLAC
-    L.g_q = A.take(TE), L.g_kv = A.take(2 * SE), L.g_c = A.take(TE), L.g_sq = A.take(TE), L.g_loc = A.take(TE);
+    L.g_q = A.take(TE), L.g_kv = kvall ? kvall + (size_t)kv_block(d, l, 0) * 2 * E * d.es : nullptr, L.g_c = A.take(TE), L.g_sq = A.take(TE), L.g_loc = A.take(TE);
     L.g_l2 = A.take(TE), L.g_sl = A.take(TE);
     L.g_pt = A.take(BE), L.g_pi = A.take(BE), L.g_dg = A.take(BE), L.g_glo = A.take(BE), L.g_l2g = A.take(BE), L.g_sg = A.take(BE);
     L.g_S = A.take((size_t)d.B * d.n * E * d.es);
@@ -87,12 +94,12 @@ void plan_fwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerF& L)
     L.lse_i = (float*)A.take((size_t)d.B * 64 * d.Lq * 4);  // up to 64 heads (the size queries do not know the head count)
   }
   if (d.nc > 3) {  // CMRC
-    L.c_q = A.take(TE), L.c_kv = A.take(2 * SE), L.c_c = A.take(TE), L.c_s = A.take(TE), L.c_h = A.take(TE);
+    L.c_q = A.take(TE), L.c_kv = kvall ? kvall + (size_t)kv_block(d, l, 1) * 2 * E * d.es : nullptr, L.c_c = A.take(TE), L.c_s = A.take(TE), L.c_h = A.take(TE);
     L.c_mod = A.take(TE), L.c_f = A.take(TE), L.e3 = A.take(TE);
     L.c_lse = (float*)A.take((size_t)d.T * 4);
   }
   if (d.nc > 4) {  // CRCMC
-    L.r_q = A.take(TE), L.r_kv = A.take(2 * SE), L.r_c = A.take(TE), L.r_Qs = A.take(TE), L.r_Ks = A.take(TE);
+    L.r_q = A.take(TE), L.r_kv = kvall ? kvall + (size_t)kv_block(d, l, 2) * 2 * E * d.es : nullptr, L.r_c = A.take(TE), L.r_Qs = A.take(TE), L.r_Ks = A.take(TE);
     L.r_a = A.take(TE), L.r_b = A.take(TE), L.e4 = A.take(TE);
     L.r_lse = (float*)A.take((size_t)d.T * 4), L.r_lse2 = (float*)A.take((size_t)d.T * 4);
   }
@@ -233,7 +240,7 @@ int xat_bwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t l
 // ---- forward of one routing layer --------------------------------------------------------------------------
 int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
               const void* const* refs, const void* other, LayerF& L, void* out_final, float* probs, int64_t ldp) {
-  const int B = d.B, T = d.T, S = d.S, nc = d.nc, hid = d.hid, n = d.n;
+  const int B = d.B, T = d.T, nc = d.nc, hid = d.hid, n = d.n;
   const int64_t TEe = (int64_t)d.Lq * E, SEe = (int64_t)d.Lk * E;
   const d2r_linear_params* lp = p.lin;
   // --- routers (fp32 end to end: routing decisions are exact) -------------------------------------------------
@@ -253,12 +260,30 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     g.d.bias = lp[D2R_RL_R2].b, g.d.s_bias_b = P, g.d.act = D2R_ACT_TANH_RELU;
     TRY(d2r_gemm(&g.d, c.st));
   }
+  // --- the alignment cores of GLAC / CMRC / CRCMC: their query projections, then ONE attention launch for all of them (same
+  //     shapes, same softmax(100 q k^T / sqrt(768)) v: three times the workgroups of a single core).  Keys and values are column
+  //     blocks of the module-wide k|v projection of `other` computed before the first layer. ---------------------------------
+  {
+    const void *qa[3], *ka[3], *va[3];
+    void* oa[3];
+    float* la[3];
+    int ncore = 0;
+    auto core = [&](const void* x, const d2r_linear_params& pq, void* qbuf, const void* kv, void* o, float* lse) -> int {
+      TRY(lin(c, T, E, E, x, E, pq, qbuf));
+      qa[ncore] = qbuf, ka[ncore] = kv, va[ncore] = (const char*)kv + E * d.es, oa[ncore] = o, la[ncore] = lse;
+      ++ncore;
+      return D2R_OK;
+    };
+    if (nc > 1) TRY(core(refs[1], lp[D2R_RL_GLAC_Q], L.g_q, L.g_kv, L.g_c, L.g_lse));
+    if (nc > 3) TRY(core(refs[3], lp[D2R_RL_CMRC_Q], L.c_q, L.c_kv, L.c_c, L.c_lse));
+    if (nc > 4) TRY(core(refs[4], lp[D2R_RL_CRCMC_Q], L.r_q, L.r_kv, L.r_c, L.r_lse));
+    if (ncore)
+      TRY(d2r_xattn_fwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, (int64_t)d.Lk * d.ldkv, va, d.ldkv, (int64_t)d.Lk * d.ldkv, oa, E, TEe, nullptr, E,
+                              TEe, nullptr, la, B, d.Lq, d.Lk, E, XSCALE, c.st));
+  }
   // --- GLAC (cell 1) ---------------------------------------------------------------------------------------------
   if (nc > 1) {
     const void* x = refs[1];
-    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_GLAC_Q], L.g_q));
-    TRY(lin(c, S, 2 * E, E, other, E, lp[D2R_RL_GLAC_KV], L.g_kv));
-    TRY(xat_fwd(c, d, L.g_q, L.g_kv, 2 * E, (const char*)L.g_kv + E * d.es, 2 * E, d.Lk, L.g_c, nullptr, L.g_lse, XSCALE));
     TRY(d2r_sqdiff_fwd(c.dt, x, L.g_c, L.g_sq, (int64_t)T * E, c.st));
     TRY(lin(c, T, E, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC], L.g_loc));
     TRY(d2r_l2norm_fwd(c.dt, L.g_loc, L.g_l2, L.g_nloc, T, E, c.st));
@@ -295,9 +320,6 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
   // --- CMRC (cell 3) -----------------------------------------------------------------------------------------------
   if (nc > 3) {
     const void* x = refs[3];
-    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CMRC_Q], L.c_q));
-    TRY(lin(c, S, 2 * E, E, other, E, lp[D2R_RL_CMRC_KV], L.c_kv));
-    TRY(xat_fwd(c, d, L.c_q, L.c_kv, 2 * E, (const char*)L.c_kv + E * d.es, 2 * E, d.Lk, L.c_c, nullptr, L.c_lse, XSCALE));
     TRY(lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE], L.c_s, D2R_ACT_TANH));
     TRY(lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT], L.c_h));
     TRY(d2r_muladd_fwd(c.dt, x, L.c_s, L.c_h, L.c_mod, (int64_t)T * E, c.st));
@@ -307,9 +329,6 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
   // --- CRCMC (cell 4) ----------------------------------------------------------------------------------------------
   if (nc > 4) {
     const void* x = refs[4];
-    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CRCMC_Q], L.r_q));
-    TRY(lin(c, S, 2 * E, E, other, E, lp[D2R_RL_CRCMC_KV], L.r_kv));
-    TRY(xat_fwd(c, d, L.r_q, L.r_kv, 2 * E, (const char*)L.r_kv + E * d.es, 2 * E, d.Lk, L.r_c, nullptr, L.r_lse, XSCALE));
     TRY(lin(c, T, E, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1], L.r_Qs, D2R_ACT_TANH));
     TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CRCMC_MLP2], L.r_Ks, D2R_ACT_TANH));
     TRY(lin(c, T, E, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1], L.r_a));
@@ -353,8 +372,10 @@ struct LayerB {
   void *s_dg, *s_da1, *s_db1, *s_dz, *s_dz1p, *s_dab, *s_dat, *s_dbt, *s_dap, *s_dbp;
 };
 
-void plan_bwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerB& K) {
-  const size_t TE = (size_t)d.T * E * d.es, SE = (size_t)d.S * E * d.es, BE = (size_t)d.B * E * d.es;
+// dkvall: gradient of the module-wide k|v projection [S, nkv*1536] (taken from the scratch before the first layer)
+void plan_bwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerB& K, char* dkvall, int l) {
+  const size_t TE = (size_t)d.T * E * d.es, BE = (size_t)d.B * E * d.es;
+  auto dkv = [&](int which) -> void* { return dkvall ? dkvall + (size_t)kv_block(d, l, which) * 2 * E * d.es : nullptr; };
   memset(&K, 0, sizeof(K));
   K.dgates = (float*)A.take((size_t)d.B * d.nc * P * 4), K.dG = (float*)A.take((size_t)d.B * d.nc * P * 4);
   K.dh = (float*)A.take((size_t)d.B * d.nc * d.hid * 4), K.dhp = (float*)A.take((size_t)d.B * d.nc * d.hid * 4);
@@ -375,20 +396,20 @@ void plan_bwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerB& K)
   if (d.nc > 1) {
     K.g_dwsum = A.take(BE), K.g_dw16 = A.take((size_t)d.B * d.n * d.es + 16), K.g_dS = A.take((size_t)d.B * d.n * E * d.es);
     K.g_dsl = A.take(TE), K.g_dl2 = A.take(TE), K.g_dloc = A.take(TE), K.g_dsq = A.take(TE), K.g_da = A.take(TE), K.g_dc = A.take(TE);
-    K.g_dq = A.take(TE), K.g_P = A.take((size_t)d.T * d.lkp * d.es), K.g_dSa = A.take((size_t)d.T * d.lkp * d.es), K.g_dkv = A.take(2 * SE);
+    K.g_dq = A.take(TE), K.g_P = A.take((size_t)d.T * d.lkp * d.es), K.g_dSa = A.take((size_t)d.T * d.lkp * d.es), K.g_dkv = dkv(0);
     K.g_dl2g = A.take(BE), K.g_dglo = A.take(BE), K.g_ddg = A.take(BE), K.g_dpt = A.take(BE), K.g_dpi = A.take(BE);
     K.g_dptp = A.take(BE), K.g_dpip = A.take(BE), K.g_da16 = A.take((size_t)d.B * d.n * d.es + 16);
     K.g_dwf = (float*)A.take((size_t)d.B * d.n * 4), K.g_daf = (float*)A.take((size_t)d.B * d.n * 4);
   }
   if (d.nc > 3) {
     K.c_dfp = A.take(TE), K.c_dmod = A.take(TE), K.c_da = A.take(TE), K.c_ds = A.take(TE), K.c_dsp = A.take(TE), K.c_dc = A.take(TE);
-    K.c_dq = A.take(TE), K.c_P = A.take((size_t)d.T * d.lkp * d.es), K.c_dSa = A.take((size_t)d.T * d.lkp * d.es), K.c_dkv = A.take(2 * SE);
+    K.c_dq = A.take(TE), K.c_P = A.take((size_t)d.T * d.lkp * d.es), K.c_dSa = A.take((size_t)d.T * d.lkp * d.es), K.c_dkv = dkv(1);
     K.c_tmp = A.take(TE);
   }
   if (d.nc > 4) {
     K.r_da = A.take(TE), K.r_P2 = A.take((size_t)d.T * d.lqp * d.es), K.r_dS2 = A.take((size_t)d.T * d.lqp * d.es), K.r_dKv = A.take(TE);
     K.r_db = A.take(TE), K.r_dQs = A.take(TE), K.r_dKs = A.take(TE), K.r_dQsp = A.take(TE), K.r_dKsp = A.take(TE), K.r_dc = A.take(TE);
-    K.r_dq = A.take(TE), K.r_P = A.take((size_t)d.T * d.lkp * d.es), K.r_dSa = A.take((size_t)d.T * d.lkp * d.es), K.r_dkv = A.take(2 * SE);
+    K.r_dq = A.take(TE), K.r_P = A.take((size_t)d.T * d.lkp * d.es), K.r_dSa = A.take((size_t)d.T * d.lkp * d.es), K.r_dkv = dkv(2);
   }
   if (d.nc > 5) {
     K.s_dg = A.take(BE), K.s_da1 = A.take(BE), K.s_db1 = A.take(BE), K.s_dz = A.take(BE), K.s_dz1p = A.take(BE), K.s_dab = A.take(BE);
@@ -405,7 +426,7 @@ int acc32(const Ctx& c, const float* tmp, float* sink, int64_t nel) { return d2r
 int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
               const void* const* refs, const void* other, const LayerF& L, LayerB& K, const void* const* douts, const void* out_final,
               const float* dprobs, int64_t ldp, void* const* dx, void* d_other, Jobs& jobs) {
-  const int B = d.B, T = d.T, S = d.S, nc = d.nc, hid = d.hid, n = d.n;
+  const int B = d.B, T = d.T, nc = d.nc, hid = d.hid, n = d.n;
   const int64_t TEe = (int64_t)d.Lq * E, SEe = (int64_t)d.Lk * E, TEn = (int64_t)T * E, BEn = (int64_t)B * E;
   const d2r_linear_params* lp = p.lin;
   // --- K8 backward ---------------------------------------------------------------------------------------------------
@@ -457,6 +478,7 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     }
   }
   // from here on every dx[j] is initialised: the cells ACCUMULATE into it (GEMM epilogues, beta = 1)
+  // ===== part 1: every cell down to the gradient of its alignment core's output (d c) =================================================
   // --- GLAC ------------------------------------------------------------------------------------------------------------
   if (nc > 1) {
     const void* x = refs[1];
@@ -486,12 +508,6 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(dxg(c, T, E, E, K.g_dloc, E, lp[D2R_RL_GLAC_LOC].w, K.g_dsq, E));
     defer(jobs, T, E, E, K.g_dloc, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC]);
     TRY(d2r_sqdiff_bwd(c.dt, x, L.g_c, K.g_dsq, K.g_da, K.g_dc, TEn, c.st));
-    TRY(xat_bwd(c, d, L.g_q, L.g_kv, 2 * E, (const char*)L.g_kv + E * d.es, 2 * E, d.Lk, K.g_dc, L.g_lse, K.g_dq, K.g_dkv, 2 * E,
-                (char*)K.g_dkv + E * d.es, 2 * E, K.g_P, K.g_dSa, XSCALE));
-    TRY(dxg(c, T, E, E, K.g_dq, E, lp[D2R_RL_GLAC_Q].w, dxj, E, 1.f, K.g_da));  // += dq Wq + d(sqdiff)/dx
-    defer(jobs, T, E, E, K.g_dq, E, x, E, lp[D2R_RL_GLAC_Q]);
-    TRY(dxg(c, S, E, 2 * E, K.g_dkv, 2 * E, lp[D2R_RL_GLAC_KV].w, d_other, E, 1.f));
-    defer(jobs, S, 2 * E, E, K.g_dkv, 2 * E, other, E, lp[D2R_RL_GLAC_KV]);
     // global path
     TRY(dxg(c, B, E, E, K.g_dS, ldsg, lp[D2R_RL_GLAC_FC2].w, K.g_dl2g, E));
     defer(jobs, B, E, E, K.g_dS, ldsg, L.g_l2g, E, lp[D2R_RL_GLAC_FC2]);
@@ -505,6 +521,69 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     defer(jobs, B, E, E, K.g_dptp, E, x, TEe, lp[D2R_RL_GLAC_TPOOL]);
     TRY(dxg(c, B, E, E, K.g_dpip, E, lp[D2R_RL_GLAC_IPOOL].w, d_other, SEe, 1.f));
     defer(jobs, B, E, E, K.g_dpip, E, other, SEe, lp[D2R_RL_GLAC_IPOOL]);
+  }
+  // --- CMRC ------------------------------------------------------------------------------------------------------------
+  if (nc > 3) {
+    const void* x = refs[3];
+    TRY(dxg(c, T, E, E, K.de[3], E, lp[D2R_RL_CMRC_FC2].w, K.c_dfp, E, 0.f, nullptr, L.c_f, D2R_ACT_RELU));
+    defer(jobs, T, E, E, K.de[3], E, L.c_f, E, lp[D2R_RL_CMRC_FC2]);
+    TRY(dxg(c, T, E, E, K.c_dfp, E, lp[D2R_RL_CMRC_FC1].w, K.c_dmod, E));
+    defer(jobs, T, E, E, K.c_dfp, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1]);
+    TRY(d2r_muladd_bwd(c.dt, x, L.c_s, K.c_dmod, K.c_da, K.c_ds, TEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.c_ds, L.c_s, K.c_dsp, TEn, c.st));
+    TRY(dxg(c, T, E, E, K.c_dsp, E, lp[D2R_RL_CMRC_SCALE].w, K.c_dc, E));
+    defer(jobs, T, E, E, K.c_dsp, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE]);
+    TRY(dxg(c, T, E, E, K.c_dmod, E, lp[D2R_RL_CMRC_SHIFT].w, K.c_dc, E, 1.f));
+    defer(jobs, T, E, E, K.c_dmod, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT]);
+  }
+  // --- CRCMC -----------------------------------------------------------------------------------------------------------
+  if (nc > 4) {
+    TRY(xat_bwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, K.de[4], L.r_lse2, K.r_da, K.r_db, E, K.r_dKv, E, K.r_P2, K.r_dS2, 1.0f));
+    TRY(dxg(c, T, E, E, K.r_da, E, lp[D2R_RL_CRCMC_FC1].w, K.r_dQs, E, 0.f, K.de[4]));  // + residual Qs -> e4
+    defer(jobs, T, E, E, K.r_da, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1]);
+    TRY(dxg(c, T, E, E, K.r_db, E, lp[D2R_RL_CRCMC_FC2].w, K.r_dKs, E, 0.f, K.r_dKv));  // + Ks as the attention's value
+    defer(jobs, T, E, E, K.r_db, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2]);
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dQs, L.r_Qs, K.r_dQsp, TEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dKs, L.r_Ks, K.r_dKsp, TEn, c.st));
+    TRY(dxg(c, T, E, E, K.r_dQsp, E, lp[D2R_RL_CRCMC_MLP1].w, K.r_dc, E));
+    defer(jobs, T, E, E, K.r_dQsp, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1]);
+  }
+  // ===== ONE backward launch for the alignment cores: dS, P, dQ; then dV / dK of every sample and core (one grouped launch)
+  //       straight into the column blocks of the module-wide k|v gradient ======================================================
+  {
+    const void *qa[3], *ka[3], *va[3], *ga[3];
+    const float* la[3];
+    void *dqa[3], *dka[3], *dva[3], *pa[3], *dsa[3];
+    int ncore = 0;
+    auto core = [&](const void* q, const void* kv, const void* dO, const float* lse, void* dq, void* dkv, void* P, void* dS) {
+      qa[ncore] = q, ka[ncore] = kv, va[ncore] = (const char*)kv + E * d.es, ga[ncore] = dO, la[ncore] = lse;
+      dqa[ncore] = dq, dka[ncore] = dkv, dva[ncore] = (char*)dkv + E * d.es, pa[ncore] = P, dsa[ncore] = dS;
+      ++ncore;
+    };
+    if (nc > 1) core(L.g_q, L.g_kv, K.g_dc, L.g_lse, K.g_dq, K.g_dkv, K.g_P, K.g_dSa);
+    if (nc > 3) core(L.c_q, L.c_kv, K.c_dc, L.c_lse, K.c_dq, K.c_dkv, K.c_P, K.c_dSa);
+    if (nc > 4) core(L.r_q, L.r_kv, K.r_dc, L.r_lse, K.r_dq, K.r_dkv, K.r_P, K.r_dSa);
+    const int64_t skv = (int64_t)d.Lk * d.ldkv;
+    if (ncore)
+      TRY(d2r_xattn_bwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, skv, va, d.ldkv, skv, ga, E, TEe, nullptr, la, dqa, E, TEe, dka, d.ldkv, skv, dva,
+                              d.ldkv, skv, pa, dsa, d.lkp, B, d.Lq, d.Lk, E, XSCALE, c.st));
+  }
+  // ===== part 2: the query-side projections (the key / value side of every cell and layer is one product at the end of the module) ===
+  if (nc > 1) {
+    TRY(dxg(c, T, E, E, K.g_dq, E, lp[D2R_RL_GLAC_Q].w, dx[1], E, 1.f, K.g_da));  // += dq Wq + d(sqdiff)/dx
+    defer(jobs, T, E, E, K.g_dq, E, refs[1], E, lp[D2R_RL_GLAC_Q]);
+  }
+  if (nc > 3) {
+    TRY(d2r_add(c.dt, K.c_da, K.de[3], K.c_tmp, TEn, c.st));  // FiLM path + skip x -> e3
+    TRY(dxg(c, T, E, E, K.c_dq, E, lp[D2R_RL_CMRC_Q].w, dx[3], E, 1.f, K.c_tmp));
+    defer(jobs, T, E, E, K.c_dq, E, refs[3], E, lp[D2R_RL_CMRC_Q]);
+  }
+  if (nc > 4) {
+    const void* x = refs[4];
+    TRY(dxg(c, T, E, E, K.r_dq, E, lp[D2R_RL_CRCMC_Q].w, dx[4], E, 1.f));
+    defer(jobs, T, E, E, K.r_dq, E, x, E, lp[D2R_RL_CRCMC_Q]);
+    TRY(dxg(c, T, E, E, K.r_dKsp, E, lp[D2R_RL_CRCMC_MLP2].w, dx[4], E, 1.f));
+    defer(jobs, T, E, E, K.r_dKsp, E, x, E, lp[D2R_RL_CRCMC_MLP2]);
   }
   // --- IMRC ------------------------------------------------------------------------------------------------------------
   if (nc > 2) {
@@ -521,48 +600,6 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
                     dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
     TRY(dxg(c, T, E, 3 * E, dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
     TRY(dwg(c, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]));
-  }
-  // --- CMRC ------------------------------------------------------------------------------------------------------------
-  if (nc > 3) {
-    const void* x = refs[3];
-    TRY(dxg(c, T, E, E, K.de[3], E, lp[D2R_RL_CMRC_FC2].w, K.c_dfp, E, 0.f, nullptr, L.c_f, D2R_ACT_RELU));
-    defer(jobs, T, E, E, K.de[3], E, L.c_f, E, lp[D2R_RL_CMRC_FC2]);
-    TRY(dxg(c, T, E, E, K.c_dfp, E, lp[D2R_RL_CMRC_FC1].w, K.c_dmod, E));
-    defer(jobs, T, E, E, K.c_dfp, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1]);
-    TRY(d2r_muladd_bwd(c.dt, x, L.c_s, K.c_dmod, K.c_da, K.c_ds, TEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.c_ds, L.c_s, K.c_dsp, TEn, c.st));
-    TRY(dxg(c, T, E, E, K.c_dsp, E, lp[D2R_RL_CMRC_SCALE].w, K.c_dc, E));
-    defer(jobs, T, E, E, K.c_dsp, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE]);
-    TRY(dxg(c, T, E, E, K.c_dmod, E, lp[D2R_RL_CMRC_SHIFT].w, K.c_dc, E, 1.f));
-    defer(jobs, T, E, E, K.c_dmod, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT]);
-    TRY(xat_bwd(c, d, L.c_q, L.c_kv, 2 * E, (const char*)L.c_kv + E * d.es, 2 * E, d.Lk, K.c_dc, L.c_lse, K.c_dq, K.c_dkv, 2 * E,
-                (char*)K.c_dkv + E * d.es, 2 * E, K.c_P, K.c_dSa, XSCALE));
-    TRY(d2r_add(c.dt, K.c_da, K.de[3], K.c_tmp, TEn, c.st));  // FiLM path + skip x -> e3
-    TRY(dxg(c, T, E, E, K.c_dq, E, lp[D2R_RL_CMRC_Q].w, dx[3], E, 1.f, K.c_tmp));
-    defer(jobs, T, E, E, K.c_dq, E, x, E, lp[D2R_RL_CMRC_Q]);
-    TRY(dxg(c, S, E, 2 * E, K.c_dkv, 2 * E, lp[D2R_RL_CMRC_KV].w, d_other, E, 1.f));
-    defer(jobs, S, 2 * E, E, K.c_dkv, 2 * E, other, E, lp[D2R_RL_CMRC_KV]);
-  }
-  // --- CRCMC -----------------------------------------------------------------------------------------------------------
-  if (nc > 4) {
-    const void* x = refs[4];
-    TRY(xat_bwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, K.de[4], L.r_lse2, K.r_da, K.r_db, E, K.r_dKv, E, K.r_P2, K.r_dS2, 1.0f));
-    TRY(dxg(c, T, E, E, K.r_da, E, lp[D2R_RL_CRCMC_FC1].w, K.r_dQs, E, 0.f, K.de[4]));  // + residual Qs -> e4
-    defer(jobs, T, E, E, K.r_da, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1]);
-    TRY(dxg(c, T, E, E, K.r_db, E, lp[D2R_RL_CRCMC_FC2].w, K.r_dKs, E, 0.f, K.r_dKv));  // + Ks as the attention's value
-    defer(jobs, T, E, E, K.r_db, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2]);
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dQs, L.r_Qs, K.r_dQsp, TEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dKs, L.r_Ks, K.r_dKsp, TEn, c.st));
-    TRY(dxg(c, T, E, E, K.r_dQsp, E, lp[D2R_RL_CRCMC_MLP1].w, K.r_dc, E));
-    defer(jobs, T, E, E, K.r_dQsp, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1]);
-    TRY(xat_bwd(c, d, L.r_q, L.r_kv, 2 * E, (const char*)L.r_kv + E * d.es, 2 * E, d.Lk, K.r_dc, L.r_lse, K.r_dq, K.r_dkv, 2 * E,
-                (char*)K.r_dkv + E * d.es, 2 * E, K.r_P, K.r_dSa, XSCALE));
-    TRY(dxg(c, T, E, E, K.r_dq, E, lp[D2R_RL_CRCMC_Q].w, dx[4], E, 1.f));
-    defer(jobs, T, E, E, K.r_dq, E, x, E, lp[D2R_RL_CRCMC_Q]);
-    TRY(dxg(c, T, E, E, K.r_dKsp, E, lp[D2R_RL_CRCMC_MLP2].w, dx[4], E, 1.f));
-    defer(jobs, T, E, E, K.r_dKsp, E, x, E, lp[D2R_RL_CRCMC_MLP2]);
-    TRY(dxg(c, S, E, 2 * E, K.r_dkv, 2 * E, lp[D2R_RL_CRCMC_KV].w, d_other, E, 1.f));
-    defer(jobs, S, 2 * E, E, K.r_dkv, 2 * E, other, E, lp[D2R_RL_CRCMC_KV]);
   }
   // --- GESC ------------------------------------------------------------------------------------------------------------
   if (nc > 5) {
@@ -592,6 +629,7 @@ int check(const d2r_interaction_desc* D, const char* fn, bool bwd) {
   D2R_REQUIRE(d2r_interaction_supported(D->dtype, D->Lq, D->Lk, D->ncell, D->heads_imrc),
               "%s: unsupported (bf16, 2..6 cells, token counts within the fused attention cores' limits)", fn);
   D2R_REQUIRE(D->layers && D->own && D->other && D->out && D->paths && D->arena && d2r_aligned16(D->arena), "%s: null / unaligned pointer", fn);
+  D2R_REQUIRE(D->kv_all.w && D->kv_all.b && (!bwd || (D->kv_all.gw && D->kv_all.gb)), "%s: kv_all (the fused k|v projections of `other`) missing", fn);
   D2R_REQUIRE(D->arena_bytes >= d2r_interaction_arena_bytes(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc),
               "%s: arena too small", fn);
   if (bwd) {
@@ -616,7 +654,8 @@ extern "C" size_t d2r_interaction_arena_bytes(int B, int Lq, int Lk, int ncell, 
   const Dims d = make_dims(B, Lq, Lk, ncell, nlayer, hid_router, hid_imrc, 16);
   Arena A(nullptr);
   LayerF L;
-  for (int l = 0; l < nlayer; ++l) plan_fwd(A, d, l == nlayer - 1 ? 1 : ncell, l == 0, l == nlayer - 1, L);
+  A.take((size_t)d.S * d.ldkv * d.es);  // the module-wide k|v projection of `other`
+  for (int l = 0; l < nlayer; ++l) plan_fwd(A, d, l == nlayer - 1 ? 1 : ncell, l == 0, l == nlayer - 1, L, nullptr, l);
   return A.off + 256;
 }
 
@@ -624,7 +663,8 @@ extern "C" size_t d2r_interaction_bwd_scratch(int B, int Lq, int Lk, int ncell, 
   const Dims d = make_dims(B, Lq, Lk, ncell, nlayer, hid_router, hid_imrc, 16);
   Arena A(nullptr);
   LayerB K;
-  for (int l = 0; l < nlayer; ++l) plan_bwd(A, d, l == nlayer - 1 ? 1 : ncell, l == 0, l == nlayer - 1, K);
+  A.take((size_t)d.S * d.ldkv * d.es);  // gradient of the module-wide k|v projection
+  for (int l = 0; l < nlayer; ++l) plan_bwd(A, d, l == nlayer - 1 ? 1 : ncell, l == 0, l == nlayer - 1, K, nullptr, l);
   A.take((size_t)d.T * E * d.es);  // zero gradient standing in for a missing d_out
   return A.off + 256;
 }
@@ -635,13 +675,17 @@ extern "C" int d2r_interaction_fwd(const d2r_interaction_desc* D, void* stream) 
   const Ctx c{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
   Arena A(D->arena);
   const int nc = d.nc, total = nc * nc * (d.nl - 1) + nc;
+  // keys | values of every alignment cell of every layer: `other` is the same tensor in all of them
+  // (models/DynamicInteraction.py:95-102), so ONE projection with N = nkv * 1536 (13,824 at DR_step 3) serves the module
+  char* kvall = (char*)A.take((size_t)d.S * d.ldkv * d.es);
+  if (d.nkv) TRY(lin(c, d.S, (int)d.ldkv, E, D->other, E, D->kv_all, kvall));
   const void* refs[6];
   for (int j = 0; j < 6; ++j) refs[j] = D->own;
   LayerF L;
   for (int l = 0; l < d.nl; ++l) {
     const bool first = l == 0, final = l == d.nl - 1;
     const int P = final ? 1 : nc;
-    plan_fwd(A, d, P, first, final, L);
+    plan_fwd(A, d, P, first, final, L, kvall, l);
     TRY(layer_fwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, L, D->out, D->paths + (size_t)l * nc * nc, total));
     for (int j = 0; j < nc && !final; ++j) refs[j] = L.outs[j];
   }
@@ -657,8 +701,10 @@ extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) 
   std::vector<LayerF> F(nl);
   std::vector<LayerB> K(nl);
   Arena A(D->arena), Z(D->scratch);
-  for (int l = 0; l < nl; ++l) plan_fwd(A, d, l == nl - 1 ? 1 : nc, l == 0, l == nl - 1, F[l]);
-  for (int l = 0; l < nl; ++l) plan_bwd(Z, d, l == nl - 1 ? 1 : nc, l == 0, l == nl - 1, K[l]);
+  char* kvall = (char*)A.take((size_t)d.S * d.ldkv * d.es);
+  char* dkvall = (char*)Z.take((size_t)d.S * d.ldkv * d.es);
+  for (int l = 0; l < nl; ++l) plan_fwd(A, d, l == nl - 1 ? 1 : nc, l == 0, l == nl - 1, F[l], kvall, l);
+  for (int l = 0; l < nl; ++l) plan_bwd(Z, d, l == nl - 1 ? 1 : nc, l == 0, l == nl - 1, K[l], dkvall, l);
   void* zero_out = Z.take(TE);
   hipError_t e = hipMemsetAsync(D->d_other, 0, (size_t)d.S * E * d.es, (hipStream_t)stream);
   if (e == hipSuccess && !D->d_out) e = hipMemsetAsync(zero_out, 0, TE, (hipStream_t)stream);
@@ -677,6 +723,13 @@ extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) 
     }
     const float* dprobs = D->d_paths ? D->d_paths + (size_t)l * nc * nc : nullptr;
     TRY(layer_bwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, F[l], K[l], douts, D->out, dprobs, total, dx, D->d_other, jobs));
+  }
+  if (d.nkv) {
+    // every cell and layer wrote its dK | dV block: the gradient w.r.t. `other` through ALL key / value projections is one product
+    // with a 13,824-long reduction (fp32 accumulation inside the MFMAs instead of nine 16-bit read-modify-write passes over d_other),
+    // and their weight gradients one [13824, 768] product over the S rows
+    TRY(dxg(c, d.S, E, (int)d.ldkv, dkvall, d.ldkv, D->kv_all.w, D->d_other, E, 1.f));
+    defer(jobs, d.S, (int)d.ldkv, E, dkvall, d.ldkv, D->other, E, D->kv_all);
   }
   return flush_jobs(c, jobs);
 }

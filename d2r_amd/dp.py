@@ -198,6 +198,8 @@ class DataParallel:
                 self._count0[i] += 1
             self._bucket_of[id(p)] = (bi, be)
             p._d2r_ready_cb = self._ready
+        for leaf, unit in getattr(self.store, "subleaves", ()):  # views of a nested fusion group report for the enclosing unit
+            leaf._d2r_ready_cb = (lambda _t, unit=unit: self._ready(unit))
         # Autograd's post-accumulate hooks are registered LAZILY, from a forward pre-hook of the module that owns the tensor,
         # i.e. under the HIP stream that module runs on.  Registering a hook creates the tensor's AccumulateGrad node, and the
         # node accumulates on the stream that was current at its creation: registered here (launching stream), the in-place

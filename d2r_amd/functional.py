@@ -336,6 +336,42 @@ def stream_join(a, b):
     return _StreamJoin.apply(a, b)
 
 
+class _SplitColumns(torch.autograd.Function):
+    """[.., n*w] -> n contiguous [.., w] column blocks (one row-copy launch each way per block); the backward assembles the
+    blocks' gradients into ONE tensor (autograd would otherwise add n zero-padded full-size tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        x = x.contiguous()
+        W = x.shape[-1]
+        w = W // n
+        rows = x.numel() // W
+        es = x.element_size()
+        outs = []
+        for i in range(n):
+            o = torch.empty(*x.shape[:-1], w, dtype=x.dtype, device=x.device)
+            _lib.call("d2r_copy_rows", o.data_ptr(), w * es, x.data_ptr() + i * w * es, W * es, w * es, rows, _stream())
+            outs.append(o)
+        ctx.meta = (n, w, W, rows, es, x.shape, x.dtype)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, w, W, rows, es, shape, dtype = ctx.meta
+        g = torch.empty(shape, dtype=dtype, device=[t for t in gs if t is not None][0].device)
+        for i, gi in enumerate(gs):
+            if gi is None:
+                g[..., i * w:(i + 1) * w].zero_()
+                continue
+            gi = gi.contiguous()
+            _lib.call("d2r_copy_rows", g.data_ptr() + i * w * es, W * es, gi.data_ptr(), w * es, w * es, rows, _stream())
+        return g, None
+
+
+def split_columns(x, n):
+    return list(_SplitColumns.apply(x, n))
+
+
 def cast_ad(x, dtype):
     return x if x.dtype == dtype else _Cast.apply(x, dtype)
 
@@ -881,8 +917,16 @@ class InteractionBundle:
     running_var); weight leaves carry ._d2r_grad (fp32 sink) and, for the compute-dtype linears, ._d2r_lp (16-bit shadow);
     the router linears (R0, R2) are multiplied as fp32 masters."""
 
-    def __init__(self, layers, ncell, hid_router, heads_imrc, hid_imrc):
+    def __init__(self, layers, ncell, hid_router, heads_imrc, hid_imrc, kv_all=None):
+        """kv_all: (weight leaf, bias leaf) of the module-wide fused k|v projection of `other` (every alignment cell of every
+        layer, rows back to back in layer order: modules._InteractionBase._fusion_members)."""
         self.ncell, self.nlayer = ncell, len(layers)
+        if kv_all is None or getattr(kv_all[0], "_d2r_lp", None) is None or getattr(kv_all[0], "_d2r_grad", None) is None:
+            raise _lib.D2RError("InteractionBundle needs the fused k|v run of ParamStore (kv_all)")
+        nkv = ((ncell > 1) + (ncell > 3) + (ncell > 4)) * len(layers)
+        if tuple(kv_all[0].shape) != (nkv * 1536, 768):
+            raise _lib.D2RError(f"kv_all has shape {tuple(kv_all[0].shape)}, expected ({nkv * 1536}, 768)")
+        self.kv_all = kv_all
         self.tdtype = None  # the 16-bit compute dtype of the weight shadows (bf16 or fp16)
         self.hid_router, self.heads_imrc, self.hid_imrc = hid_router, heads_imrc, hid_imrc
         self.table = (_lib.RoutingLayerParams * self.nlayer)()
@@ -905,7 +949,8 @@ class InteractionBundle:
                     self.tdtype = wc.dtype
                 e = t.lin[_lib.RL[name]]
                 e.w, e.b, e.gw, e.gb = wc.data_ptr(), b.data_ptr(), w._d2r_grad.data_ptr(), b._d2r_grad.data_ptr()
-                self.params += [w, b]
+                if not name.endswith("_KV"):  # (views of the module-wide k|v run: kv_all reports for them)
+                    self.params += [w, b]
                 key += [e.w, e.gw]
             if "bn" in spec:
                 bw, bb, rm, rv = spec["bn"]
@@ -913,6 +958,8 @@ class InteractionBundle:
                 t.g_bn_weight, t.g_bn_bias = bw._d2r_grad.data_ptr(), bb._d2r_grad.data_ptr()
                 self.params += [bw, bb]
                 key += [t.bn_running_mean]
+        self.params += [kv_all[0], kv_all[1]]
+        key += [kv_all[0]._d2r_lp.data_ptr(), kv_all[0]._d2r_grad.data_ptr()]
         self.key = tuple(key)
         self.total_paths = ncell * ncell * (self.nlayer - 1) + ncell
 
@@ -933,6 +980,8 @@ class _Interaction(torch.autograd.Function):
         d.dtype, d.B, d.Lq, d.Lk, d.ncell, d.nlayer = _dt(own), B, Lq, Lk, bundle.ncell, bundle.nlayer
         d.hid_router, d.heads_imrc, d.hid_imrc, d.train = bundle.hid_router, bundle.heads_imrc, bundle.hid_imrc, int(train)
         d.layers = bundle.table
+        kw, kb = bundle.kv_all
+        d.kv_all.w, d.kv_all.b, d.kv_all.gw, d.kv_all.gb = kw._d2r_lp.data_ptr(), kb.data_ptr(), kw._d2r_grad.data_ptr(), kb._d2r_grad.data_ptr()
         out = torch.empty_like(own)
         paths = torch.empty(B, bundle.total_paths, dtype=torch.float32, device=own.device)
         nbytes = lib.d2r_interaction_arena_bytes(B, Lq, Lk, bundle.ncell, bundle.nlayer, bundle.hid_router, bundle.hid_imrc)

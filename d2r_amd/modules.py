@@ -169,7 +169,11 @@ class CrossModalAlignment(D2RModule):
     def _fusion_members(self):
         return [self.key, self.value]
 
-    def forward(self, own, other):
+    def forward(self, own, other, kv=None):
+        """kv: this alignment's [B, Lk, 1536] block of the module-wide k|v projection of `other` (computed once per module
+        forward by _InteractionBase), or None -> projected here."""
+        if kv is not None:
+            return F.attention_kv(self.query(own), kv, 1, 100.0 / math.sqrt(E))
         fz = self._fused_linear()
         if fz is not None:
             return F.attention_kv(self.query(own), fz(other, self.cdtype), 1, 100.0 / math.sqrt(E))
@@ -183,7 +187,7 @@ class RectifiedIdentityCell(D2RModule):
         super().__init__()
         self.router = Router(num_out_path, args.embed_size, args.hid_router)
 
-    def forward(self, x, other=None):
+    def forward(self, x, other=None, kv=None):
         return x
 
 
@@ -229,7 +233,7 @@ class IntraModelReasoningCell(D2RModule):
         self.router = Router(num_out_path, args.embed_size, args.hid_router)
         self.sa = SelfAttention(args.embed_size, args.hid_IMRC, args.num_head_IMRC)
 
-    def forward(self, x, other=None):
+    def forward(self, x, other=None, kv=None):
         return self.sa(x)
 
 
@@ -242,8 +246,8 @@ class Refinement(D2RModule):
         self.fc_1, self.fc_2 = Linear(embed_size, embed_size), Linear(embed_size, embed_size)
         self.CrossModalAlignment = CrossModalAlignment()
 
-    def forward(self, own, other):
-        c = self.CrossModalAlignment(own, other)
+    def forward(self, own, other, kv=None):
+        c = self.CrossModalAlignment(own, other, kv)
         mod = F.muladd(own, self.fc_scale(c, act=ACT_TANH), self.fc_shift(c))
         return self.fc_2(self.fc_1(mod, act=ACT_RELU), residual=own)
 
@@ -254,8 +258,8 @@ class CrossModalRefinementCell(D2RModule):
         self.refine = Refinement(args.embed_size)
         self.router = Router(num_out_path, args.embed_size, args.hid_router)
 
-    def forward(self, own, other):
-        return self.refine(own, other)
+    def forward(self, own, other, kv=None):
+        return self.refine(own, other, kv)
 
 
 class AttentionFiltration(D2RModule):
@@ -289,8 +293,8 @@ class GlobalLocalAlignmentCell(D2RModule):
         self.fc_sim_tranloc, self.fc_sim_tranglo = Linear(E, E), Linear(E, E)
         self.fc_1, self.fc_2 = Linear(E, E), Linear(E, E)
 
-    def forward(self, own, other):
-        c = self.CrossModalAlignment(own, other)
+    def forward(self, own, other, kv=None):
+        c = self.CrossModalAlignment(own, other, kv)
         sl = self.fc_1(F.l2norm(self.fc_sim_tranloc(F.sqdiff(own, c))))  # [B,Lq,768]
         dg = F.sqdiff(self.text_cls_pool(own), self.image_cls_pool(other))
         sg = self.fc_2(F.l2norm(self.fc_sim_tranglo(dg)))  # [B,768]
@@ -305,7 +309,7 @@ class GlobalEnhancedSemanticCell(D2RModule):
         self.text_cls_pool, self.image_cls_pool = BertPooler(), BertPooler()
         self.fc_mlp = _Sequential(**{"0": Linear(E, E), "2": Linear(E, E)})
 
-    def forward(self, own, other):
+    def forward(self, own, other, kv=None):
         a, b = self.text_cls_pool(own), self.image_cls_pool(other)
         z = self.fc_mlp[2](self.fc_mlp[0](F.add(a, b), act=ACT_TANH))
         return F.lerp_gate(F.softmax_rows(z), a, b)  # [B,768]
@@ -320,8 +324,8 @@ class ContextRichCrossModalCell(D2RModule):
         self.fc_mlp_2 = _Sequential(**{"0": Linear(E, E)})
         self.fc_1, self.fc_2 = Linear(E, E), Linear(E, E)
 
-    def forward(self, own, other):
-        c = self.CrossModalAlignment(own, other)
+    def forward(self, own, other, kv=None):
+        c = self.CrossModalAlignment(own, other, kv)
         Qs = self.fc_mlp_1[0](c, act=ACT_TANH)
         Ks = self.fc_mlp_2[0](own, act=ACT_TANH)
         return F.attention(self.fc_1(Qs), self.fc_2(Ks), Ks, 1, 1.0, residual=Qs)  # unscaled softmax(QK^T)
@@ -359,7 +363,8 @@ class _RoutingLayer(D2RModule):
     def _fusion_members(self):
         return {"r0": [c.router.mlp[0] for c in self._cells()], "r2": [c.router.mlp[2] for c in self._cells()]}
 
-    def _route(self, refs: List[torch.Tensor], other: torch.Tensor):
+    def _route(self, refs: List[torch.Tensor], other: torch.Tensor, kv=None):
+        """kv: {cell name: its [B, Lk, 1536] block of the module-wide k|v projection} or None."""
         cells = self._cells()
         r0, r2 = self._fused_linear("r0"), self._fused_linear("r2")
         if r0 is not None:  # the six routers as two GEMMs (fp32): hidden [B, 6*hid] then gates [B, 6*P]
@@ -377,7 +382,7 @@ class _RoutingLayer(D2RModule):
                 pooled = F.mean_pool(refs)  # [6,B,768] in one launch
                 gates = [c.router.gate_from_pooled(pooled[j]) for j, c in enumerate(cells)]
             G = torch.stack(gates, dim=1)  # fp32 [B,ncell,P]
-        embs = [c(refs[j], other) for j, c in enumerate(cells)]
+        embs = [c(refs[j], other, None if kv is None else kv.get(self.cell_names[j])) for j, c in enumerate(cells)]
         if self.num_out_path == 1:
             probs, outs = F.route_aggregate(G, *embs, refs=refs[1:])
         else:
@@ -388,14 +393,14 @@ class _RoutingLayer(D2RModule):
 class DynamicInteraction_Layer0(_RoutingLayer):
     first_layer = True
 
-    def forward(self, text, image):
+    def forward(self, text, image, kv=None):
         own, other = (image, text) if self.swap else (text, image)
-        return self._route([own] * self.num_cell, other)
+        return self._route([own] * self.num_cell, other, kv)
 
 
 class DynamicInteraction_Layer(_RoutingLayer):
-    def forward(self, ref_wrd, text, image):
-        return self._route(list(ref_wrd), text if self.swap else image)
+    def forward(self, ref_wrd, text, image, kv=None):
+        return self._route(list(ref_wrd), text if self.swap else image, kv)
 
 
 class Reversed_DynamicInteraction_Layer0(DynamicInteraction_Layer0):
@@ -422,6 +427,25 @@ class _InteractionBase(D2RModule):
         total_paths = num_cells ** 2 * (num_layer_routing - 1) + num_cells
         self.path_mapping = Linear(total_paths, path_hid)  # dead parameter (models/InteractionModule.py:19)
         self.bn = nn.BatchNorm1d(args.embed_size)  # dead module (:20)
+
+    KV_CELLS = ("glac", "cmrc", "crcmc")  # the cells that project `other` to keys and values (models/Cells.py:147,85,238)
+
+    def _kv_alignments(self):
+        """Every CrossModalAlignment of the module, layer by layer: they all project the SAME tensor (`other` is the raw
+        encoder output in every layer, models/DynamicInteraction.py:95-102)."""
+        out = []
+        for layer in [self.dynamic_itr_l0, *self.dynamic_itr_l1, self.dynamic_itr_l2]:
+            for name in self.KV_CELLS:
+                if name in layer.cell_names:
+                    cell = getattr(layer, name)
+                    out.append(cell.refine.CrossModalAlignment if name == "cmrc" else cell.CrossModalAlignment)
+        return out
+
+    def _fusion_members(self):
+        # one [n * 1536, 768] run of every key | value projection of `other` (all cells, all layers): ONE GEMM per branch
+        # (N = 13,824 at DR_step 3) instead of nine with N = 1,536, and one dX / dW product each in the backward pass
+        members = [lin for cma in self._kv_alignments() for lin in (cma.key, cma.value)]
+        return {"kv_all": members} if len(members) > 2 else {}
 
     def _bundle_spec(self):
         """{RL name: (weight leaf, bias leaf)} per routing layer for functional.InteractionBundle (None: not prepared)."""
@@ -477,9 +501,14 @@ class _InteractionBase(D2RModule):
             try:
                 spec = self._bundle_spec()
                 imrc = getattr(l0, "imrc", None)
+                kv = self._fused_linear("kv_all")
+                if kv is None:  # a single alignment in the whole module (two cells, DR_step 2 ...): its own k | v pair is the run
+                    cmas = self._kv_alignments()
+                    kv = cmas[0]._fused_linear() if cmas else None
                 b = F.InteractionBundle(spec, self.num_cells, l0.ric.router.mlp[0].out_features,
                                         imrc.sa.h if imrc is not None else 16,
-                                        imrc.sa.feed_forward_layer.fc1.out_features if imrc is not None else E)
+                                        imrc.sa.feed_forward_layer.fc1.out_features if imrc is not None else E,
+                                        kv_all=None if kv is None else (kv.weight, kv.bias))
             except (LookupError, F._lib.D2RError):
                 return None
             self._bundle_cache = b
@@ -496,12 +525,18 @@ class _InteractionBase(D2RModule):
                         layer.glac.SAF_module.bn.num_batches_tracked += 1
             return [out], F.matmul_nt(paths, paths)
         B = text.shape[0]
-        refs, p0 = self.dynamic_itr_l0(text, image)
+        layers = [self.dynamic_itr_l0, *self.dynamic_itr_l1, self.dynamic_itr_l2]
+        kvs = [None] * len(layers)
+        fz = self._fused_linear("kv_all")
+        if fz is not None:  # ONE k|v projection of `other` for every alignment cell of every layer (as the one-call path)
+            blocks = iter(F.split_columns(fz(other, self.cdtype), len(self._kv_alignments())))
+            kvs = [{name: next(blocks) for name in self.KV_CELLS if name in layer.cell_names} for layer in layers]
+        refs, p0 = self.dynamic_itr_l0(text, image, kvs[0])
         plist = [p0.reshape(B, -1)]
-        for layer in self.dynamic_itr_l1:
-            refs, pm = layer(refs, text, image)
+        for layer, kv in zip(self.dynamic_itr_l1, kvs[1:-1]):
+            refs, pm = layer(refs, text, image, kv)
             plist.append(pm.reshape(B, -1))
-        out, pf = self.dynamic_itr_l2(refs, text, image)
+        out, pf = self.dynamic_itr_l2(refs, text, image, kvs[-1])
         plist.append(pf.reshape(B, -1))
         paths = torch.cat(plist, dim=-1)  # fp32 [B, 36(DR-1)+6]; DR_step=2 (extension): cat(l0, l2)
         return out, F.matmul_nt(paths, paths)

@@ -81,11 +81,19 @@ class ParamStore:
                 raise ValueError(f"parameter {n!r} would fall into two optimiser groups")
         # same-input projections (q|k|v, k|v) are laid out back to back so one GEMM serves them (FusedLinear)
         fusions = list(model.fusion_groups()) if hasattr(model, "fusion_groups") else []
-        first_of, member_ids, tight = {}, set(), set()
-        for owner, key, linears in fusions:
+        # Groups may NEST (the k|v pair of one cross-modal alignment inside the module-wide run of every k|v projection of
+        # `other`): the largest group fixes the layout, a group wholly inside an earlier one only gets views of it.
+        fusions.sort(key=lambda f: -len(f[2]))
+        first_of, member_ids, tight, nested = {}, set(), set(), set()
+        for gi, (owner, key, linears) in enumerate(fusions):
             ws, bs = [l.weight for l in linears], [l.bias for l in linears]
+            ids = [id(t) for t in ws + bs]
+            if all(i in member_ids for i in ids):
+                nested.add(gi)
+                continue
+            assert not any(i in member_ids for i in ids), "fusion groups may nest but not overlap partially"
             first_of[id(ws[0])] = ws + bs
-            member_ids.update(id(t) for t in ws + bs)
+            member_ids.update(ids)
             tight.update(id(t) for t in ws[:-1] + bs[:-1])  # members are packed without alignment padding
         name_of = {id(p): n for n, p in live}
         ordered = []
@@ -126,8 +134,10 @@ class ParamStore:
         for n, p in self.dead:
             p.requires_grad_(False)
         # fused leaves: autograd leaves aliasing the members' storage; their gradient sinks alias the members' grads
-        self.fused = []  # (leaf tensor, offset, numel)
-        for owner, key, linears in fusions:
+        self.fused = []  # (leaf tensor, offset, numel, member ids): the top-level groups, i.e. the units of the flat buffer
+        self.subleaves = []  # (leaf of a nested group, the top-level leaf whose storage it views)
+        top = []  # (weight leaf, bias leaf, weight range, bias range) of the top-level groups
+        for gi, (owner, key, linears) in enumerate(fusions):
             ws, bs = [l.weight for l in linears], [l.bias for l in linears]
             K = ws[0].shape[1]
             nrows = sum(w.shape[0] for w in ws)
@@ -144,6 +154,11 @@ class ParamStore:
             if not isinstance(getattr(owner, "_fused", None), dict):
                 owner._fused = {}
             owner._fused[key] = FusedLinear(fw, fb, len(linears))
+            if gi in nested:  # readiness of its gradient is reported for the enclosing unit (d2r_amd.dp)
+                pw, pb = next((tw, tb) for tw, tb, (a, b), _ in top if a <= ow < b)
+                self.subleaves += [(fw, pw), (fb, pb)]
+                continue
+            top.append((fw, fb, (ow, ow + nrows * K), (ob, ob + nrows)))
             self.fused.append((fw, ow, nrows * K, [id(w) for w in ws]))
             self.fused.append((fb, ob, nrows, [id(b) for b in bs]))
         self.refresh_lowp()

@@ -431,6 +431,11 @@ typedef struct {
   const float* d_paths;      /* fp32 [B, total_paths] or NULL */
   void* d_own; void* d_other;             /* [B,Lq,768], [B,Lk,768]  OVERWRITTEN */
   void* scratch; size_t scratch_bytes;    /* >= d2r_interaction_bwd_scratch() */
+  /* The key | value projections of `other` of EVERY alignment cell (GLAC, CMRC, CRCMC) of EVERY layer as one fused linear: rows
+   * [k | v] of (layer 0: GLAC, CMRC, CRCMC), (layer 1: ...), ... i.e. [nkv * 1536, 768] with nkv = cells-with-alignment * nlayer
+   * (`other` is the same tensor in every layer, models/DynamicInteraction.py:95-102): one GEMM with N = 13,824 at DR_step 3 in
+   * the forward pass, one dX and one dW product in the backward pass.  The D2R_RL_*_KV entries of `layers` are then unused. */
+  d2r_linear_params kv_all;
 } d2r_interaction_desc;
 int d2r_interaction_supported(int dtype, int Lq, int Lk, int ncell, int heads_imrc);
 size_t d2r_interaction_arena_bytes(int B, int Lq, int Lk, int ncell, int nlayer, int hid_router, int hid_imrc);
