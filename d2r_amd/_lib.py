@@ -94,7 +94,7 @@ SIGNATURES = {
     "d2r_xattn_fwd_multi": (i32, [i32, i32, C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64,
                                   C.POINTER(vp), i64, i64, vp, C.POINTER(vp), i32, i32, i32, i32, f32, vp]),
     "d2r_xattn_bwd_multi": (i32, [i32, i32, C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64,
-                                  vp, C.POINTER(vp), C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64,
+                                  C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64, vp, C.POINTER(vp), C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64, C.POINTER(vp), i64, i64,
                                   C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i32, f32, vp]),
     "d2r_layernorm_fwd": (i32, [i32, vp, vp, vp, f32, i64, i32, vp, vp, vp, vp]),
     "d2r_layernorm_bwd_workspace": (sz, [i64, i32]),

@@ -48,6 +48,15 @@ extern "C" int d2r_xattn_supported(int dtype, int Lq, int Lk, int D) {
 int d2r_xattn2_fwd_try(int dtype, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
                        const void* const* v, int64_t ldv, int64_t svb, void* const* o, int64_t ldo, int64_t sob, const void* const* residual,
                        int64_t ldr, int64_t srb, const float* mask, float* const* lse, int B, int Lq, int Lk, float scale, hipStream_t st);  // xattn2.hip
+int d2r_xattn3_fwd_try(int dtype, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
+                       const void* const* v, int64_t ldv, int64_t svb, void* const* o, int64_t ldo, int64_t sob, const void* const* residual,
+                       int64_t ldr, int64_t srb, const float* mask, float* const* lse, int B, int Lq, int Lk, float scale, hipStream_t st);  // xattn3.hip
+int d2r_xattn3_bwd_try(int dtype, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
+                       const void* const* v, int64_t ldv, int64_t svb, const void* const* dO, int64_t ldg, int64_t sgb, const void* const* o,
+                       int64_t ldo, int64_t sob, const void* const* residual, int64_t ldr, int64_t srb, const float* mask,
+                       const float* const* lse, void* const* P, void* const* dS, int lkp, int B, int Lq, int Lk, float scale, hipStream_t st);
+int d2r_xattn3_dkv_try(int dtype, int ngroup, const void* const* W, const void* const* X, void* const* out, const int64_t* ldx, const int64_t* sxb,
+                       const int64_t* ldo, const int64_t* sob, const int* trans, int lkp, int B, int Lq, int Lk, hipStream_t st);
 int d2r_gemm_tn_batched16(int dtype, int M, int m_store, int N, int K, int64_t lda, int64_t sAb, int64_t ldb, int64_t sBb, int64_t ldc,
                           int64_t sCb, const void* const* A, const void* const* B, void* const* C, int ngroups, int nb, void* stream);  // gemm.hip
 
@@ -78,10 +87,28 @@ extern "C" int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, c
   return D2R_BY_DTYPE(dtype, mha_bwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, dO, ldg, sgb, mask, lse, dsum, dq, lddq, sdqb, dk, lddk,
                                          sdkb, dv, lddv, sdvb, B, H, Lq, Lk, head_dim, scale, p_drop, seed, stream));
 }
+static int x3_enabled() {
+  static const int on = getenv("D2R_XATTN3") ? atoi(getenv("D2R_XATTN3")) : 1;
+  return on;
+}
+static bool x3_offsets_fit(int64_t ld, int L) { return ld * (int64_t)L < (int64_t)1 << 31; }  // per-sample element offsets are 32-bit in xattn3
+
 extern "C" int d2r_xattn_fwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
                                    int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, void* const* h_o, int64_t ldo, int64_t sob,
                                    const void* const* h_residual, int64_t ldr, int64_t srb, const float* mask, float* const* h_lse, int B,
                                    int Lq, int Lk, int D, float scale, void* stream) {
+  if (x3_enabled() && Lk <= 256 && d2r_xattn_supported(dtype, Lq, Lk, D) && B >= 1 && ncore >= 1 && ncore <= 4 && h_q && h_k && h_v && h_o && h_lse &&
+      x3_offsets_fit(ldk, Lk) && x3_offsets_fit(ldv, Lk)) {
+    bool ok = true;
+    for (int c = 0; c < ncore; ++c)
+      ok &= h_lse[c] && h_q[c] && h_k[c] && h_v[c] && h_o[c] && d2r_aligned16(h_q[c]) && d2r_aligned16(h_k[c]) && d2r_aligned16(h_v[c]) &&
+            d2r_aligned16(h_o[c]) && (!h_residual || !h_residual[c] || d2r_aligned16(h_residual[c]));
+    ok &= ldq % 8 == 0 && sqb % 8 == 0 && ldk % 8 == 0 && skb % 8 == 0 && ldv % 8 == 0 && svb % 8 == 0 && ldo % 8 == 0 && sob % 8 == 0 &&
+          (!h_residual || (ldr % 8 == 0 && srb % 8 == 0));
+    if (ok && d2r_xattn3_fwd_try(dtype, ncore, h_q, ldq, sqb, h_k, ldk, skb, h_v, ldv, svb, h_o, ldo, sob, h_residual, ldr, srb, mask, h_lse, B, Lq, Lk,
+                                 scale, (hipStream_t)stream))
+      return d2r_check_launch("d2r_xattn_fwd(v3)");
+  }
   return D2R_BY_DTYPE(dtype, xattn_fwd_run(dtype, ncore, h_q, ldq, sqb, h_k, ldk, skb, h_v, ldv, svb, h_o, ldo, sob, h_residual, ldr, srb, mask,
                                            h_lse, B, Lq, Lk, D, scale, stream));
 }
@@ -101,14 +128,50 @@ extern "C" int d2r_xattn_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb,
 }
 extern "C" int d2r_xattn_bwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
                                    int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, const void* const* h_dO, int64_t ldg,
-                                   int64_t sgb, const float* mask, const float* const* h_lse, void* const* h_dq, int64_t lddq, int64_t sdqb,
+                                   int64_t sgb, const void* const* h_o, int64_t ldo, int64_t sob, const void* const* h_residual, int64_t ldr,
+                                   int64_t srb, const float* mask, const float* const* h_lse, void* const* h_dq, int64_t lddq, int64_t sdqb,
                                    void* const* h_dk, int64_t lddk, int64_t sdkb, void* const* h_dv, int64_t lddv, int64_t sdvb,
                                    void* const* h_P, void* const* h_dS, int lkp, int B, int Lq, int Lk, int D, float scale, void* stream) {
   D2R_REQUIRE(h_dk && h_dv && ncore >= 1 && ncore <= 4, "d2r_xattn_bwd_multi: null pointer array / 1..4 problems per launch");
+  bool x3 = x3_enabled() && Lk <= 256 && h_o && d2r_xattn_supported(dtype, Lq, Lk, D) && B >= 1 && h_q && h_k && h_v && h_dO && h_lse && h_dq &&
+            h_P && h_dS && lkp >= Lk && lkp % 8 == 0 && x3_offsets_fit(ldk, Lk) && x3_offsets_fit(ldv, Lk);
+  if (x3) {
+    for (int c = 0; c < ncore; ++c)
+      x3 &= h_lse[c] && h_q[c] && h_k[c] && h_v[c] && h_dO[c] && h_o[c] && h_dq[c] && h_P[c] && h_dS[c] && d2r_aligned16(h_q[c]) &&
+            d2r_aligned16(h_k[c]) && d2r_aligned16(h_v[c]) && d2r_aligned16(h_dO[c]) && d2r_aligned16(h_o[c]) && d2r_aligned16(h_dq[c]) &&
+            d2r_aligned16(h_P[c]) && d2r_aligned16(h_dS[c]) && (!h_residual || !h_residual[c] || d2r_aligned16(h_residual[c]));
+    x3 &= ldq % 8 == 0 && sqb % 8 == 0 && ldk % 8 == 0 && skb % 8 == 0 && ldv % 8 == 0 && svb % 8 == 0 && ldg % 8 == 0 && sgb % 8 == 0 &&
+          ldo % 8 == 0 && sob % 8 == 0 && lddq % 8 == 0 && sdqb % 8 == 0 && (!h_residual || (ldr % 8 == 0 && srb % 8 == 0)) &&
+          lddk % 4 == 0 && sdkb % 4 == 0 && lddv % 4 == 0 && sdvb % 4 == 0;
+    for (int c = 0; c < ncore && x3; ++c)
+      x3 &= h_dk[c] && h_dv[c] && !(reinterpret_cast<uintptr_t>(h_dk[c]) & 7u) && !(reinterpret_cast<uintptr_t>(h_dv[c]) & 7u);
+  }
+  // third generation: the query-side kernel leaves P and dS; dV = P^T dO, dK = dS^T Q AND dQ = dS K of every sample and problem
+  // are then ONE launch of the product kernel (it needs Lq, lkp <= 256)
+  if (x3 && Lq <= 256 && lkp <= 256) {
+    if (!d2r_xattn3_bwd_try(dtype, ncore, h_q, ldq, sqb, h_k, ldk, skb, h_v, ldv, svb, h_dO, ldg, sgb, h_o, ldo, sob, h_residual, ldr, srb, mask, h_lse,
+                            h_P, h_dS, lkp, B, Lq, Lk, scale, (hipStream_t)stream))
+      return d2r_fail(D2R_ERR_INVALID, "d2r_xattn_bwd_multi: the third-generation kernel refused an eligible shape");
+    if (int rc = d2r_check_launch("d2r_xattn_bwd(v3)")) return rc;
+    const void *W[12], *X[12];
+    void* O[12];
+    int64_t ldx[12], sxb_[12], ldo_[12], sob_[12];
+    int tr[12];
+    int ng = 0;
+    for (int c = 0; c < ncore; ++c) {
+      D2R_REQUIRE(h_dk[c] && h_dv[c], "d2r_xattn_bwd_multi: null dk / dv");
+      W[ng] = h_P[c], X[ng] = h_dO[c], O[ng] = h_dv[c], ldx[ng] = ldg, sxb_[ng] = sgb, ldo_[ng] = lddv, sob_[ng] = sdvb, tr[ng++] = 0;
+      W[ng] = h_dS[c], X[ng] = h_q[c], O[ng] = h_dk[c], ldx[ng] = ldq, sxb_[ng] = sqb, ldo_[ng] = lddk, sob_[ng] = sdkb, tr[ng++] = 0;
+      W[ng] = h_dS[c], X[ng] = h_k[c], O[ng] = h_dq[c], ldx[ng] = ldk, sxb_[ng] = skb, ldo_[ng] = lddq, sob_[ng] = sdqb, tr[ng++] = 1;
+    }
+    if (!d2r_xattn3_dkv_try(dtype, ng, W, X, O, ldx, sxb_, ldo_, sob_, tr, lkp, B, Lq, Lk, (hipStream_t)stream))
+      return d2r_fail(D2R_ERR_INVALID, "d2r_xattn_bwd_multi: the product kernel refused an eligible shape (alignment of dq / dk / dv?)");
+    return d2r_check_launch("d2r_xattn_bwd(products)");
+  }
   if (int rc = D2R_BY_DTYPE(dtype, xattn_bwd_run(dtype, ncore, h_q, ldq, sqb, h_k, ldk, skb, h_v, ldv, svb, h_dO, ldg, sgb, mask, h_lse, h_dq, lddq,
                                                  sdqb, h_P, h_dS, lkp, B, Lq, Lk, D, scale, stream)))
     return rc;
-  // key side: dV = P^T dO and dK = dS^T Q of every sample and problem in ONE grouped, batched launch.  The two outputs may have
+  // second generation: the key side as grouped, batched TN products of the LDS-DMA GEMM kernel.  The two outputs may have
   // different strides (k | v packed in one projection output have the same): one launch per distinct stride pair.
   const void* A[8];
   const void* Bm[8];

@@ -227,13 +227,13 @@ int xat_fwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t l
 }
 // backward: dq [T,E]; dk / dv written at (ptr, ld) with batch stride Lk*ld; P / dS: [B,Lq,lkp] scratch
 int xat_bwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t ldk, const void* v, int64_t ldv, int Lk, const void* dO,
-            const float* lse, void* dq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* P, void* dS, float scale) {
+            const void* o, const void* res, const float* lse, void* dq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* P, void* dS, float scale) {
   const int lkp = (Lk + 7) / 8 * 8;
-  const void *qa[1] = {q}, *ka[1] = {k}, *va[1] = {v}, *ga[1] = {dO};
+  const void *qa[1] = {q}, *ka[1] = {k}, *va[1] = {v}, *ga[1] = {dO}, *oa[1] = {o}, *ra[1] = {res};
   const float* la[1] = {lse};
   void *dqa[1] = {dq}, *dka[1] = {dk}, *dva[1] = {dv}, *pa[1] = {P}, *dsa[1] = {dS};
   return d2r_xattn_bwd_multi(c.dt, 1, qa, E, (int64_t)d.Lq * E, ka, ldk, (int64_t)Lk * ldk, va, ldv, (int64_t)Lk * ldv, ga, E, (int64_t)d.Lq * E,
-                             nullptr, la, dqa, E, (int64_t)d.Lq * E, dka, lddk, (int64_t)Lk * lddk, dva, lddv, (int64_t)Lk * lddv, pa, dsa, lkp,
+                             oa, E, (int64_t)d.Lq * E, res ? ra : nullptr, E, (int64_t)d.Lq * E, nullptr, la, dqa, E, (int64_t)d.Lq * E, dka, lddk, (int64_t)Lk * lddk, dva, lddv, (int64_t)Lk * lddv, pa, dsa, lkp,
                              d.B, d.Lq, Lk, E, scale, c.st);
 }
 
@@ -538,7 +538,7 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
   }
   // --- CRCMC -----------------------------------------------------------------------------------------------------------
   if (nc > 4) {
-    TRY(xat_bwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, K.de[4], L.r_lse2, K.r_da, K.r_db, E, K.r_dKv, E, K.r_P2, K.r_dS2, 1.0f));
+    TRY(xat_bwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, K.de[4], L.e4, L.r_Qs, L.r_lse2, K.r_da, K.r_db, E, K.r_dKv, E, K.r_P2, K.r_dS2, 1.0f));
     TRY(dxg(c, T, E, E, K.r_da, E, lp[D2R_RL_CRCMC_FC1].w, K.r_dQs, E, 0.f, K.de[4]));  // + residual Qs -> e4
     defer(jobs, T, E, E, K.r_da, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1]);
     TRY(dxg(c, T, E, E, K.r_db, E, lp[D2R_RL_CRCMC_FC2].w, K.r_dKs, E, 0.f, K.r_dKv));  // + Ks as the attention's value
@@ -551,21 +551,21 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
   // ===== ONE backward launch for the alignment cores: dS, P, dQ; then dV / dK of every sample and core (one grouped launch)
   //       straight into the column blocks of the module-wide k|v gradient ======================================================
   {
-    const void *qa[3], *ka[3], *va[3], *ga[3];
+    const void *qa[3], *ka[3], *va[3], *ga[3], *oa[3];
     const float* la[3];
     void *dqa[3], *dka[3], *dva[3], *pa[3], *dsa[3];
     int ncore = 0;
-    auto core = [&](const void* q, const void* kv, const void* dO, const float* lse, void* dq, void* dkv, void* P, void* dS) {
-      qa[ncore] = q, ka[ncore] = kv, va[ncore] = (const char*)kv + E * d.es, ga[ncore] = dO, la[ncore] = lse;
+    auto core = [&](const void* q, const void* kv, const void* o, const void* dO, const float* lse, void* dq, void* dkv, void* P, void* dS) {
+      qa[ncore] = q, ka[ncore] = kv, va[ncore] = (const char*)kv + E * d.es, ga[ncore] = dO, la[ncore] = lse, oa[ncore] = o;
       dqa[ncore] = dq, dka[ncore] = dkv, dva[ncore] = (char*)dkv + E * d.es, pa[ncore] = P, dsa[ncore] = dS;
       ++ncore;
     };
-    if (nc > 1) core(L.g_q, L.g_kv, K.g_dc, L.g_lse, K.g_dq, K.g_dkv, K.g_P, K.g_dSa);
-    if (nc > 3) core(L.c_q, L.c_kv, K.c_dc, L.c_lse, K.c_dq, K.c_dkv, K.c_P, K.c_dSa);
-    if (nc > 4) core(L.r_q, L.r_kv, K.r_dc, L.r_lse, K.r_dq, K.r_dkv, K.r_P, K.r_dSa);
+    if (nc > 1) core(L.g_q, L.g_kv, L.g_c, K.g_dc, L.g_lse, K.g_dq, K.g_dkv, K.g_P, K.g_dSa);
+    if (nc > 3) core(L.c_q, L.c_kv, L.c_c, K.c_dc, L.c_lse, K.c_dq, K.c_dkv, K.c_P, K.c_dSa);
+    if (nc > 4) core(L.r_q, L.r_kv, L.r_c, K.r_dc, L.r_lse, K.r_dq, K.r_dkv, K.r_P, K.r_dSa);
     const int64_t skv = (int64_t)d.Lk * d.ldkv;
     if (ncore)
-      TRY(d2r_xattn_bwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, skv, va, d.ldkv, skv, ga, E, TEe, nullptr, la, dqa, E, TEe, dka, d.ldkv, skv, dva,
+      TRY(d2r_xattn_bwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, skv, va, d.ldkv, skv, ga, E, TEe, oa, E, TEe, nullptr, E, TEe, nullptr, la, dqa, E, TEe, dka, d.ldkv, skv, dva,
                               d.ldkv, skv, pa, dsa, d.lkp, B, d.Lq, d.Lk, E, XSCALE, c.st));
   }
   // ===== part 2: the query-side projections (the key / value side of every cell and layer is one product at the end of the module) ===

@@ -610,7 +610,7 @@ def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device, p_drop=0.0)
     return o, P, seed
 
 
-def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None, p_drop=0.0, seed=0):
+def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None, p_drop=0.0, seed=0, o=None, res=None):
     """g: contiguous [B,Lq,E]; q/k/v and dq/dk/dv: (ptr, row stride, batch stride).  P: probabilities [B,H,Lq,Lkp]
     of the unfused forward, or the fp32 log-sum-exp [B,H,Lq] of the fused one."""
     B, Lq, Lk, E = geo
@@ -623,6 +623,7 @@ def _attn_bwd(g, q, k, v, P, dq, dk, dv, geo, H, scale, dtype, device, mask=None
         dS = torch.empty(B, Lq, Lkp, dtype=dtype, device=device)
         one = lambda x: _iparr([x])
         _lib.call("d2r_xattn_bwd_multi", dt, 1, one(q[0]), q[1], q[2], one(k[0]), k[1], k[2], one(v[0]), v[1], v[2], one(g.data_ptr()), E, Lq * E,
+                  None if o is None else one(o.data_ptr()), E, Lq * E, None if res is None else one(res.data_ptr()), E, Lq * E,
                   _ptr(mask), one(P.data_ptr()), one(dq[0]), dq[1], dq[2], one(dk[0]), dk[1], dk[2], one(dv[0]), dv[1], dv[2],
                   one(Pb.data_ptr()), one(dS.data_ptr()), Lkp, B, Lq, Lk, E, scale, _stream(),
                   meta=dict(group=tag, algo_bytes=float(2 * B * (2 * Lq + 2 * Lk) * E * 2)))
@@ -673,20 +674,20 @@ class _Attention(torch.autograd.Function):
         o, P, seed = _attn_fwd(_desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), geo, H, scale, mask, residual, q.dtype,
                                q.device, p_drop)
         ctx.drop = (p_drop, seed)
-        ctx.save_for_backward(q, k, v, P)
+        ctx.save_for_backward(q, k, v, P, o if H == 1 else None, residual if H == 1 else None)
         ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
         return o
 
     @staticmethod
     def backward(ctx, g):
-        q, k, v, P = ctx.saved_tensors
+        q, k, v, P, o, res = ctx.saved_tensors
         geo, H, scale, has_res = ctx.cfg
         E = geo[3]
         g = g.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         _attn_bwd(g, _desc(q, 0, E), _desc(k, 0, E), _desc(v, 0, E), P, _desc(dq, 0, E), _desc(dk, 0, E), _desc(dv, 0, E),
-                  geo, H, scale, q.dtype, q.device, ctx.mask, *ctx.drop)
+                  geo, H, scale, q.dtype, q.device, ctx.mask, *ctx.drop, o=o, res=res)
         return dq, dk, dv, None, None, None, (g if has_res else None), None
 
 
@@ -705,20 +706,20 @@ class _AttentionQKV(torch.autograd.Function):
         o, P, seed = _attn_fwd(_desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), geo, H, scale, mask, residual,
                                qkv.dtype, qkv.device, p_drop)
         ctx.drop = (p_drop, seed)
-        ctx.save_for_backward(qkv, P)
+        ctx.save_for_backward(qkv, P, o if H == 1 else None, residual if H == 1 else None)
         ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
         return o
 
     @staticmethod
     def backward(ctx, g):
-        qkv, P = ctx.saved_tensors
+        qkv, P, o, res = ctx.saved_tensors
         geo, H, scale, has_res = ctx.cfg
         E, E3 = geo[3], 3 * geo[3]
         g = g.contiguous()
         d = torch.empty_like(qkv)
         _attn_bwd(g, _desc(qkv, 0, E3), _desc(qkv, E, E3), _desc(qkv, 2 * E, E3), P, _desc(d, 0, E3), _desc(d, E, E3),
-                  _desc(d, 2 * E, E3), geo, H, scale, qkv.dtype, qkv.device, ctx.mask, *ctx.drop)
+                  _desc(d, 2 * E, E3), geo, H, scale, qkv.dtype, qkv.device, ctx.mask, *ctx.drop, o=o, res=res)
         return d, None, None, None, (g if has_res else None), None
 
 
@@ -735,20 +736,20 @@ class _AttentionKV(torch.autograd.Function):
         o, P, seed = _attn_fwd(_desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), geo, H, scale, mask, residual,
                                q.dtype, q.device, p_drop)
         ctx.drop = (p_drop, seed)
-        ctx.save_for_backward(q, kv, P)
+        ctx.save_for_backward(q, kv, P, o if H == 1 else None, residual if H == 1 else None)
         ctx.mask = mask
         ctx.cfg = (geo, H, scale, residual is not None)
         return o
 
     @staticmethod
     def backward(ctx, g):
-        q, kv, P = ctx.saved_tensors
+        q, kv, P, o, res = ctx.saved_tensors
         geo, H, scale, has_res = ctx.cfg
         E = geo[3]
         g = g.contiguous()
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         _attn_bwd(g, _desc(q, 0, E), _desc(kv, 0, 2 * E), _desc(kv, E, 2 * E), P, _desc(dq, 0, E), _desc(dkv, 0, 2 * E),
-                  _desc(dkv, E, 2 * E), geo, H, scale, q.dtype, q.device, ctx.mask, *ctx.drop)
+                  _desc(dkv, E, 2 * E), geo, H, scale, q.dtype, q.device, ctx.mask, *ctx.drop, o=o, res=res)
         return dq, dkv, None, None, None, (g if has_res else None), None
 
 

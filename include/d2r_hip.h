@@ -313,13 +313,17 @@ int d2r_xattn_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, const void
  * device pointers; h_residual may be NULL (or hold NULLs).  d2r_xattn_bwd_multi also runs the key-side products
  * dV = P^T dO and dK = dS^T Q of every sample and core (ONE grouped, batched launch of the LDS-DMA GEMM kernel when dk / dv
  * share their strides, e.g. the two halves of a packed k|v gradient), so it returns dq, dk and dv; h_P / h_dS are scratch
- * (16-bit [B, Lq, lkp] each, lkp = Lk rounded up to 8). */
+ * (16-bit [B, Lq, lkp] each, lkp = Lk rounded up to 8).  With h_o given (and Lk <= 256) the third-generation kernels run
+ * (xattn3.hip: queries split over the waves, K / V streamed once through a six-slot LDS-DMA ring, D = rowsum(dO o (O - residual))
+ * from the saved output); without it the second-generation query-side kernel, which recomputes D from P and dP. */
 int d2r_xattn_fwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
                         int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, void* const* h_o, int64_t ldo, int64_t sob,
                         const void* const* h_residual, int64_t ldr, int64_t srb, const float* mask, float* const* h_lse, int B, int Lq,
                         int Lk, int D, float scale, void* stream);
 int d2r_xattn_bwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
                         int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, const void* const* h_dO, int64_t ldg, int64_t sgb,
+                        const void* const* h_o /* the forward outputs (residual included), or NULL */, int64_t ldo, int64_t sob,
+                        const void* const* h_residual /* what the forward added, or NULL */, int64_t ldr, int64_t srb,
                         const float* mask, const float* const* h_lse, void* const* h_dq, int64_t lddq, int64_t sdqb, void* const* h_dk,
                         int64_t lddk, int64_t sdkb, void* const* h_dv, int64_t lddv, int64_t sdvb, void* const* h_P, void* const* h_dS,
                         int lkp, int B, int Lq, int Lk, int D, float scale, void* stream);

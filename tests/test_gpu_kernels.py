@@ -785,7 +785,7 @@ def test_xattn_multi_launch_matches_single_launches(gpu, lowp, cfg):
             sl = slice(c0, c0 + ncore_per_call)
             n = len(q[sl])
             _lib.call("d2r_xattn_bwd_multi", dt, n, arr(q[sl]), E, Lq * E, arr(kv[sl]), 2 * E, Lk * 2 * E, arr([t.data_ptr() + E * es for t in kv[sl]]),
-                      2 * E, Lk * 2 * E, arr(dO[sl]), E, Lq * E, None, arr(l1[sl]), arr(dq[sl]), E, Lq * E, arr(dkv[sl]), 2 * E, Lk * 2 * E,
+                      2 * E, Lk * 2 * E, arr(dO[sl]), E, Lq * E, arr(o1[sl]), E, Lq * E, None, E, Lq * E, None, arr(l1[sl]), arr(dq[sl]), E, Lq * E, arr(dkv[sl]), 2 * E, Lk * 2 * E,
                       arr([t.data_ptr() + E * es for t in dkv[sl]]), 2 * E, Lk * 2 * E, arr(P[sl]), arr(dS[sl]), lkp, B, Lq, Lk, E, scale, st)
         return dq, dkv, P, dS
 
