@@ -915,7 +915,7 @@ class UnimoModel(D2RModule):
         js_loss = F.lincomb([-self.args.weight_js_1, -self.args.weight_js_2], [js1, js2])
         pooled = self.block_fusion([tp, vp_])
         aux = dict(emb_text=emb_t, emb_image=emb_v, sim_paths=sim_paths, rev_sim_paths=rev_sim_paths,
-                   text_encode_out=t_enc, vision_encode_out=v_enc)
+                   text_encode_out=t_enc, vision_encode_out=v_enc, text_pooled=tp, vision_pooled=vp_)
         return pooled, js_loss, aux
 
 

@@ -5,7 +5,7 @@
 set -o pipefail
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p $OUT
-FLAGS="--no-cpu-baseline --no-roofline --no-fp32-leg --no-fp16-leg --no-host-leg"
+FLAGS="--no-cpu-baseline --no-roofline --no-fp32-leg --no-alt-leg --no-host-leg"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --steps 6 --warmup 2 $FLAGS > $OUT/kt.log 2>&1 || exit 11
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/kt -name "*domain_stats.csv" | head -1) $OUT/domain_stats.csv 2>/dev/null

@@ -213,8 +213,9 @@ def test_full_model_at_the_benchmark_shape_vs_oracle(gpu, dtype):
     init, against the pinned oracle in fp32 on the host.
 
     fp32 compute : |logits|, |loss| errors <= 2e-5; global gradient cosine >= 0.9999.
-    fp16 compute : |logits|, |loss| errors <= 1e-3 (the north star's tolerance); global gradient cosine >= 0.9, >= 0.999 for the
-                   parameters whose gradient does not pass through Block's signed square root.
+    fp16 compute : |logits|, |loss| errors <= 1e-3 (the north star's tolerance); global gradient cosine >= 0.93, >= 0.999 for the
+                   parameters whose gradient does not pass through Block's signed square root (the well-conditioned gradient check at
+                   this shape is test_benchmark_shape_gradients_with_fixed_cotangents_vs_oracle below).
     bf16 compute : the error is printed next to the emulated floor ("bf16 MFMA operands, fp32 everything else" applied
                    to the oracle, tests/lowp_emulation.py); asserted: <= max(1e-3, 3 x floor) for logits and loss, global
                    gradient cosine >= 0.9."""
@@ -276,7 +277,7 @@ def test_full_model_at_the_benchmark_shape_vs_oracle(gpu, dtype):
         # 24 encoder + 3 routing layers left in the pooled vectors; Block itself already runs in fp32 here.  Control experiment
         # (tests/probes/lowp_c2_parts.py): the fp32 path with ONLY Block's two input vectors rounded to fp16 gives 0.9987, rounded
         # to bf16 0.976.  The parameters that do not sit behind Block keep cos >= 0.999.
-        assert cos >= 0.9 and cos_side >= 0.999, (cos, cos_side)
+        assert cos >= 0.93 and cos_side >= 0.999, (cos, cos_side)
     else:
         from lowp_emulation import STORE_ALL
         fl, flog = lowp_floor(sd, cfg, batch, True, torch.bfloat16)
@@ -294,6 +295,95 @@ def test_full_model_at_the_benchmark_shape_vs_oracle(gpu, dtype):
         assert e_logit <= max(1e-3, 2.5 * s_logit), (e_logit, f_logit, s_logit)
         assert e_loss <= max(1e-3, 2.5 * s_loss), (e_loss, f_loss, s_loss)
         assert cos >= 0.8, cos
+
+
+_FIXED_COT_REF = {}
+
+
+def fixed_cotangent_gradients(gpu, dtype, lscale=None, per_tensor=None):
+    """One forward + backward of  S = <text_pooled, c1> + <vision_pooled, c2> + js_loss  at the C2 shape on the HIP path in `dtype`
+    and on the pinned oracle (fp32, host; cached) -> (objective error, global cosine, |g|/|ref|, cosine over the 24 encoder
+    layers, number of tensors)."""
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    from oracle import d2r_oracle as O
+    torch.manual_seed(2023)
+    layers, B, L = 12, 8, 128
+    tc = TextConfig(num_hidden_layers=layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vc = VisionConfig(num_hidden_layers=layers, image_size=224, patch_size=16)
+    model = M.UnimoModelF(default_args(), vc, tc)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = O.OracleConfig(text_layers=layers, vision_layers=layers, image_size=224, patch_size=16)
+    batch = O.synthetic_batch(cfg, B, L, seed=9, ragged=False)
+    ids, mask, tt, labels, images = batch
+    c1, c2 = _rnd(B, 768, seed=71, scale=0.05), _rnd(B, 768, seed=72, scale=0.05)
+    if not _FIXED_COT_REF:
+        torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+        osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+               for k, v in sd.items()}
+        _, _, oaux = O.forward(osd, cfg, ids, mask, tt, labels, images, train=True)
+        tp_o = O.cls_pool(osd, "model.text_pool", oaux["emb_text"])
+        vp_o = O.cls_pool(osd, "model.vision_pool", oaux["emb_image"])
+        s_o = (tp_o * c1).sum() + (vp_o * c2).sum() + oaux["js_loss"]
+        s_o.backward()
+        _FIXED_COT_REF.update(s=float(s_o), grads={k: v.grad.detach().double() for k, v in osd.items()
+                                                   if torch.is_tensor(v) and v.requires_grad and v.grad is not None})
+    ref_s, ref_g = _FIXED_COT_REF["s"], _FIXED_COT_REF["grads"]
+    model.to(gpu).set_compute_dtype(dtype).train()
+    ParamStore(model, dtype)
+    _, js, aux = model.model(input_ids=ids.to(gpu), attention_mask=mask.to(gpu), token_type_ids=tt.to(gpu), pixel_values=images.to(gpu))
+    s = (aux["text_pooled"] * c1.to(gpu)).sum() + (aux["vision_pooled"] * c2.to(gpu)).sum() + js
+    if lscale is None:
+        lscale = 1024.0 if dtype == torch.float16 else 1.0
+    (s * lscale).backward()
+    torch.cuda.synchronize()
+    dot = ng = nr = 0.0
+    enc = [0.0, 0.0, 0.0]
+    n = 0
+    for name, p in model.named_parameters():
+        ref = ref_g.get(name)
+        if ref is None or p.grad is None:
+            continue
+        got = p.grad.detach().double().cpu() / lscale
+        assert torch.isfinite(got).all(), name
+        d_, g_, r_ = float((got * ref).sum()), float(got.pow(2).sum()), float(ref.pow(2).sum())
+        dot, ng, nr, n = dot + d_, ng + g_, nr + r_, n + 1
+        if per_tensor is not None:
+            per_tensor[name] = (d_ / max((g_ * r_) ** 0.5, 1e-300), (g_ / max(r_, 1e-300)) ** 0.5, r_ ** 0.5)
+        if ".encoder." in name:
+            enc = [enc[0] + d_, enc[1] + g_, enc[2] + r_]
+    return (abs(float(s) - ref_s), dot / max((ng * nr) ** 0.5, 1e-300), (ng / nr) ** 0.5, enc[0] / max((enc[1] * enc[2]) ** 0.5, 1e-300), n)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["f32", "fp16", "bf16"])
+def test_benchmark_shape_gradients_with_fixed_cotangents_vs_oracle(gpu, dtype):
+    """The backward pass of everything in front of Block at the C2 shape, WITHOUT Block's signed square root in the way.
+
+    The end-to-end gradient of the loss is ill-conditioned in any 16-bit mode: Block (models/XModules.py:541-549) takes
+    sign(z) sqrt|z| of 1600 products that are spread around zero, derivative 0.5/sqrt|z|.  The oracle in fp64 arithmetic with
+    nothing but its weight matrices rounded ONCE to fp16 (no kernel of ours involved) already turns the gradient by cos 0.984 at
+    this shape, bf16 0.924 (profiles/precision_policy_c2_r03.log).  This test replaces the cotangent that Block hands back by
+    FIXED random vectors:
+        S = <text_pooled, c1> + <vision_pooled, c2> + js_loss
+    (text_pooled / vision_pooled are Block's two inputs, models/modeling_unimo.py:886-889), so every encoder layer, routing layer,
+    router, cross-attention core and pooler runs its backward at the benchmark shape on a better-conditioned objective (the same
+    weight rounding: fp16 0.9992, bf16 0.944; the oracle with every matmul operand and every stored activation rounded to fp16 in
+    the FORWARD pass only: 0.9948), against the pinned oracle in fp32 on the host.
+
+    Measured on MI355X: fp32 1.00000, fp16 0.971 (|g|/|ref| 1.22), bf16 0.931 (1.48).  tests/probes/fixed_cot_probe.py locates
+    what is left: the image branch and the last routing layer of the text branch keep cos >= 0.999 per cell; the loss sits in the
+    first two routing layers of the text branch behind the temperature-100 softmax over 197 image keys (cmrc.refine 0.82,
+    crcmc.CrossModalAlignment |g|/|ref| 1.5), whose near-ties make dS = P o (dP - D) a difference of rounded numbers — the
+    second-generation and the third-generation attention kernels give the same figures (0.9719 / 0.9709), and the loss scale does
+    not matter (2^10, 2^14, 2^18: identical to five digits, i.e. nothing underflows).  Bounds: 0.9999 / 0.96 / 0.9."""
+    e_s, cos, ratio, cos_enc, n = fixed_cotangent_gradients(gpu, dtype)
+    print(f"[C2-shape fixed cotangents {str(dtype)[6:]}] objective err {e_s:.2e}; gradient cosine over {n} tensors {cos:.5f}, |g|/|ref| "
+          f"{ratio:.4f}; the 24 encoder layers alone: cosine {cos_enc:.5f}")
+    assert n > 600, n  # every encoder / routing / pooler parameter took part
+    lim = {torch.float32: 0.9999, torch.float16: 0.96, torch.bfloat16: 0.9}[dtype]
+    assert cos >= lim and cos_enc >= lim, (cos, cos_enc)
+    assert abs(ratio - 1.0) <= {torch.float32: 1e-3, torch.float16: 0.3, torch.bfloat16: 0.6}[dtype]
 
 
 C4 = dict(name="C4", seq=256, image_size=384, patch=16, classes=7, dr=3, cells=6, lowp=torch.bfloat16)   # 577 image tokens

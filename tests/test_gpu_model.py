@@ -5,9 +5,11 @@ fp64 on the host.  All product calls go through the C ABI (d2r_amd.functional ->
 Tolerances (written here on purpose):
   fp32 compute  : outputs  |err| <= 30*noise_ref + 3e-5*scale ; gradients rel-L2 <= 30*noise_ref_k + 2e-3
   fp32 compute  : (gradients) rel <= 3*max_k noise_ref + 30*noise_ref_k + 2e-3
-  bf16 compute  : logits/loss |err| is REPORTED against the 1e-3 north star and asserted at 2e-2 on these
-                  adversarial seeded-weight fixtures (softmax(100 s/sqrt(768)) is near one-hot there: SURVEY.md
-                  section 7); test_bf16_default_init_logits checks the reference's own default init;
+  fp16 compute  : THE BENCHMARKED DTYPE (bench.py headline): logits / loss / js |err| <= 1e-3 (the north star's tolerance) on
+                  every fixture, embeddings cos >= 0.9995
+  bf16 compute  : the secondary 16-bit mode (reported beside the headline): logits/loss |err| asserted at 5e-3 (measured
+                  <= 2.3e-3; bf16 operand rounding ALONE, applied to the oracle, is 0.9e-3 on these fixtures:
+                  profiles/precision_policy_goldens_r03.log, so no bf16-operand mode can promise 1e-3);
                   embeddings <= 6e-2*scale; gradient norms rel <= 0.6 (median <= 0.06)
   routing decisions (open/closed paths, skip gates): EXACTLY equal in both modes.
 """
@@ -271,7 +273,7 @@ def test_full_model_vs_reference_golden(gpu, case, dtype):
             else:
                 assert e <= 8e-3 * max(s, 1.0), f"{case.name}/{k}: fp16 err {e:.3e} (scale {s:.2e})"
         elif k in ("loss", "logits", "js_loss"):
-            assert e <= 2e-2, f"{case.name}/{k}: bf16 err {e:.3e} (north-star target 1e-3)"
+            assert e <= 5e-3, f"{case.name}/{k}: bf16 err {e:.3e} (north-star target 1e-3 is met by the fp16 / fp32 modes)"
         elif k.startswith("emb_"):
             c = _cos(v, ref)
             assert c >= 0.98 and e <= 0.3 * max(s, 1.0), f"{case.name}/{k}: bf16 cos {c:.4f} err {e:.3e} (scale {s:.2e})"
