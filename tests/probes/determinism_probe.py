@@ -3,6 +3,10 @@ process, no collectives) and diffs the flat gradient buffers; with the two branc
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+import d2r_amd._lib as _L
+if os.environ.get("PROBE_LIB"):  # experiment: another build of the library (e.g. routing.hip with packed fp32 math)
+    _L.LIB_PATH = os.path.abspath(os.environ["PROBE_LIB"])
+    print("library under test:", _L.LIB_PATH, flush=True)
 from d2r_amd import modules as M
 from d2r_amd.config import TextConfig, VisionConfig, default_args
 from d2r_amd.params import ParamStore
