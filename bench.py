@@ -76,7 +76,10 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="(default at N > 1) overlap the bucketed grad all-reduce with backward")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce the whole gradient buffer after backward")
     ap.add_argument("--grad-comm", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the links")
-    ap.add_argument("--shard-optimizer", action="store_true", help="N > 1: reduce-scatter + all-gather, AdamW on 1/N of the buffer")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1: per bucket reduce-scatter of the gradients, AdamW on 1/N of the buffer, all-gather of the weights")
+    ap.add_argument("--algorithm", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
+                    help="N > 1: gradient reduction per bucket (RCCL all-reduce, or reduce-scatter + all-gather issued explicitly)")
     ap.add_argument("--bert-dropout", type=float, default=0.0,
                     help="hidden / attention-probability dropout of the BERT config (BASELINE.md section 3 benchmarks 0)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("D2R_BENCH_GRAPH", "0")),
@@ -198,8 +201,9 @@ def main():
         opt.enable_loss_scaling()  # scaled loss, device-side overflow check and step skip: all inside the timed step
     total_steps = args.warmup + args.steps + 8
     sched = LinearWarmupSchedule(opt, 0.01 * total_steps, total_steps)
-    dp = DataParallel(store, opt, model, overlap=not (args.no_overlap or args.shard_optimizer),  # (no effect at N = 1)
-                      grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32, shard_optimizer=args.shard_optimizer)
+    dp = DataParallel(store, opt, model, overlap=not args.no_overlap,  # (no effect at N = 1)
+                      grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32, shard_optimizer=args.shard_optimizer,
+                      algorithm=args.algorithm)
     dp.broadcast_parameters()
     batch = synthetic_batch(args.batch, args.seq, args.image_size, dev, seed=rank)
 

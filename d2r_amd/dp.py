@@ -11,6 +11,14 @@ on a side stream as soon as every parameter in it has its WHOLE gradient, overla
 the dW-sink callbacks of functional._Linear / the whole-layer C calls and from the deferred grouped launches; a
 parameter shared by several call sites reports several times per step, so the first overlapped step only counts the
 reports and later steps wait for the last one (DataParallel._ready).
+
+Reduction algorithm (``algorithm=``): "all_reduce" (RCCL picks ring / tree itself) or "reduce_scatter_all_gather" — the two
+phases written out per bucket (``ncclReduceScatter`` into the rank's stripe of the bucket, then ``ncclAllGather``), same bytes on
+every xGMI link, but each phase is a separate collective the overlap can place.  ``shard_optimizer=True`` keeps only the first
+phase for the gradients: every bucket is cut into `world` stripes, rank r receives the summed gradients of stripe r of EVERY
+bucket (so the scatter of a bucket can go out as soon as the bucket is complete, overlapped with the rest of backward), runs
+AdamW on its stripes (1/world of the optimiser's 30 bytes per parameter) and the updated fp32 weights are all-gathered bucket
+by bucket.
 """
 from __future__ import annotations
 
@@ -31,6 +39,9 @@ def init_process_group_from_env(backend: Optional[str] = None):
     if world == 1:
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # The host driver of this pool exposes dmabuf IPC only: with the legacy IPC mode RCCL's intra-node transport setup fails in
+    # hipIpcGetMemHandle ("invalid argument") before the first collective.  The launcher environment already exports 0; a
+    # process started some other way (mp.spawn from a notebook, a bare `python bench.py --gpus N`) gets the same default here.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # D2R_DIST_BACKEND=gloo: rehearsal of the multi-rank control flow with several ranks on ONE GPU (RCCL refuses that)
     backend = backend or os.environ.get("D2R_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -55,23 +66,57 @@ def shard_batch(batch, rank: int, world: int):
     return tuple(out)
 
 
-class FlatGradReducer:
-    """Bucketed SUM all-reduce of a flat fp32 gradient buffer.  ``comm_dtype=torch.bfloat16`` sends every bucket as bf16
-    (half the bytes on the xGMI links; the sum over ranks is then formed in bf16 by the collective, the fp32 buffer gets the
-    rounded result) - an optional trade of gradient precision for link time, off by default."""
+ALGORITHMS = ("all_reduce", "reduce_scatter_all_gather")
 
-    def __init__(self, flat_g: torch.Tensor, bucket_elems: int, group=None, comm_dtype: torch.dtype = torch.float32):
+
+def stripe_bounds(a: int, b: int, rank: int, world: int):
+    """Bucket [a, b) cut into `world` 16-byte-aligned stripes: -> (own stripe, body = all stripes, tail).  The tail (fewer than
+    4 * world elements, only where the bucket length is not a multiple of 4 * world) is all-reduced and owned by every rank."""
+    per = (b - a) // (4 * world) * 4
+    return (a + rank * per, a + (rank + 1) * per), (a, a + per * world), (a + per * world, b)
+
+
+class FlatGradReducer:
+    """Bucketed SUM reduction of a flat fp32 gradient buffer.
+
+    mode "all_reduce": one all-reduce per bucket.  mode "reduce_scatter_all_gather": reduce-scatter into the rank's stripe of
+    the bucket, then all-gather of the stripes (the explicit two-phase form of the same sum).  mode "reduce_scatter": the first
+    phase only — afterwards a rank holds the summed gradients of its stripe (and of the bucket's tail) and the rest of the
+    bucket is stale (sharded optimiser).  gloo has no reduce-scatter: the CPU rehearsal all-reduces the bucket instead, which
+    leaves a superset of the same values.
+    ``comm_dtype=torch.bfloat16`` sends every bucket as bf16 (half the bytes on the xGMI links; the sum over ranks is then formed
+    in bf16 by the collective, the fp32 buffer gets the rounded result) - an optional trade of gradient precision for link time,
+    off by default and only with mode "all_reduce"."""
+
+    def __init__(self, flat_g: torch.Tensor, bucket_elems: int, group=None, comm_dtype: torch.dtype = torch.float32,
+                 mode: str = "all_reduce"):
         self.flat_g, self.group = flat_g, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert mode in ("all_reduce", "reduce_scatter_all_gather", "reduce_scatter"), mode
+        self.mode = mode
         n = flat_g.numel()
+        if mode != "all_reduce":  # stripes of 4 * k elements: keep the buckets a multiple of 4 * world so that only the last has a tail
+            q = 4 * self.world
+            bucket_elems = max(q, bucket_elems // q * q)
         self.bounds = [(a, min(n, a + bucket_elems)) for a in range(0, n, bucket_elems)]
+        self.stripes = [stripe_bounds(a, b, self.rank, self.world) for a, b in self.bounds]
         self.handles = []
         self.comm_stream = torch.cuda.Stream() if flat_g.is_cuda else None
         assert comm_dtype in (torch.float32, torch.bfloat16)
+        if comm_dtype != torch.float32 and mode != "all_reduce":
+            raise ValueError("bf16 gradient buckets are implemented for algorithm='all_reduce' only")
         self.comm_dtype = comm_dtype
         # one staging buffer per bucket (buckets are in flight together when the reduction overlaps with backward)
         self.staging = ([torch.empty(b - a, dtype=comm_dtype, device=flat_g.device) for a, b in self.bounds]
                         if comm_dtype != torch.float32 else None)
         self._unstage = []
+        self._native_rs = None
+
+    def _has_reduce_scatter(self) -> bool:
+        if self._native_rs is None:
+            self._native_rs = dist.get_backend(self.group) != "gloo"
+        return self._native_rs
 
     def launch_bucket(self, i: int):
         a, b = self.bounds[i]
@@ -90,6 +135,21 @@ class FlatGradReducer:
             self._issue(i, view)
 
     def _issue(self, i: int, view: torch.Tensor):
+        if self.mode != "all_reduce":
+            (oa, ob), (ba, bb), (ta, tb) = self.stripes[i]
+            g = self.flat_g
+            if bb > ba:
+                if self._has_reduce_scatter():
+                    # in place: the output stripe aliases its own position inside the input (ncclReduceScatter's in-place form)
+                    self.handles.append(dist.reduce_scatter_tensor(g[oa:ob], g[ba:bb], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    if self.mode == "reduce_scatter_all_gather":
+                        # same communication stream, issued behind the scatter (collectives of one group execute in issue order)
+                        self.handles.append(dist.all_gather_into_tensor(g[ba:bb], g[oa:ob], group=self.group, async_op=True))
+                else:
+                    self.handles.append(dist.all_reduce(g[ba:bb], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if tb > ta:
+                self.handles.append(dist.all_reduce(g[ta:tb], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
         if self.staging is None:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
@@ -121,32 +181,38 @@ class FlatGradReducer:
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
+    def gather_stripes(self, buf: torch.Tensor):
+        """All ranks publish their stripes of `buf` (a tensor laid out like the gradient buffer: updated weights, optimiser
+        moments): afterwards every rank holds all of it.  Tails are identical on all ranks already."""
+        for (oa, ob), (ba, bb), _ in self.stripes:
+            if bb > ba:
+                dist.all_gather_into_tensor(buf[ba:bb], buf[oa:ob].clone(), group=self.group)
+
 
 class DataParallel:
     def __init__(self, store: ParamStore, optimizer, model: torch.nn.Module, bucket_mb: int = 128, group=None,
                  overlap: bool = False, bucket_elems: Optional[int] = None, grad_comm_dtype: torch.dtype = torch.float32,
-                 shard_optimizer: bool = False):
+                 shard_optimizer: bool = False, algorithm: str = "all_reduce"):
         """grad_comm_dtype: torch.bfloat16 sends the gradient buckets as bf16 (see FlatGradReducer).
-        shard_optimizer: reduce-scatter + all-gather instead of all-reduce - every rank receives the summed gradients of ITS
-        1/world slice of the flat buffer only, runs the fused AdamW on that slice (1/world of the optimiser's 30 bytes per
-        parameter of HBM traffic) and the updated fp32 weights are all-gathered; same bytes on the links as the all-reduce.
-        Not combined with overlap (the whole buffer is scattered after backward)."""
+        algorithm: "all_reduce" or "reduce_scatter_all_gather" (module docstring).
+        shard_optimizer: reduce-scatter of every bucket + AdamW on this rank's stripes + all-gather of the updated weights
+        (same bytes on the links as the all-reduce); works with overlap: a bucket's scatter goes out when the bucket is complete."""
         self.store, self.opt, self.model, self.group = store, optimizer, model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if algorithm not in ALGORITHMS:
+            raise ValueError(f"algorithm must be one of {ALGORITHMS}, got {algorithm!r}")
         self.shard_optimizer = bool(shard_optimizer) and self.world > 1
-        if self.shard_optimizer and overlap:
-            raise ValueError("shard_optimizer=True reduces the whole buffer after backward: use overlap=False")
-        self.reducer = (FlatGradReducer(store.flat_g, bucket_elems or bucket_mb * (1 << 20) // 4, group, grad_comm_dtype)
+        self.algorithm = "reduce_scatter_all_gather" if self.shard_optimizer else algorithm
+        mode = "reduce_scatter" if self.shard_optimizer else algorithm
+        self.reducer = (FlatGradReducer(store.flat_g, bucket_elems or bucket_mb * (1 << 20) // 4, group, grad_comm_dtype, mode=mode)
                         if self.world > 1 else None)
         optimizer.grad_scale = 1.0 / self.world
+        optimizer.dp_group = group
         if self.shard_optimizer:
-            n = store.flat_g.numel()
-            per = n // (self.world * 4) * 4  # 16-byte aligned slices; the tail (< 4 * world elements) is all-reduced and updated by all
-            self.shard = (self.rank * per, (self.rank + 1) * per)
-            self.shard_body = per * self.world
-            optimizer.element_range = self.shard if per > 0 else (0, 0)
-            optimizer.element_tail = (self.shard_body, n)
+            # this rank updates its stripe of every bucket, and every rank updates the (tiny) bucket tails
+            optimizer.element_ranges = [r for own, _, tail in self.reducer.stripes for r in (own, tail) if r[1] > r[0]]
+            optimizer.shard_gather = self.reducer.gather_stripes
         self.overlap = overlap and self.world > 1
         self._pending: List[int] = []
         self._bucket_of = {}
@@ -221,17 +287,45 @@ class DataParallel:
                 continue
             per_module.setdefault(mod, []).append(p)
         self._hook_handles = []
+        self._unhooked = {}  # module -> (fired box, its tensors): who has no autograd hook yet
         for mod, tensors in per_module.items():
-            def once(m, args, tensors=tensors, box=[]):
+            box = []
+
+            def once(m, args, tensors=tensors, box=box):
                 if not box:
                     box.append(True)
                     for t in tensors:
                         t.register_post_accumulate_grad_hook(self._ready)
+            self._unhooked[mod] = (box, tensors)
             self._hook_handles.append(mod.register_forward_pre_hook(once))
         self._expect = None  # id(parameter) -> reports per step, learnt in the first overlapped step
         from . import functional as F
         F.EARLY_FLUSH = True  # queued weight gradients of the routing modules go out before the encoders' backward
         self.begin_step()
+
+    def _close_hook_hole(self):
+        """End of the calibration step.  A tensor whose owning module never ran through ``__call__`` (every Linear inside a
+        whole-layer / whole-module C call, a child whose weight the parent reads directly) has no autograd hook: its gradient
+        arrives through the sinks only, which report by themselves.  Should autograd ever accumulate a piece into such a tensor
+        later, nobody would count it and its bucket could be reduced before the piece lands - so those tensors get a hook now
+        that turns the event into an error instead of an incomplete sum."""
+        names = {id(e[1]): e[0] for e in getattr(self.store, "entries", ()) if len(e) >= 2}
+        for mname, mod in (self.model.named_modules() if self.model is not None else ()):
+            for key, fz in (getattr(mod, "_fused", None) or {}).items():
+                names[id(fz.weight)], names[id(fz.bias)] = f"{mname}: fused group '{key}' weight", f"{mname}: fused group '{key}' bias"
+
+        def unexpected(t):
+            if getattr(t, "_d2r_anchor", False):
+                return  # the anchor input of a whole-layer / whole-module node: torch runs the hook although the node returned None for it
+            raise RuntimeError("data-parallel overlap: autograd accumulated a gradient into a parameter whose owner did not run in the "
+                               f"calibration step (its pieces were expected from the gradient sinks only): {names.get(id(t), '<fused leaf>')}; "
+                               "run with overlap=False")
+        for mod, (box, tensors) in self._unhooked.items():
+            if not box:
+                box.append(True)  # (the module's own pre-hook must not register the counting hook on top later)
+                for t in tensors:
+                    t.register_post_accumulate_grad_hook(unexpected)
+        self._unhooked = {}
 
     def begin_step(self):
         if self.overlap:
@@ -265,12 +359,10 @@ class DataParallel:
     def reduce_gradients(self):
         if self.world == 1:
             return
-        if self.shard_optimizer:
-            self._reduce_scatter()
-            return
         if self.overlap:
             if self._expect is None:
                 self._expect = dict(self._got)
+                self._close_hook_hole()
             # buckets whose parameters did not all report (unused this step, or the calibration step) are reduced now
             for i, done in enumerate(self._launched):
                 if not done:
@@ -280,28 +372,10 @@ class DataParallel:
         else:
             self.reducer.reduce_all()
 
-    # -- sharded optimiser: reduce-scatter the gradients, all-gather the updated weights ----------------------------------
-    def _reduce_scatter(self):
-        from . import functional as F
-        cur = torch.cuda.current_stream() if self.store.flat_g.is_cuda else None
-        if cur is not None:
-            for st in list(F._COMPUTE_STREAMS) + F.wgrad_streams():
-                cur.wait_stream(st)
-        g, (a, b), body = self.store.flat_g, self.shard, self.shard_body
-        if body > 0:
-            if dist.get_backend(self.group) == "gloo":  # gloo has no reduce-scatter: the rehearsal sums everything and keeps its slice
-                dist.all_reduce(g[:body], op=dist.ReduceOp.SUM, group=self.group)
-            else:
-                dist.reduce_scatter_tensor(g[a:b], g[:body], op=dist.ReduceOp.SUM, group=self.group)
-        if body < g.numel():
-            dist.all_reduce(g[body:], op=dist.ReduceOp.SUM, group=self.group)
-
     def gather_parameters(self):
-        """After optimizer.step() of a sharded step: every rank publishes its updated slice of the fp32 weights; the 16-bit
+        """After optimizer.step() of a sharded step: every rank publishes its updated stripes of the fp32 weights; the 16-bit
         shadow is re-derived locally."""
         if not self.shard_optimizer:
             return
-        w, (a, b), body = self.store.flat_w, self.shard, self.shard_body
-        if body > 0:
-            dist.all_gather_into_tensor(w[:body], w[a:b].clone(), group=self.group)
+        self.reducer.gather_stripes(self.store.flat_w)
         self.store.refresh_lowp()

@@ -199,9 +199,11 @@ class FusedAdamW:
         self.grad_scale = 1.0  # 1/world_size under data parallelism (gradients are SUM-reduced)
         self.loss_scale = 1.0  # > 1 after enable_loss_scaling() (fp16 compute dtype)
         self._scaler = None
-        # sharded data parallelism (d2r_amd.dp, shard_optimizer=True): this rank updates [element_range) and the common tail only
-        self.element_range = None
-        self.element_tail = None
+        # sharded data parallelism (d2r_amd.dp, shard_optimizer=True): this rank updates these element ranges only (its stripe of
+        # every gradient bucket + the bucket tails); shard_gather(buffer) publishes the stripes of a flat buffer to all ranks
+        self.element_ranges = None
+        self.shard_gather = None
+        self.dp_group = None
         names = {0: "other", 1: "text", 2: "vision", 3: "fc"}
         self.param_groups = []
         for g, (a, b) in sorted(store.group_ranges.items()):
@@ -248,12 +250,12 @@ class FusedAdamW:
         st = self.store
         sc["flag"].zero_()
         _lib.call("d2r_grad_nonfinite", st.flat_g.data_ptr(), st.n, sc["flag"].data_ptr(), _stream())
-        if self.element_range is not None:
-            # sharded optimiser: a rank holds the REDUCED gradients of its own slice only - an overflow in another rank's slice
+        if self.element_ranges is not None:
+            # sharded optimiser: a rank holds the REDUCED gradients of its own stripes only - an overflow in another rank's stripe
             # must drop the step here too, or the replicas diverge
             import torch.distributed as dist
-            if dist.is_initialized() and dist.get_world_size() > 1:
-                dist.all_reduce(sc["flag"], op=dist.ReduceOp.MAX)
+            if dist.is_initialized() and dist.get_world_size(self.dp_group) > 1:
+                dist.all_reduce(sc["flag"], op=dist.ReduceOp.MAX, group=self.dp_group)
 
     def _scaler_after_step(self):
         sc = self._scaler
@@ -263,14 +265,14 @@ class FusedAdamW:
 
     def _owned(self, rng):
         """The parts of a parameter group's element range this rank updates: all of it, or (sharded optimiser) its
-        intersections with the rank's slice and with the common tail."""
+        intersections with the rank's stripes and the bucket tails."""
         a, b = rng
         if b <= a:
             return []
-        if self.element_range is None:
+        if self.element_ranges is None:
             return [(a, b)]
         out = []
-        for lo, hi in (self.element_range, self.element_tail):
+        for lo, hi in self.element_ranges:
             x, y = max(a, lo), min(b, hi)
             if y > x:
                 out.append((x, y))
@@ -331,7 +333,15 @@ class FusedAdamW:
                       self.betas[0], self.betas[1], self.eps, pg["weight_decay"], None, _stream())
 
     def state_dict(self):
-        return dict(m=self.m, v=self.v, step=self.step_count, lrs=[pg["lr"] for pg in self.param_groups])
+        """Under the sharded optimiser a rank's moments are current for its own stripes only: they are all-gathered first (a
+        collective - every rank must call state_dict()), so that the result is the same complete state on every rank."""
+        if self.element_ranges is not None and self.shard_gather is not None:
+            self.shard_gather(self.m)
+            self.shard_gather(self.v)
+        sd = dict(m=self.m, v=self.v, step=self.step_count, lrs=[pg["lr"] for pg in self.param_groups], loss_scale=self.loss_scale)
+        if self._scaler is not None:
+            sd["scaler"] = dict(good=self._scaler["good"], skipped=self._scaler["skipped"])
+        return sd
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"])
@@ -339,6 +349,11 @@ class FusedAdamW:
         self.step_count = int(sd["step"])
         for pg, lr in zip(self.param_groups, sd["lrs"]):
             pg["lr"] = lr
+        if self._scaler is not None and "loss_scale" in sd:  # an fp16 run resumes at the scale it had reached, not at 2^14
+            self.loss_scale = float(sd["loss_scale"])
+            self._scaler["used_scale"] = self.loss_scale
+            self._scaler["good"] = int(sd.get("scaler", {}).get("good", 0))
+            self._scaler["skipped"] = int(sd.get("scaler", {}).get("skipped", 0))
 
 
 class LinearWarmupSchedule:

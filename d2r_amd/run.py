@@ -79,7 +79,11 @@ def build_parser():
     p.add_argument("--num_workers", default=4, type=int)
     p.add_argument("--dp_overlap", action="store_true")
     p.add_argument("--dp_grad_comm", default="f32", choices=["f32", "bf16"], help="dtype of the gradient buckets on the links")
-    p.add_argument("--dp_shard_optimizer", action="store_true", help="reduce-scatter + all-gather, AdamW on 1/world of the buffer")
+    p.add_argument("--dp_shard_optimizer", action="store_true",
+                   help="per bucket: reduce-scatter of the gradients, AdamW on this rank's stripe, all-gather of the updated weights "
+                        "(combines with --dp_overlap)")
+    p.add_argument("--dp_algorithm", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
+                   help="gradient reduction per bucket: RCCL's all-reduce, or its two phases issued explicitly")
     p.add_argument("--cleanup_output", action="store_true", help="reference behaviour: rmtree('./output') at the end")
     return p
 

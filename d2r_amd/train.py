@@ -90,9 +90,9 @@ class MSDTrainer:
             self.optimizer.enable_loss_scaling()
         shard = bool(getattr(self.args, "dp_shard_optimizer", False))
         self.dp = DataParallel(self.store, self.optimizer, self.model,
-                               overlap=bool(getattr(self.args, "dp_overlap", False)) and not shard,
+                               overlap=bool(getattr(self.args, "dp_overlap", False)),
                                grad_comm_dtype=torch.bfloat16 if getattr(self.args, "dp_grad_comm", "f32") == "bf16" else torch.float32,
-                               shard_optimizer=shard)
+                               shard_optimizer=shard, algorithm=getattr(self.args, "dp_algorithm", "all_reduce"))
         self.dp.broadcast_parameters()
         if self.train_data is not None:
             self.scheduler = LinearWarmupSchedule(self.optimizer, self.args.warmup_ratio * self.train_num_steps,
@@ -217,7 +217,9 @@ class MSDTrainer:
                 os.makedirs(self.args.save_path, exist_ok=True)
                 torch.save(self.model.state_dict(), self.args.save_path + "best_model.pth")
                 self.logger.info("Save best model at {}".format(self.args.save_path))
-            self.dp.barrier()  # nobody looks for / loads best_model.pth while rank 0 is still writing it
+        # unconditional: every rank reaches it whatever it decided above (a collective behind a per-rank floating-point
+        # comparison could pair with the next one); nobody looks for / loads best_model.pth while rank 0 is still writing it
+        self.dp.barrier()
         self.model.train()
         return result
 

@@ -24,7 +24,8 @@ full = (ids, torch.ones(4, 16, dtype=torch.long), torch.zeros(4, 16, dtype=torch
         torch.randn(4, 3, 64, 64, generator=g))
 batch = tuple(t.to(dev) for t in shard_batch(full, rank, world))
 results = {}
-MODES = {False: {}, True: dict(overlap=True), "shard": dict(shard_optimizer=True), "bf16": dict(grad_comm_dtype=torch.bfloat16)}
+MODES = {False: {}, True: dict(overlap=True), "shard": dict(shard_optimizer=True), "bf16": dict(grad_comm_dtype=torch.bfloat16),
+         "shard_overlap": dict(shard_optimizer=True, overlap=True), "rs_ag": dict(algorithm="reduce_scatter_all_gather", overlap=True)}
 for overlap, kw in MODES.items():
     torch.manual_seed(100 + rank)  # different replicas on purpose: broadcast_parameters must make them identical
     tc = TextConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
@@ -92,7 +93,9 @@ for step_i, (ga, gb) in enumerate(zip(results[False][2], results[True][2])):
         break
 upd = lambda key: (results[key][1] - w_start).double()
 cos_bf16 = float((upd("bf16") @ upd(False)) / (upd("bf16").norm() * upd(False).norm()))
-torch.save({"first_grad_divergence": first, "same_shard": bool(torch.equal(results[False][1], results["shard"][1])), "cos_bf16": cos_bf16, "losses_bf16": results["bf16"][0],
+torch.save({"first_grad_divergence": first, "same_shard": bool(torch.equal(results[False][1], results["shard"][1])),
+            "same_shard_overlap": bool(torch.equal(results[False][1], results["shard_overlap"][1])),
+            "same_rs_ag": bool(torch.equal(results[False][1], results["rs_ag"][1])), "cos_bf16": cos_bf16, "losses_bf16": results["bf16"][0],
             "losses": results[True][0], "losses_plain": results[False][0], "same_modes": same_modes, "same_ranks": same_ranks,
             "n_diff": int(ne.sum()), "bad": bad[:40], "n_bad": len(bad), "bounds": bounds,
             "bad_buckets": [(i, count(a, b)) for i, (a, b) in enumerate(bounds) if count(a, b)],

@@ -42,8 +42,9 @@ class _FakeStore:
 
 class _FakeOpt:
     grad_scale = 1.0
-    element_range = None
-    element_tail = None
+    element_ranges = None
+    shard_gather = None
+    dp_group = None
 
 
 def _overlap_readiness(rank):
@@ -100,29 +101,130 @@ def _bf16_buckets_and_sharded_optimizer(rank, world):
     class Store(_FakeStore):
         def __init__(self):
             super().__init__()
-            self.flat_g = torch.zeros(303)  # 303 = 2 x 148 + 7: slices of 148 elements and a tail of 7
+            self.flat_g = torch.zeros(303)
             self.flat_w = torch.arange(303, dtype=torch.float32).clone()
 
         def refresh_lowp(self):
             self.refreshed = True
 
+    # buckets of 128 elements (a multiple of 4 * world): [0,128) [128,256) [256,303); the last one: stripes of 20 and a tail of 7
     store, opt = Store(), _FakeOpt()
-    dp = DataParallel(store, opt, None, shard_optimizer=True)
-    assert dp.shard == (148 * rank, 148 * (rank + 1)) and dp.shard_body == 296
-    assert opt.element_range == dp.shard and opt.element_tail == (296, 303) and opt.grad_scale == 0.5
+    dp = DataParallel(store, opt, None, shard_optimizer=True, bucket_elems=130)
+    assert dp.reducer.bounds == [(0, 128), (128, 256), (256, 303)] and dp.reducer.mode == "reduce_scatter"
+    own = [(64 * rank, 64 * rank + 64), (128 + 64 * rank, 192 + 64 * rank), (256 + 20 * rank, 276 + 20 * rank)]
+    assert opt.element_ranges == own + [(296, 303)], opt.element_ranges
+    assert opt.grad_scale == 0.5 and opt.shard_gather is not None
     store.flat_g += (rank + 1)
     dp.reduce_gradients()
-    a, b = dp.shard
-    assert torch.equal(store.flat_g[a:b], torch.full((148,), 3.0)) and torch.equal(store.flat_g[296:], torch.full((7,), 3.0))
-    owned = FusedAdamW._owned(opt, (100, 300))  # a parameter group's range against this rank's slice and the tail
-    assert owned == ([(100, 148), (296, 300)] if rank == 0 else [(148, 296), (296, 300)]), owned
+    for a, b in opt.element_ranges:  # summed where this rank will update (gloo leaves the other stripes summed too; RCCL leaves them stale)
+        assert torch.equal(store.flat_g[a:b], torch.full((b - a,), 3.0))
+    owned = FusedAdamW._owned(opt, (100, 300))  # a parameter group's range against this rank's stripes and the tail
+    assert owned == ([(128, 192), (256, 276), (296, 300)] if rank == 0 else [(100, 128), (192, 256), (276, 296), (296, 300)]), owned
     assert FusedAdamW._owned(opt, (0, 0)) == []
     for x, y in FusedAdamW._owned(opt, (0, 303)):  # a stand-in optimiser: w -= grad_scale * g on the owned elements only
         store.flat_w[x:y] -= opt.grad_scale * store.flat_g[x:y]
     dp.gather_parameters()
     assert store.refreshed and torch.equal(store.flat_w, torch.arange(303, dtype=torch.float32) - 1.5)
+
+    # sharded AND overlapped: a bucket's scatter goes out at the last gradient piece of its last parameter
+    class Store96(Store):  # three 96-element parameters = three buckets of 96 (a multiple of 4 * world)
+        def __init__(self):
+            super().__init__()
+            self.flat_g = torch.zeros(288)
+
+        def units(self):
+            return [(p, 96 * i, 96) for i, p in enumerate(self.params)]
+
+    store, opt = Store96(), _FakeOpt()
+    dp = DataParallel(store, opt, None, shard_optimizer=True, overlap=True, bucket_elems=96)
+    assert len(dp.reducer.bounds) == 3
+    order = []
+    launch = dp.reducer.launch_bucket
+    dp.reducer.launch_bucket = lambda i: (order.append(i), launch(i))[1]
+    p0, p1, p2 = store.params
+    for it in range(2):
+        store.flat_g.zero_()
+        order.clear()
+        dp.begin_step()
+        for p, i in ((p2, 2), (p0, 0), (p1, 1)):
+            store.flat_g[96 * i:96 * i + 96] += (rank + 1) * (i + 1)
+            dp._ready(p)
+        dp.reduce_gradients()
+        assert order == ([0, 1, 2] if it == 0 else [2, 0, 1]), order
+        for a, b in opt.element_ranges:
+            assert torch.equal(store.flat_g[a:b], torch.full((b - a,), 3.0 * (a // 96 + 1))), (a, b)
+
+    # the explicit two-phase algorithm gives the all-reduce's result
+    flat = torch.arange(1003, dtype=torch.float32) * (rank + 1)
+    red = FlatGradReducer(flat, bucket_elems=256, mode="reduce_scatter_all_gather")
+    red.reduce_all()
+    assert torch.equal(flat, torch.arange(1003, dtype=torch.float32) * 3)
     with pytest.raises(ValueError):
-        DataParallel(Store(), _FakeOpt(), None, shard_optimizer=True, overlap=True)
+        DataParallel(Store(), _FakeOpt(), None, algorithm="ring")
+    with pytest.raises(ValueError):
+        FlatGradReducer(flat, 256, comm_dtype=torch.bfloat16, mode="reduce_scatter")
+
+    # FusedAdamW.state_dict() under sharding: the moments of the other ranks' stripes are gathered first
+    class PStore(Store):
+        group_ranges = {0: (0, 200), 3: (200, 303)}
+
+    store = PStore()
+    opt = FusedAdamW(store, lr=1e-3)
+    dp = DataParallel(store, opt, None, shard_optimizer=True, bucket_elems=128)
+    for a, b in opt.element_ranges:
+        opt.m[a:b] = 1.0 + rank
+        opt.v[a:b] = 10.0 + rank
+    sd = opt.state_dict()
+    want_m = torch.zeros(303)
+    for r in range(world):
+        for (oa, ob), _, _ in [__import__("d2r_amd.dp", fromlist=["stripe_bounds"]).stripe_bounds(a, b, r, world) for a, b in dp.reducer.bounds]:
+            want_m[oa:ob] = 1.0 + r
+    want_m[296:] = 1.0 + rank  # (the tail is every rank's own)
+    assert torch.equal(sd["m"], want_m) and sd["loss_scale"] == 1.0
+
+
+class _Child(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(100))
+
+
+class _Parent(torch.nn.Module):
+    """Uses child.weight directly: the child never runs through __call__, so its pre-hook never registers the counting hook."""
+
+    def __init__(self):
+        super().__init__()
+        self.child = _Child()
+        self.own = torch.nn.Parameter(torch.ones(100))
+
+    def forward(self, x):
+        return (x * self.child.weight * self.own).sum()
+
+
+def _hook_hole(rank):
+    """A parameter whose owner never ran in the calibration step and that autograd accumulates into anyway: without the hook
+    installed at the end of calibration its bucket could go out before the piece lands (nobody reports it) — it must raise."""
+    from d2r_amd.dp import DataParallel
+    model = _Parent()
+
+    class Store:
+        flat_g = torch.zeros(200)
+        dead = []
+
+        def units(self):
+            return [(model.own, 0, 100), (model.child.weight, 100, 100)]
+
+    model.own.grad = Store.flat_g[0:100].view(100)
+    model.child.weight.grad = Store.flat_g[100:200].view(100)
+    dp = DataParallel(Store(), _FakeOpt(), model, overlap=True, bucket_elems=100)
+    dp.begin_step()
+    model(torch.full((100,), float(rank + 1))).backward()   # calibration: child.weight's gradient arrives unreported
+    dp.reduce_gradients()                                  # ... and everything is reduced after backward: still the right sum
+    assert torch.equal(Store.flat_g, torch.full((200,), 3.0))
+    Store.flat_g.zero_()
+    dp.begin_step()
+    with pytest.raises(RuntimeError, match="owner did not run in the calibration step"):
+        model(torch.ones(100)).backward()
 
 
 def _worker(rank, world, port, q):
@@ -154,6 +256,7 @@ def _worker(rank, world, port, q):
             shard_batch((torch.zeros(3, 2),), rank, world)
         _overlap_readiness(rank)
         _bf16_buckets_and_sharded_optimizer(rank, world)
+        _hook_hole(rank)
     finally:
         dist.barrier()
         dist.destroy_process_group()

@@ -510,11 +510,13 @@ def test_default_init_gradients_vs_oracle(gpu, dtype):
         assert cos >= 0.99 and np.median(rel) <= 0.06 and np.quantile(rel, 0.9) <= 0.2, (cos, np.median(rel), np.quantile(rel, 0.9))
         assert min(part_cos.values()) >= 0.97, part_cos
     else:
-        # Measured on MI355X: global cosine 0.961, median per-tensor error 0.19.  The error is NOT spread evenly: every
+        # Measured on MI355X (round 3, after the key/value gradient of `other` became ONE K = 13,824 product with fp32 accumulation
+        # instead of a chain of 16-bit beta = 1 epilogues): global cosine 0.965, median per-tensor error 0.16, p90 0.39 (round 2's
+        # end: 0.90 / 0.35 / 0.70 asserted).  The error is NOT spread evenly: every
         # gradient that flows through Block's signed square root (models/XModules.py:547, derivative 0.5/sqrt|z|)
         # inherits the amplified bf16 error of the routing outputs (cos 0.91-0.97), while the parts that only see the
         # JS loss (extra self layers, cls poolers) and the fp32 head keep cos >= 0.995.
-        assert cos >= 0.9 and np.median(rel) <= 0.35 and np.quantile(rel, 0.9) <= 0.7, (cos, np.median(rel), np.quantile(rel, 0.9))
+        assert cos >= 0.93 and np.median(rel) <= 0.30 and np.quantile(rel, 0.9) <= 0.60, (cos, np.median(rel), np.quantile(rel, 0.9))
         for k in ("fc", "model.block_fusion.linear_out", "model.self_text.0", "model.self_vision.0",
                   "model.text_cls_pool.dense", "model.vision_cls_pool.dense"):
             assert part_cos[k] >= 0.99, (k, part_cos[k])

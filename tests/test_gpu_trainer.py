@@ -279,5 +279,7 @@ def test_data_parallel_two_ranks_on_one_gpu(gpu, tmp_path):
         assert res["same_ranks"], "replicas diverged"
         # reduce-scatter + all-gather with AdamW on this rank's slice: the same sums, the same update -> the same weights
         assert res["same_shard"], "the sharded optimiser (reduce-scatter / all-gather) changed the result"
+        assert res["same_shard_overlap"], "the sharded optimiser with overlapped per-bucket scatters changed the result"
+        assert res["same_rs_ag"], "algorithm='reduce_scatter_all_gather' changed the result"
         # gradient buckets sent as bf16: a rounded sum, same direction of the three-step update
         assert res["cos_bf16"] >= 0.9 and all(l == l for l in res["losses_bf16"]), (res["cos_bf16"], res["losses_bf16"])
