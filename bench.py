@@ -421,7 +421,12 @@ def main():
         per_family = {}
         VARIANT = {0: "tiles", 1: "ldsdma128x64", 2: "ldsdma128x128w4", 3: "ldsdma128x128w8", 11: "ldsdma128x64p", 12: "ldsdma128x128w4p",
                    13: "ldsdma128x128w8p", 20: "ldsdma128x128", 21: "tiles64x64", 30: "skinny"}
+        ATT = {10001: "xattn_core_fwd", 10002: "xattn_core_bwd"}  # recorded by d2r_xattn_{fwd,bwd}_multi in the step's real launch shape
+        att = {}
         for i in range(n_rec):
+            if fam[i] in ATT:
+                att.setdefault(ATT[fam[i]], []).append((ms[i], fl[i], by[i]))
+                continue
             var, base = fam[i] // 100, fam[i] % 100
             # one row per KERNEL (template instance family), e.g. gemm_bf16_TN_grouped_ldsdma128x128 = gemm_glds_kernel<__bf16, TN, 128, 2, 1, true>
             name = "gemm_%s_%s%s_%s" % (("f32", "bf16", "f16")[base // 8], ("NT", "NN", "TN")[(base % 8) // 2], "_grouped" if base & 1 else "",
@@ -433,6 +438,13 @@ def main():
             clip = lambda t: med if (t > 8.0 * med and t > 0.2) else t  # a host hiccup between the two events is not kernel time
             summ[name] = dict(calls=len(recs), ms=sum(max(clip(t) - bracket_ms, 0.25 * clip(t)) for t, _, _ in recs), flops=sum(f for _, f, _ in recs),
                               bytes=sum(b for _, _, b in recs), algo_bytes=0.0, outliers=sum(1 for t in ts if t > 8.0 * med and t > 0.2))
+        for name, recs in att.items():  # (three alignment cores per launch in the routing modules: replaces the op-by-op row)
+            ts = sorted(t for t, _, _ in recs)
+            med = ts[len(ts) // 2]
+            clip = lambda t: med if (t > 8.0 * med and t > 0.2) else t
+            nb = sum(b for _, _, b in recs)
+            summ[name] = dict(calls=len(recs), ms=sum(max(clip(t) - bracket_ms, 0.25 * clip(t)) for t, _, _ in recs), flops=sum(f for _, f, _ in recs),
+                              bytes=nb, algo_bytes=nb, lib_timed=True)
         kernels = []
         for name, r in summ.items():
             calls, t_s = r["calls"], r["ms"] * 1e-3
@@ -449,7 +461,7 @@ def main():
                 nbytes = r["algo_bytes"] if r["algo_bytes"] > 0 else r["bytes"]
                 if nbytes > 0:
                     ach = nbytes / t_s / 1e9
-                    if name.startswith("xattn_core") and name.endswith("bwd"):
+                    if name.startswith("xattn_core") and name.endswith("bwd") and not r.get("lib_timed"):
                         ach = 2 * summ.get("xattn_core_fwd", r)["algo_bytes"] / t_s / 1e9  # bwd = 2x fwd bytes
                     ent.update(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                frac=round(ach / HBM_PEAK_GBS, 4))

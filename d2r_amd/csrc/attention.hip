@@ -38,6 +38,7 @@
 #include <stdlib.h>
 
 #include "gemm_args.h"
+#include "ktimer.h"
 
 extern "C" int d2r_mha_supported(int dtype, int Lq, int Lk, int head_dim) {
   return d2r_is16(dtype) && (head_dim == 64 || head_dim == 48) && Lq >= 1 && Lk >= 1 && Lq <= 1024 && Lk <= 1024;
@@ -97,6 +98,10 @@ extern "C" int d2r_xattn_fwd_multi(int dtype, int ncore, const void* const* h_q,
                                    int64_t skb, const void* const* h_v, int64_t ldv, int64_t svb, void* const* h_o, int64_t ldo, int64_t sob,
                                    const void* const* h_residual, int64_t ldr, int64_t srb, const float* mask, float* const* h_lse, int B,
                                    int Lq, int Lk, int D, float scale, void* stream) {
+  // (measurement aid, armed by d2r_gemm_timer: the launch in its real configuration, algorithmic bytes = q, k, v read and o written
+  // once per problem)
+  D2RTimerScope timed((hipStream_t)stream, 10001, 4.0 * ncore * B * (double)Lq * Lk * D,
+                      (double)ncore * B * (2.0 * Lq + 2.0 * Lk) * D * (dtype == D2R_F32 ? 4 : 2));
   if (x3_enabled() && Lk <= 256 && d2r_xattn_supported(dtype, Lq, Lk, D) && B >= 1 && ncore >= 1 && ncore <= 4 && h_q && h_k && h_v && h_o && h_lse &&
       x3_offsets_fit(ldk, Lk) && x3_offsets_fit(ldv, Lk)) {
     bool ok = true;
@@ -133,6 +138,9 @@ extern "C" int d2r_xattn_bwd_multi(int dtype, int ncore, const void* const* h_q,
                                    void* const* h_dk, int64_t lddk, int64_t sdkb, void* const* h_dv, int64_t lddv, int64_t sdvb,
                                    void* const* h_P, void* const* h_dS, int lkp, int B, int Lq, int Lk, int D, float scale, void* stream) {
   D2R_REQUIRE(h_dk && h_dv && ncore >= 1 && ncore <= 4, "d2r_xattn_bwd_multi: null pointer array / 1..4 problems per launch");
+  // (measurement aid: the whole backward op = query-side launch + product launch; algorithmic bytes = 2 x the forward's)
+  D2RTimerScope timed((hipStream_t)stream, 10002, 10.0 * ncore * B * (double)Lq * Lk * D,
+                      2.0 * ncore * B * (2.0 * Lq + 2.0 * Lk) * D * (dtype == D2R_F32 ? 4 : 2));
   bool x3 = x3_enabled() && Lk <= 256 && h_o && d2r_xattn_supported(dtype, Lq, Lk, D) && B >= 1 && h_q && h_k && h_v && h_dO && h_lse && h_dq &&
             h_P && h_dS && lkp >= Lk && lkp % 8 == 0 && x3_offsets_fit(ldk, Lk) && x3_offsets_fit(ldv, Lk);
   if (x3) {

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "gemm_args.h"
+#include "ktimer.h"
 
 template <typename T, int LAYOUT, int BM, int BN, int WAVES_M, int WAVES_N, int NBUF, bool GROUPED = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, GemmGroup grp) {
@@ -416,27 +417,24 @@ static std::vector<GemmTimerRec> g_timer_recs;
 static std::mutex g_timer_mu;
 static volatile int g_timer_on = 0;
 
-struct GemmTimerScope {
-  bool armed = false;
+D2RTimerScope::D2RTimerScope(hipStream_t stream, int fam, double fl, double by) : family(fam), flops(fl), bytes(by), st(stream) {
+  if (fam < 10000) d2r_gemm_variant_tl = 0;
+  if (!g_timer_on) return;
+  if (hipEventCreate(&e0) != hipSuccess) return;
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
+  (void)hipEventRecord(e0, st);
+  armed = true;
+}
+D2RTimerScope::~D2RTimerScope() {
+  if (!armed) return;
   GemmTimerRec rec;
-  hipStream_t st;
-  GemmTimerScope(hipStream_t stream, int family, double flops, double bytes) : st(stream) {
-    d2r_gemm_variant_tl = 0;
-    if (!g_timer_on) return;
-    rec.family = family, rec.flops = flops, rec.bytes = bytes;
-    if (hipEventCreate(&rec.e0) != hipSuccess) return;
-    if (hipEventCreate(&rec.e1) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
-    (void)hipEventRecord(rec.e0, st);
-    armed = true;
-  }
-  ~GemmTimerScope() {
-    if (!armed) return;
-    rec.family += 100 * d2r_gemm_variant_tl;
-    (void)hipEventRecord(rec.e1, st);
-    std::lock_guard<std::mutex> lk(g_timer_mu);
-    g_timer_recs.push_back(rec);
-  }
-};
+  rec.family = family < 10000 ? family + 100 * d2r_gemm_variant_tl : family;
+  rec.flops = flops, rec.bytes = bytes, rec.e0 = e0, rec.e1 = e1;
+  (void)hipEventRecord(e1, st);
+  std::lock_guard<std::mutex> lk(g_timer_mu);
+  g_timer_recs.push_back(rec);
+}
+typedef D2RTimerScope GemmTimerScope;
 
 extern "C" int d2r_gemm_timer(int on) {
   std::lock_guard<std::mutex> lk(g_timer_mu);

@@ -307,24 +307,33 @@ class DataParallel:
         """End of the calibration step.  A tensor whose owning module never ran through ``__call__`` (every Linear inside a
         whole-layer / whole-module C call, a child whose weight the parent reads directly) has no autograd hook: its gradient
         arrives through the sinks only, which report by themselves.  Should autograd ever accumulate a piece into such a tensor
-        later, nobody would count it and its bucket could be reduced before the piece lands - so those tensors get a hook now
-        that turns the event into an error instead of an incomplete sum."""
+        later, nobody would count it and its bucket could be reduced before the piece lands - so those tensors (the ones that
+        reported from their sinks during calibration) get a hook now that turns the event into an error instead of an
+        incomplete sum."""
         names = {id(e[1]): e[0] for e in getattr(self.store, "entries", ()) if len(e) >= 2}
         for mname, mod in (self.model.named_modules() if self.model is not None else ()):
             for key, fz in (getattr(mod, "_fused", None) or {}).items():
                 names[id(fz.weight)], names[id(fz.bias)] = f"{mname}: fused group '{key}' weight", f"{mname}: fused group '{key}' bias"
 
-        def unexpected(t):
-            if getattr(t, "_d2r_anchor", False):
-                return  # the anchor input of a whole-layer / whole-module node: torch runs the hook although the node returned None for it
-            raise RuntimeError("data-parallel overlap: autograd accumulated a gradient into a parameter whose owner did not run in the "
-                               f"calibration step (its pieces were expected from the gradient sinks only): {names.get(id(t), '<fused leaf>')}; "
-                               "run with overlap=False")
+        def guard(name):
+            def unexpected(g):
+                # (torch runs tensor hooks also when a node handed back None for the tensor - the anchor input of a whole-layer call,
+                # a weight whose gradient the kernel wrote into the sink itself: nothing is accumulated then)
+                if g is not None:
+                    raise RuntimeError("data-parallel overlap: autograd accumulated a gradient into a parameter whose owner did not run in "
+                                       f"the calibration step (its pieces were expected from the gradient sinks only): {name}; run with "
+                                       "overlap=False")
+            return unexpected
+
         for mod, (box, tensors) in self._unhooked.items():
             if not box:
                 box.append(True)  # (the module's own pre-hook must not register the counting hook on top later)
                 for t in tensors:
-                    t.register_post_accumulate_grad_hook(unexpected)
+                    # A tensor nobody reported in the calibration step (e.g. the patch-embedding weight, used by its parent through
+                    # a plain autograd op) keeps its bucket's count above zero for ever: that bucket is reduced after backward,
+                    # which is safe.  The dangerous case is a tensor that DID report from its sinks: its bucket does go out early.
+                    if id(t) in self._expect:
+                        t.register_hook(guard(names.get(id(t), "<fused leaf>")))
         self._unhooked = {}
 
     def begin_step(self):

@@ -904,7 +904,6 @@ class _EncoderLayer(torch.autograd.Function):
 def encoder_layer(x, bundle: LayerBundle, mask=None, p_attn: float = 0.0, p_hidden: float = 0.0):
     """One whole BertLayer / CLIPEncoderLayer (16-bit compute dtype) as a single autograd node and a single C call each way;
     p_attn / p_hidden: training-time dropout on the attention probabilities / on the two dense outputs."""
-    bundle.params[0]._d2r_anchor = True  # handed to autograd only so that the node exists; its gradient slot always gets None
     return _EncoderLayer.apply(x, bundle.params[0], bundle, mask, float(p_attn), float(p_hidden))
 
 
@@ -1032,7 +1031,6 @@ class _Interaction(torch.autograd.Function):
 
 def interaction(own, other, bundle: InteractionBundle, train: bool):
     """One whole (Reversed_)InteractionModule as a single autograd node: -> (emb [B,Lq,768], paths fp32 [B,total_paths])."""
-    bundle.params[0]._d2r_anchor = True  # (see encoder_layer)
     return _Interaction.apply(own, other, bundle.params[0], bundle, bool(train))
 
 

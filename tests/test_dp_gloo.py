@@ -202,29 +202,40 @@ class _Parent(torch.nn.Module):
 
 
 def _hook_hole(rank):
-    """A parameter whose owner never ran in the calibration step and that autograd accumulates into anyway: without the hook
-    installed at the end of calibration its bucket could go out before the piece lands (nobody reports it) — it must raise."""
+    """A parameter whose owner never ran in the calibration step, whose gradient is reported by a sink (so its bucket goes out
+    early), and that autograd accumulates into as well: without the guard installed at the end of calibration the second piece
+    could land after the bucket's collective — it must raise.  A parameter nobody reports at all only keeps its bucket back."""
     from d2r_amd.dp import DataParallel
-    model = _Parent()
+    for sink_reports in (False, True):
+        model = _Parent()
 
-    class Store:
-        flat_g = torch.zeros(200)
-        dead = []
+        class Store:
+            flat_g = torch.zeros(200)
+            dead = []
 
-        def units(self):
-            return [(model.own, 0, 100), (model.child.weight, 100, 100)]
+            def units(self):
+                return [(model.own, 0, 100), (model.child.weight, 100, 100)]
 
-    model.own.grad = Store.flat_g[0:100].view(100)
-    model.child.weight.grad = Store.flat_g[100:200].view(100)
-    dp = DataParallel(Store(), _FakeOpt(), model, overlap=True, bucket_elems=100)
-    dp.begin_step()
-    model(torch.full((100,), float(rank + 1))).backward()   # calibration: child.weight's gradient arrives unreported
-    dp.reduce_gradients()                                  # ... and everything is reduced after backward: still the right sum
-    assert torch.equal(Store.flat_g, torch.full((200,), 3.0))
-    Store.flat_g.zero_()
-    dp.begin_step()
-    with pytest.raises(RuntimeError, match="owner did not run in the calibration step"):
-        model(torch.ones(100)).backward()
+        model.own.grad = Store.flat_g[0:100].view(100)
+        model.child.weight.grad = Store.flat_g[100:200].view(100)
+        dp = DataParallel(Store(), _FakeOpt(), model, overlap=True, bucket_elems=100)
+        dp.begin_step()
+        model(torch.full((100,), float(rank + 1))).backward()   # child.weight's autograd piece arrives without a counting hook
+        if sink_reports:
+            dp._ready(model.child.weight)                          # ... and a sink of some kernel reports the same tensor
+        dp.reduce_gradients()                                      # calibration: everything is reduced after backward
+        assert torch.equal(Store.flat_g, torch.full((200,), 3.0))
+        Store.flat_g.zero_()
+        dp.begin_step()
+        if not sink_reports:
+            model(torch.full((100,), float(rank + 1))).backward()  # never reported: its bucket simply waits for the end of backward
+            assert not dp._launched[1]
+            dp.reduce_gradients()
+            assert torch.equal(Store.flat_g, torch.full((200,), 3.0))
+            Store.flat_g.zero_()
+        else:
+            with pytest.raises(RuntimeError, match="owner did not run in the calibration step"):
+                model(torch.ones(100)).backward()
 
 
 def _worker(rank, world, port, q):
