@@ -51,6 +51,7 @@ struct X3Args {
   int B, Lq, Lk, lkp, ntile, ncore;
   float scale;
   int dbg;  // timing experiments only (D2R_X3_DBG): 1 = no DMA issue, 2 = no LDS fragment reads / MFMAs, 3 = DMA + waits only in phase V
+  unsigned long long* ts;  // timing experiments only: cycle stamps of block 0's waves (forward kernel), [4 waves][64]
 };
 
 template <typename P>
@@ -63,6 +64,10 @@ __device__ __forceinline__ P x3_pick(P const (&arr)[X3_MAXCORE], int core) {  //
 
 // position of 16-byte chunk c (0..95) of ring row r: XOR inside aligned groups of 16 chunks (256 B = one bank row)
 __device__ __forceinline__ int swz(int c, int r) { return (c & ~15) | ((c & 15) ^ (r & 15)); }
+// ... of a chunk that is read with ds_read_b64_tr_b16 (forward kernel, V chunks): a 32-lane group of that read covers rows 0-7 or 8-15,
+// 32 contiguous bytes (two chunks) of each: the XOR acts on chunk PAIRS, or rows r and r ^ 1 would land on the same banks (measured:
+// SQ_LDS_BANK_CONFLICT = a third of the forward kernel's LDS cycles with the row swizzle above)
+__device__ __forceinline__ int swz_tr(int c, int r) { return (c & ~15) | ((c & 15) ^ ((r & 7) << 1)); }
 
 __device__ __forceinline__ float g4max(float v) {  // over the 4 lane groups holding one MFMA column
   v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -137,7 +142,7 @@ __device__ __forceinline__ RingOffs ring_offs(int fr, int fq, int tq, int tp) {
   for (int m = 0; m < 4; ++m) r.row[m] = fr * ROWB + (((m * 4 + fq) ^ (fr & 15)) << 4);
   const int vrow = fq * 4 + tq;
 #pragma unroll
-  for (int m = 0; m < 8; ++m) r.tr[m] = vrow * ROWB + (((m * 2 + (tp >> 1)) ^ (vrow & 15)) << 4) + (tp & 1) * 8;
+  for (int m = 0; m < 8; ++m) r.tr[m] = vrow * ROWB + (((m * 2 + (tp >> 1)) ^ ((vrow & 7) << 1)) << 4) + (tp & 1) * 8;
   return r;
 }
 
@@ -160,6 +165,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const E* Vg = x3_pick(a.v, core) + b * a.svb;
   float* Ms = reinterpret_cast<float*>(smem + NS * CB);
   const int nkc = (a.Lk + CH - 1) / CH, G = 2 * nkc;
+  unsigned long long tsv[40];
+  const bool stamping = a.ts != nullptr && blockIdx.x == 0;
+#define X3_STAMP(i) do { if (stamping) tsv[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  X3_STAMP(0);
 
   for (int key = tid; key < LKMAX; key += 256) Ms[key] = key < a.Lk ? (a.mask ? a.mask[(int64_t)b * a.Lk + key] : 0.f) : -INFINITY;
   // this wave's 16 query rows as B fragments of the score product: lane (fr, fq) holds Q[q0 + fr][32 kk + 8 fq .. + 7]
@@ -171,13 +180,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const E8*>(qp + kk * 32);
   }
   // per-lane source of this wave's six 1-KiB pieces of a chunk image [16 rows][1536 B]
-  int prow[6], pcol[6];
+  int prow[6], pcol[6], pcolv[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int o = (wave * 6 + i) * 1024 + lane * 16;
     const int row = o / ROWB, cp = (o - row * ROWB) >> 4;
     prow[i] = row;
     pcol[i] = swz(cp, row) * 8;  // the swizzle is an involution: image position cp of row `row` holds source chunk swz(cp,row)
+    pcolv[i] = swz_tr(cp, row) * 8;  // V chunks: the image the transposing reads want
   }
   // pieces [i0, i1) of chunk g  (issuing the six pieces of a chunk two at a time between the MFMA batches of a step measured SLOWER
   // than all six right behind the barrier: 48 vs 40 us for three problems of the text branch)
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 6; ++i) {
       if (i < i0 || i >= i1) continue;
       const int key = min(key0 + prow[i], a.Lk - 1);  // clamped: masked (-inf) scores / zero probabilities for keys >= Lk
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (key * ld + pcol[i])),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (key * ld + (isv ? pcolv[i] : pcol[i]))),
                                        (__attribute__((address_space(3))) void*)(base + (wave * 6 + i) * 1024), 16, 0, 0);
     }
   };
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned sbase = lds_addr(smem), mbase = lds_addr(Ms) + fq * 16;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q fragments and mask values have landed: only DMA pieces in the queue from here
   __syncthreads();
+  X3_STAMP(1);
 #pragma unroll
   for (int g = 0; g < NS - 1; ++g)
     if (g < G) issue(g);
@@ -245,6 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < 8; ++j) acc = H16<E>::mfma32(kf[0][j], qf[16 + j], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[t][r] = acc[r] * a.scale + m4[r];
+      X3_STAMP(2 + t);
     }
   }
   // ---- softmax over the keys of query fr: in-lane over tiles and rows, then across the four lane groups ---------------------------
@@ -272,6 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f32x4 o[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  X3_STAMP(18);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (t < nkc) {
@@ -301,9 +314,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < NB; ++i) o[bq * NB + i] = H16<E>::mfma16(vf[bq & 1][i], pf[t], o[bq * NB + i]);
         __builtin_amdgcn_sched_barrier(0);
       }
+      X3_STAMP(19 + t);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave left the ring: it now stages the output tile
+  X3_STAMP(35);
   // ---- epilogue: o[dt][r] = O[q = fr][d = dt*16 + fq*4 + r] -> this wave's 16 LDS rows -> whole-row global stores -------------------
   constexpr int LDO = XE + 8;
   E* Os = reinterpret_cast<E*>(smem) + wave * QW * LDO;
@@ -331,6 +346,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     st_pack<E, 8>(Og + (int64_t)qrow * a.ldo + ch * 8, v);
   }
   if (fq == 0 && q0 + fr < a.Lq) x3_pick(a.lse, core)[(int64_t)b * a.Lq + q0 + fr] = mx + logf(sum);
+  if (stamping) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tsv[36] = __builtin_amdgcn_s_memtime();
+    if (lane == 0)
+      for (int i = 0; i < 37; ++i) a.ts[wave * 64 + i] = tsv[i];
+  }
+#undef X3_STAMP
 }
 
 // ================================================================================================================================
@@ -609,6 +631,8 @@ __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
   }
 }
 
+unsigned long long* g_x3_stamps = nullptr;  // tests/probes/xattn3_probe.py (d2r_xattn3_debug_stamps): cycle stamps of block 0
+
 template <typename E>
 void x3_fill(X3Args<E>& a, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
              const void* const* v, int64_t ldv, int64_t svb, void* const* o, int64_t ldo, int64_t sob, const void* const* residual,
@@ -623,6 +647,7 @@ void x3_fill(X3Args<E>& a, int ncore, const void* const* q, int64_t ldq, int64_t
   a.ntile = (Lq + QT - 1) / QT;
   static const int dbg = getenv("D2R_X3_DBG") ? atoi(getenv("D2R_X3_DBG")) : 0;
   a.dbg = dbg;
+  a.ts = g_x3_stamps;
 }
 
 template <typename E>
@@ -666,6 +691,11 @@ int x3_dkv_launch(int ngroup, const void* const* W, const void* const* X, void* 
 }  // namespace
 
 // Host entry used by d2r_xattn_fwd_multi (attention.hip).  Returns 1 when the launch was taken (Lk <= 256), else 0.
+// measurement aid of tests/probes/xattn3_probe.py, not declared in include/d2r_hip.h: block 0 of the forward kernel leaves
+// s_memtime stamps of its four waves in dst [4][64] (0 start, 1 loop entry, 2+t end of score tile t, 18 softmax done, 19+t end of
+// value tile t, 35 ring released, 36 end); nullptr switches it off
+extern "C" void d2r_xattn3_debug_stamps(unsigned long long* dst) { g_x3_stamps = dst; }
+
 int d2r_xattn3_fwd_try(int dtype, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
                        const void* const* v, int64_t ldv, int64_t svb, void* const* o, int64_t ldo, int64_t sob, const void* const* residual,
                        int64_t ldr, int64_t srb, const float* mask, float* const* lse, int B, int Lq, int Lk, float scale, hipStream_t st) {

@@ -46,3 +46,22 @@ for Lq, Lk in ((128, 197), (197, 128), (128, 128), (197, 197)):
         us = e0.elapsed_time(e1) / n * 1e3
         mb = ncore * B * (2 * Lq + 2 * Lk) * E * 2 / 1e6 * (2 if name == "bwd" else 1)
         print(f"dbg={os.environ.get('D2R_X3_DBG', '0')} Lq={Lq} Lk={Lk} ncore={ncore} {name}: {us:7.1f} us  ({mb / us * 1e-3 * 1e3:.0f} GB/s algorithmic)", flush=True)
+    if os.environ.get("D2R_X3_STAMPS"):  # where does block 0 of the forward kernel spend its cycles?
+        import ctypes as C
+        lib = _lib.load()
+        buf = torch.zeros(4 * 64, dtype=torch.int64, device=dev)
+        lib.d2r_xattn3_debug_stamps.argtypes = [C.c_void_p]
+        lib.d2r_xattn3_debug_stamps.restype = None
+        for rep in range(3):
+            lib.d2r_xattn3_debug_stamps(C.c_void_p(buf.data_ptr()))
+            fwd()
+            torch.cuda.synchronize()
+            lib.d2r_xattn3_debug_stamps(None)
+        t = buf.cpu().view(4, 64)
+        nkc = (Lk + 15) // 16
+        for w in range(4):
+            r = t[w]
+            k = [int(r[2 + i] - (r[1] if i == 0 else r[1 + i])) for i in range(nkc)]
+            v = [int(r[19 + i] - (r[18] if i == 0 else r[18 + i])) for i in range(nkc)]
+            print(f"  stamps Lq={Lq} Lk={Lk} wave {w}: prologue {int(r[1] - r[0])} | score tiles {k} | softmax {int(r[18] - r[1 + nkc])} | value tiles {v} | "
+                  f"ring release {int(r[35] - r[18 + nkc])} | epilogue {int(r[36] - r[35])} | total {int(r[36] - r[0])} cycles", flush=True)
