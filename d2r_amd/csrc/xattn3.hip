@@ -280,41 +280,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int t = 0; t < NT; ++t) pf[t] = E4{(E)(s[t][0] * inv), (E)(s[t][1] * inv), (E)(s[t][2] * inv), (E)(s[t][3] * inv)};
 
-  // ---- phase V: O^T[d][q] += V_t^T P_t^T, all 48 column tiles of the 768-wide output per wave ----------------------------------------
+  // ---- phase V: O^T[d][q] += V^T P^T, all 48 column tiles of the 768-wide output per wave, TWO key tiles per step ----------------
+  // v_mfma_f32_16x16x32 contracts over 32 keys: k-slot (fq, j) = key tile 2u, row fq*4 + j for j < 4, key tile 2u+1, row fq*4 + j - 4
+  // otherwise - the A operand is then the transposing read of chunk 2u followed by the SAME read of chunk 2u+1, the B operand the two
+  // probability packs side by side (half the MFMA issue slots of the 16-key form; an odd last tile is paired with zeros).
   f32x4 o[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   X3_STAMP(18);
+  int issued = nkc + NS - 2;  // youngest chunk in the queue (phase K issued up to chunk g + NS - 1 at step g)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t < nkc) {
-      const int g = nkc + t;
-      ring_wait(g);
-      const int gn = g + NS - 1;
-      const unsigned slot = sbase + (g % NS) * CB;
-      if (a.dbg == 2 || a.dbg == 3) { issue(gn); continue; }
-      // V^T fragments through the transposing read, twelve column tiles per batch, the next batch in flight behind the MFMAs
-      constexpr int NB = 12;
-      E4 vf[2][NB];
-      auto fetch = [&](int d0, E4 (&dst)[NB]) {
+  for (int u = 0; u < NT / 2; ++u) {
+    const int t0 = 2 * u, t1 = 2 * u + 1;
+    if (t0 < nkc) {
+      const bool two = t1 < nkc;
+      const int g0 = nkc + t0, g1 = two ? g0 + 1 : g0;
+      wait_vm_n(6 * (min(issued, G - 1) - g1));  // chunk g1 (and every older one) has landed for this wave
+      asm volatile("s_barrier" ::: "memory");    // ... for every wave, and everybody has left the chunks before g0
+      for (int gn = issued + 1; gn <= g0 + NS - 1; ++gn) issue(gn);  // chunk x goes into the slot chunk x - NS has left
+      issued = max(issued, g0 + NS - 1);
+      if (a.dbg == 2 || a.dbg == 3) continue;
+      const unsigned slot0 = sbase + (g0 % NS) * CB, slot1 = sbase + (g1 % NS) * CB;
+      E8 pp;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) dst[i] = lds_tr<E4>(slot + ro.tr[(d0 + i) & 7] + ((d0 + i) >> 3) * 256);
+      for (int j = 0; j < 4; ++j) pp[j] = pf[t0][j], pp[4 + j] = two ? pf[t1][j] : (E)0.f;
+      constexpr int NB = 6;  // column tiles per batch: 12 reads, the next batch in flight behind the MFMAs (lgkmcnt counts to 15)
+      E4 va[2][NB], vb[2][NB];
+      auto fetch = [&](int d0, E4 (&da)[NB], E4 (&db)[NB]) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const unsigned off = ro.tr[(d0 + i) & 7] + ((d0 + i) >> 3) * 256;
+          da[i] = lds_tr<E4>(slot0 + off);
+          db[i] = lds_tr<E4>(slot1 + off);
+        }
       };
-      issue(gn);
-      fetch(0, vf[0]);
+      fetch(0, va[0], vb[0]);
 #pragma unroll
       for (int bq = 0; bq < NDT / NB; ++bq) {
         if (bq + 1 < NDT / NB) {
-          fetch((bq + 1) * NB, vf[(bq + 1) & 1]);
+          fetch((bq + 1) * NB, va[(bq + 1) & 1], vb[(bq + 1) & 1]);
           wait_lgkm<12>();
         } else {
           wait_lgkm<0>();
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) o[bq * NB + i] = H16<E>::mfma16(vf[bq & 1][i], pf[t], o[bq * NB + i]);
+        for (int i = 0; i < NB; ++i) {
+          E8 vv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vv[j] = va[bq & 1][i][j], vv[4 + j] = vb[bq & 1][i][j];
+          o[bq * NB + i] = H16<E>::mfma32(vv, pp, o[bq * NB + i]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      X3_STAMP(19 + t);
+      X3_STAMP(19 + u);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave left the ring: it now stages the output tile

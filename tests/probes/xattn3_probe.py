@@ -62,6 +62,7 @@ for Lq, Lk in ((128, 197), (197, 128), (128, 128), (197, 197)):
         for w in range(4):
             r = t[w]
             k = [int(r[2 + i] - (r[1] if i == 0 else r[1 + i])) for i in range(nkc)]
-            v = [int(r[19 + i] - (r[18] if i == 0 else r[18 + i])) for i in range(nkc)]
-            print(f"  stamps Lq={Lq} Lk={Lk} wave {w}: prologue {int(r[1] - r[0])} | score tiles {k} | softmax {int(r[18] - r[1 + nkc])} | value tiles {v} | "
-                  f"ring release {int(r[35] - r[18 + nkc])} | epilogue {int(r[36] - r[35])} | total {int(r[36] - r[0])} cycles", flush=True)
+            nv = (nkc + 1) // 2  # value tiles go two per step
+            v = [int(r[19 + i] - (r[18] if i == 0 else r[18 + i])) for i in range(nv)]
+            print(f"  stamps Lq={Lq} Lk={Lk} wave {w}: prologue {int(r[1] - r[0])} | score tiles {k} | softmax {int(r[18] - r[1 + nkc])} | value tile pairs {v} | "
+                  f"ring release {int(r[35] - r[18 + nv])} | epilogue {int(r[36] - r[35])} | total {int(r[36] - r[0])} cycles", flush=True)
