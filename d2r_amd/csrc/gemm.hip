@@ -567,10 +567,114 @@ static bool skinny_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
   return true;
 }
 
+// ---- skinny 16-bit GEMM: M <= 32 rows of 16-bit operands (the per-sample vectors of the routing cells: GLAC's global branch,
+// GESC, the cells' cls poolers and their dX) -------------------------------------------------------------------------------------
+// Same decomposition as the fp32 kernel above - a workgroup owns 16 output columns, its four waves split K, all loads of a pass in
+// flight before the first MFMA, partials summed through LDS in a fixed order - on v_mfma_f32_16x16x32 (a lane loads 8 consecutive
+// k = one 16-byte pack per operand row).  NT reads B [N,K] rows directly; NN (B [K,N], the dX direction) stages each wave's k-rows
+// of the 16 columns in LDS and takes the fragments with the transposing read.  Epilogue = the split-K reduce kernel's (bias,
+// saved pre-activation, activation, activation gradient of a reference, residual, beta), 16-bit or fp32 output.  Replaces, per
+// call, a 32x64-tile launch over split-K slabs plus its reduce launch (about 110 launches per training step).
+template <typename E, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_skinny_h16_kernel(GemmArgs g) {
+  typedef typename H16<E>::v8 E8;
+  typedef typename H16<E>::v4 E4;
+  constexpr int MAXS = 8;  // k-steps of 32 per wave and pass: K = 1024 per pass
+  constexpr bool NN = LAYOUT == D2R_GEMM_NN;
+  __shared__ float red[4][2][16][17];
+  __shared__ __attribute__((aligned(16))) E bs[NN ? 4 * MAXS * 32 * 16 : 8];  // NN: per wave [k of the pass][16 columns]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
+  const E* A = reinterpret_cast<const E*>(g.A);
+  const E* B = reinterpret_cast<const E*>(g.B);
+  const int n0 = blockIdx.x * 16;
+  const int col = min(n0 + fr, g.N - 1);  // clamped: the matching outputs are not stored
+  const int r0 = min(fr, g.M - 1), r1 = min(16 + fr, g.M - 1);
+  const bool two = g.M > 16;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int ksteps = g.K / 32, per = (ksteps + 3) / 4;
+  const int kbeg = min(wave * per, ksteps), kend = min(kbeg + per, ksteps);
+  E* mine = bs + (NN ? wave * (MAXS * 32 * 16) : 0);
+  for (int s0 = kbeg; s0 < kbeg + per; s0 += MAXS) {  // (the same trip count in every wave: the NN staging synchronises per wave only)
+    const int ns = max(0, min(MAXS, kend - s0));
+    E8 a0[MAXS], a1[MAXS], b[MAXS];
+    Pack<E, 8> xr[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < ns) {
+        const int k = (s0 + s) * 32 + fq * 8;
+        a0[s] = *reinterpret_cast<const E8*>(A + (int64_t)r0 * g.lda + k);
+        if (two) a1[s] = *reinterpret_cast<const E8*>(A + (int64_t)r1 * g.lda + k);
+        if constexpr (!NN) b[s] = *reinterpret_cast<const E8*>(B + (int64_t)col * g.ldb + k);
+        else xr[s] = ld_pack<E, 8>(B + (int64_t)((s0 + s) * 32 + (lane >> 1)) * g.ldb + n0 + (lane & 1) * 8);  // 32 k-rows x 32 bytes
+      }
+    }
+    if constexpr (NN) {
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s)
+        if (s < ns) st_pack<E, 8>(mine + (s * 32 + (lane >> 1)) * 16 + (lane & 1) * 8, xr[s]);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's stores have landed (the slab is private to the wave)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) {
+        if (s < ns) {
+          const E* p0 = mine + (s * 32 + fq * 8 + tq) * 16 + tp * 4;
+          const E4 lo = H16<E>::tr_read(p0), hi = H16<E>::tr_read(p0 + 4 * 16);
+          b[s] = E8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < ns) {
+        acc0 = H16<E>::mfma32(a0[s], b[s], acc0);
+        if (two) acc1 = H16<E>::mfma32(a1[s], b[s], acc1);
+      }
+    }
+    if constexpr (NN) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();  // the fragments are in registers before the next pass overwrites the slab
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[wave][0][fq * 4 + r][fr] = acc0[r];
+    red[wave][1][fq * 4 + r][fr] = acc1[r];
+  }
+  __syncthreads();
+  for (int e = tid; e < 512; e += 256) {
+    const int mt = e >> 8, row = (e >> 4) & 15, c = e & 15;
+    const int m = mt * 16 + row, n = n0 + c;
+    if (m >= g.M || n >= g.N) continue;
+    float v = (red[0][mt][row][c] + red[1][mt][row][c]) + (red[2][mt][row][c] + red[3][mt][row][c]);
+    v = g.alpha * v + (g.bias ? g.bias[n] : 0.f);
+    const int64_t ci = (int64_t)m * g.ldc + n;
+    if (g.P) store_c(g.P, g.c_dtype, ci, v);
+    v = act_apply_cold(g.act, v);
+    if (g.G) v *= act_grad_cold(g.gact, load_c(g.G, g.c_dtype, ci));
+    if (g.R) v += load_c(g.R, g.c_dtype, (int64_t)m * g.ldr + n);
+    if (g.beta != 0.f) v += g.beta * load_c(g.C, g.c_dtype, ci);
+    store_c(g.C, g.c_dtype, ci, v);
+  }
+}
+
+template <typename E, int LAYOUT>
+static bool skinny_h16_try(const GemmArgs& a, int batch, hipStream_t st) {
+  static const int on = env_int("D2R_GEMM_SKINNY16", 1);
+  if (!on || !g_skinny || batch != 1 || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 32 != 0 || a.dbias || !a.vecA || !a.vecB) return false;
+  if (LAYOUT == D2R_GEMM_NN && a.N % 16 != 0) return false;  // (a 16-column slab per workgroup is loaded unguarded)
+  hipLaunchKernelGGL((gemm_skinny_h16_kernel<E, LAYOUT>), dim3(d2r_cdiv(a.N, 16)), dim3(256), 0, st, a);
+  d2r_gemm_variant_tl = 31;
+  return true;
+}
+
 template <typename T, int LAYOUT>
 static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t ws_bytes) {
   if constexpr (sizeof(T) == 4 && LAYOUT != D2R_GEMM_TN) {
     if (skinny_f32_try<LAYOUT>(a, batch, st)) return d2r_check_launch("d2r_gemm(skinny)");
+  }
+  if constexpr (sizeof(T) == 2 && LAYOUT != D2R_GEMM_TN) {
+    if (skinny_h16_try<T, LAYOUT>(a, batch, st)) return d2r_check_launch("d2r_gemm(skinny 16-bit)");
   }
   if constexpr (sizeof(T) == 2) {
     // large bf16 shapes: LDS-DMA pipelined 128xBN kernel (forced with tile 4 = 128x128, 5 = 128x64 for A/B runs)
@@ -695,6 +799,7 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd; a.band = 0;
   static const int g_dbg = env_int("D2R_GEMM_DBG", 0);
   a.dbg = g_dbg;
+  a.ts = nullptr;
   D2R_REQUIRE(!d->dbias || (d->layout == D2R_GEMM_TN && d->nb * d->nh == 1), "d2r_gemm: dbias needs the TN layout and batch 1");
   a.dbias = d->dbias;
   D2R_REQUIRE(!d->grad_ref || d->nb * d->nh == 1, "d2r_gemm: grad_ref needs batch 1");

@@ -46,6 +46,9 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
+  const bool stamping = g.ts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+#define GEMM_STAMP(i) do { if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g.ts[wave * 8 + (i)] = t_; } } while (0)
+  GEMM_STAMP(0);
   int tile_m, tile_n, z = 0;
   if constexpr (RAGGED) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
   else xcd_tile(g.xcd, tile_m, tile_n, g.band);
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_barrier" ::: "memory");  // (asm + memory clobber: the compiler may not move LDS reads / DMA issues across it)
+    if (t == 0) GEMM_STAMP(1);
     // tile t has landed for every wave (own counted vmcnt + barrier)
     const unsigned char* bA = smem + cur * BUF;
     const unsigned char* bB = bA + A_BYTES;
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
   }
 
   }
+  GEMM_STAMP(2);
 
   if constexpr (WGRAD) {
     // acc[i][j][r] = C[wm0 + i*16 + fr][wn0 + j*16 + fq*4 + r]: one 16-byte fp32 pack per lane and tile
@@ -364,6 +369,10 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       if (g.dbg == 5) continue;
       epilogue_pack8(g, pv, Cg, Pg, Rg, Gg, ci, ri, g.N - col);
     }
+    if (stamping) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GEMM_STAMP(3);
+    }
     return;
   }
 #pragma unroll
@@ -410,6 +419,11 @@ static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
   }
 }
 
+// measurement aid of tests/probes/gemm_stamps.py (not declared in include/d2r_hip.h): workgroup (0,0) of the next LDS-DMA launches
+// leaves s_memtime stamps per wave in dst[wave*8 + i]: 0 entry, 1 first tile landed, 2 K-loop done, 3 stores drained
+static unsigned long long* g_gemm_stamps = nullptr;
+extern "C" void d2r_gemm_debug_stamps(unsigned long long* dst) { g_gemm_stamps = dst; }
+
 // Returns 1 when the launch was taken by the LDS-DMA kernel, 0 when the shape is not eligible.
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st) {
   if (!d2r_is16(a.dtype) || batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
@@ -420,6 +434,7 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
   if ((a_strided && a.M % 8 != 0) || (b_strided && a.N % 8 != 0)) return 0;
   const bool f16 = a.dtype == D2R_F16;
   GemmArgs ab = a;
+  ab.ts = g_gemm_stamps;
   {
     // column bands for wide outputs: the B panels of a band (band x BN x K x 2 bytes) should take about a third of the 4 MB L2
     const int bnw = (bn % 1000) == 64 ? 64 : 128;

@@ -554,6 +554,7 @@ class Reversed_InteractionModule(_InteractionBase):
 # ------------------------------------------------------------------------------------------------------
 # encoders
 # ------------------------------------------------------------------------------------------------------
+INTERLEAVE_ENCODERS = os.environ.get("D2R_INTERLEAVE", "1") != "0"  # issue the two encoders layer by layer in alternation
 COMPOSITE_LAYERS = os.environ.get("D2R_COMPOSITE", "1") != "0"  # whole encoder layers as one C call (bf16 only)
 COMPOSITE_ROUTING = os.environ.get("D2R_COMPOSITE_ROUTING", "1") != "0"  # whole interaction modules as one C call (bf16 only)
 
@@ -778,13 +779,17 @@ class UnimoEncoder(D2RModule):
         self.vision_layers = nn.ModuleList([CLIPEncoderLayer(vision_config) for _ in range(vision_config.num_hidden_layers)])
         self.text_layer = nn.ModuleList([BertLayer(text_config) for _ in range(text_config.num_hidden_layers)])
 
-    def run_vision(self, v):
-        for layer in self.vision_layers:
+    def run_vision(self, v, gate=None):
+        for i, layer in enumerate(self.vision_layers):
+            if gate is not None:
+                gate("vision", i)  # (FusedAdamW.overlap_with_forward: this layer's weights of the previous step's update are in place)
             v = layer(v)
         return v
 
-    def run_text(self, t, key_mask):
-        for layer in self.text_layer:
+    def run_text(self, t, key_mask, gate=None):
+        for i, layer in enumerate(self.text_layer):
+            if gate is not None:
+                gate("text", i)
             t = layer(t, key_mask)
         return t
 
@@ -847,6 +852,7 @@ class UnimoModel(D2RModule):
         self.text_pooler = BertPooler() if add_pooling_layer else None  # dead (ingest assert needs it)
         self.use_streams = os.environ.get("D2R_STREAMS", "1") != "0"
         self._streams = None
+        self._param_gate = None  # set by FusedAdamW.overlap_with_forward(model)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, pixel_values=None):
         """-> (pooler_output [B,768], js_loss, aux) — models/modeling_unimo.py:786-894."""
@@ -864,7 +870,10 @@ class UnimoModel(D2RModule):
         if two:
             main = torch.cuda.current_stream()
             if self._streams is None:
-                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                # (D2R_STREAM_PRIO: priority of the two branch streams; -1 = above the optimiser stream of
+                #  FusedAdamW.overlap_with_forward, whose HBM-bound workgroups then only take the slots the branches leave free)
+                prio = int(os.environ.get("D2R_STREAM_PRIO", "0"))
+                self._streams = (torch.cuda.Stream(priority=prio), torch.cuda.Stream(priority=prio))
                 for st in self._streams:
                     F.register_compute_stream(st)  # joined at the end of every backward pass
             sT, sV = self._streams
@@ -876,10 +885,35 @@ class UnimoModel(D2RModule):
             sV.wait_stream(main)
         else:
             on_t = on_v = contextlib.nullcontext
+        # Optional gate of FusedAdamW.overlap_with_forward(): the previous step's parameter update runs on its own stream, chunk by
+        # chunk in the order the forward pass needs the weights; a gate makes the CURRENT stream wait for the chunk it names.
+        gate = self._param_gate
         with on_v():
-            v_enc = self.encoder.run_vision(self.vision_pre_layrnorm(self.vision_embeddings(pixel_values)))
+            if gate is not None:
+                gate("vision", -1)
+            v_enc = self.vision_pre_layrnorm(self.vision_embeddings(pixel_values))
         with on_t():
-            t_enc = self.encoder.run_text(self.text_embeddings(input_ids, token_type_ids), key_mask)
+            if gate is not None:
+                gate("text", -1)
+            t_enc = self.text_embeddings(input_ids, token_type_ids)
+        if two and INTERLEAVE_ENCODERS:
+            # The host needs about as long to enqueue a step as the GPU needs to run it: a whole encoder issued before the other
+            # leaves the second stream empty for the first milliseconds of every pass.  Layer i of both encoders is issued before
+            # layer i + 1 of either (autograd replays the same alternation backwards).
+            for i, (lv, lt) in enumerate(zip(self.encoder.vision_layers, self.encoder.text_layer)):
+                with on_v():
+                    if gate is not None:
+                        gate("vision", i)
+                    v_enc = lv(v_enc)
+                with on_t():
+                    if gate is not None:
+                        gate("text", i)
+                    t_enc = lt(t_enc, key_mask)
+        else:
+            with on_v():
+                v_enc = self.encoder.run_vision(v_enc, gate)
+            with on_t():
+                t_enc = self.encoder.run_text(t_enc, key_mask, gate)
         if two:
             # barrier through the launching stream, then fork again (a direct sT<->sV cross wait is legal HIP but
             # crashes hipStreamEndCapture on ROCm 7.2 when the step is being captured into a hipGraph)
@@ -892,18 +926,24 @@ class UnimoModel(D2RModule):
             sT.wait_stream(main)
             sV.wait_stream(main)
         with on_t():
+            if gate is not None:
+                gate("all", 0)
             t_out = t_enc
             for layer in self.self_text:
                 t_out = layer(t_out, key_mask)
             t_cls = self.text_cls_pool(t_out, fp32=True)
-            (emb_t,), sim_paths = self.itr_module(t_enc, v_enc)
-            js1 = F.js_div(sim_paths, F.matmul_nt(t_cls, t_cls))
-            tp = self.text_pool(emb_t, fp32=True)
         with on_v():
+            if gate is not None:
+                gate("all", 0)
             v_out = v_enc
             for layer in self.self_vision:
                 v_out = layer(v_out)
             v_cls = self.vision_cls_pool(v_out, fp32=True)
+        with on_t():
+            (emb_t,), sim_paths = self.itr_module(t_enc, v_enc)
+            js1 = F.js_div(sim_paths, F.matmul_nt(t_cls, t_cls))
+            tp = self.text_pool(emb_t, fp32=True)
+        with on_v():
             (emb_v,), rev_sim_paths = self.Reversed_itr_module(t_enc, v_enc)
             js2 = F.js_div(rev_sim_paths, F.matmul_nt(v_cls, v_cls))
             vp_ = self.vision_pool(emb_v, fp32=True)

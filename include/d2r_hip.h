@@ -119,7 +119,7 @@ void d2r_gemm_tuning(int nbuf, int vepi, int tile);
  * bracket each launch with HIP events on the launching stream.  d2r_gemm_timer(1) clears and arms, d2r_gemm_timer(0)
  * disarms; d2r_gemm_timer_read waits for the recorded events and returns per launch: family = dtype * 8 + layout * 2 +
  * grouped + 100 * kernel variant (0 generic tiles, 1 LDS-DMA 128x64, 2 / 3 LDS-DMA 128x128 on four / eight waves, 20 grouped
- * LDS-DMA weight gradients, 21 grouped generic, 22 grouped batched 16-bit, 30 skinny fp32), flops, algorithmic bytes (operands
+ * LDS-DMA weight gradients, 21 grouped generic, 22 grouped batched 16-bit, 30 skinny fp32, 31 skinny 16-bit), flops, algorithmic bytes (operands
  * once, output once, twice when accumulated), milliseconds.  The single-head attention entry points record as well: family
  * 10001 = d2r_xattn_fwd_multi (one launch), 10002 = d2r_xattn_bwd_multi (its launches together; bytes = 2 x forward).  Returns the
  * number of records copied (or, with family == NULL, the number pending, which it discards). */

@@ -466,6 +466,42 @@ def test_skinny_fp32_gemm(gpu, cfg):
     assert float((c.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("lowp", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [("NT", 32, 768, 768), ("NT", 8, 768, 768), ("NT", 17, 96, 1600), ("NT", 1, 16, 64), ("NN", 32, 768, 768),
+                                 ("NN", 3, 128, 768), ("NN", 32, 1600, 96)], ids=lambda c: "-".join(map(str, c)))
+def test_skinny_16bit_gemm(gpu, cfg, lowp):
+    """The 16-bit kernel for products with at most 32 rows (per-sample vectors of the routing cells; K a multiple of 32, NN: N a
+    multiple of 16): plain with 16-bit and with fp32 output, strided A rows (token 0 of every sample), and the full epilogue
+    (bias, tanh + saved pre-activation, residual, accumulation) against fp64 on the rounded operands."""
+    from d2r_amd import functional as F
+    from d2r_amd._lib import BF16, F16, F32, GEMM_NN, GEMM_NT, ACT_TANH, ACT_NONE
+    lay, M, N, K = cfg
+    code = BF16 if lowp == torch.bfloat16 else F16
+    layout = GEMM_NT if lay == "NT" else GEMM_NN
+    L = 5
+    a_all = rnd(M, L, K, seed=1).to(lowp).to(gpu)  # rows of the product = token 0 of every sample: lda = L * K
+    a = a_all[:, 0]
+    b = (rnd(N, K, seed=2, scale=0.1) if lay == "NT" else rnd(K, N, seed=2, scale=0.1)).to(lowp).to(gpu)
+    bias = rnd(N, seed=3).to(gpu)
+    res = rnd(M, N, seed=4).to(lowp).to(gpu)
+    c0 = rnd(M, N, seed=5).to(lowp).to(gpu)
+    prod = a.double() @ (b.double().t() if lay == "NT" else b.double())
+    ldb = K if lay == "NT" else N
+    eps = 2.0 ** -8 if lowp == torch.bfloat16 else 2.0 ** -11
+    for c_dt, c_code in ((lowp, code), (torch.float32, F32)):
+        c = torch.empty(M, N, dtype=c_dt, device=gpu)
+        F.gemm(layout, M, N, K, a_all.data_ptr(), L * K, b.data_ptr(), ldb, c.data_ptr(), N, dtype=code, c_dtype=c_code)
+        tol = (eps if c_dt != torch.float32 else 1e-5) * float(prod.abs().max()) + 1e-6
+        assert float((c.double() - prod).abs().max()) <= tol, (cfg, c_dt)
+    c, pre = c0.clone(), torch.empty(M, N, dtype=lowp, device=gpu)
+    F.gemm(layout, M, N, K, a_all.data_ptr(), L * K, b.data_ptr(), ldb, c.data_ptr(), N, dtype=code, c_dtype=code, alpha=0.5, beta=1.0,
+           bias=bias.data_ptr(), act=ACT_TANH, residual=res.data_ptr(), ldr=N, preact=pre.data_ptr())
+    want_pre = 0.5 * prod + bias.double()[None, :]
+    want = torch.tanh(want_pre) + res.double() + c0.double()
+    assert float((pre.double() - want_pre).abs().max()) <= eps * float(want_pre.abs().max()) + 1e-6
+    assert float((c.double() - want).abs().max()) <= 2 * eps * float(want.abs().max()) + 1e-6
+
+
 def test_copy_rows(gpu):
     """d2r_copy_rows: strided row gather / scatter in one launch (16-byte vector path and the byte path), checked against slicing."""
     from d2r_amd import _lib

@@ -181,20 +181,25 @@ def test_cli_smoke(gpu, tmp_path):
     assert "Test Eval results" in r.stderr and os.path.exists(os.path.join(str(tmp_path), "best_model.pth"))
 
 
-def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4):
+def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4, layers=1, overlap_chunks=0, dtype=torch.bfloat16):
     from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
-    model, args = _tiny(torch.bfloat16)
+    model, args = _tiny(dtype, layers=layers)
     model.load_state_dict(sd, strict=True)
     model.to(gpu).train()
+    model.set_compute_dtype(dtype)
     model.model.use_streams = use_streams
-    store = ParamStore(model, torch.bfloat16)
+    store = ParamStore(model, dtype)
     opt = FusedAdamW(store, lr=1e-3)
+    if dtype == torch.float16:
+        opt.enable_loss_scaling(init_scale=2.0 ** 10)
+    if overlap_chunks:
+        opt.overlap_with_forward(model, chunks=overlap_chunks)
     sched = LinearWarmupSchedule(opt, 2, 10)
     losses = []
     if not use_graph:
         for _ in range(n):
             loss, _ = model(*batch)
-            loss.backward()
+            opt.scale_loss(loss).backward()
             opt.step()
             sched.step()
             opt.zero_grad()
@@ -242,6 +247,26 @@ def test_streams_and_graph_replay_are_bit_identical_to_single_stream_eager(gpu):
                 bad = (a != b).nonzero().flatten()
                 names = sorted({n for n, o, k in got[4] if ((bad >= o) & (bad < o + k)).any()})
                 raise AssertionError(f"{tag}: {what} differs in {bad.numel()} elements of {names[:12]} ({len(names)} tensors)")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_update_overlapped_with_the_next_forward_is_bit_identical(gpu, dtype):
+    """FusedAdamW.overlap_with_forward: the update of step N on its own stream, chunk by chunk in forward order, the forward pass
+    of step N+1 gated per encoder layer, zero_grad behind the update - against the plain step (same launches, same elements:
+    weights, moments and losses must agree exactly), with one and two compute streams, and with the fp16 loss scaler (whose
+    non-finite check has to precede every piece of the update)."""
+    from oracle import d2r_oracle as O
+    cfg = O.OracleConfig(text_layers=3, vision_layers=3, image_size=64, patch_size=32)
+    sd = O.seeded_state_dict(cfg, seed=5, router_bias="normal")
+    batch = tuple(t.to(gpu) for t in O.synthetic_batch(cfg, 4, 12, seed=9))
+    base = _run_steps(gpu, sd, batch, False, False, n=5, layers=3, dtype=dtype)
+    assert base[0][-1] != base[0][0]
+    for chunks, use_streams in ((1, False), (2, True), (3, True)):
+        got = _run_steps(gpu, sd, batch, False, use_streams, n=5, layers=3, overlap_chunks=chunks, dtype=dtype)
+        tag = f"chunks={chunks} streams={use_streams}"
+        assert got[0] == base[0], (tag, got[0], base[0])
+        for what, a, b in zip(("w", "m", "v"), got[1:4], base[1:4]):
+            assert torch.equal(a, b), f"{tag}: {what} differs in {int((a != b).sum())} elements"
 
 
 def test_data_parallel_two_ranks_on_one_gpu(gpu, tmp_path):
