@@ -649,6 +649,137 @@ __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
   }
 }
 
+// ---- compact product kernel (the shapes of the path: Lq, Lk <= 256 with min(Lq, Lk) <= 128) --------------------------------------------
+// Same product as above with (i) at most EIGHT B fragments per wave - two output row tiles x up to four k-steps, or one row tile x
+// up to eight - so that the kernel fits 128 VGPRs, (ii) an LDS footprint sized by the launch (<= 64 KB: the W image [KP][LDW] or the
+// X chunk image [KP][80]) - two workgroups per CU, so that the 9 x 32 = 288 workgroups of a three-problem launch are all resident
+// instead of running as one and an eighth rounds, and (iii) ROW-PERMUTED LDS images: bit 2 and bit 3 of the row index swap places,
+// which makes the eight rows one 32-lane group of ds_read_b64_tr_b16 touches (k0 + {0..3, 8..11}, then + 4) consecutive; with a row
+// stride of an odd number of 32-byte units their 32-byte segments fall on eight different bank groups (the natural order put rows
+// r and r + 8 on the same banks: SQ_LDS_BANK_CONFLICT was 55 % of the LDS cycles).
+__device__ __forceinline__ int dkv_prow(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// lane (fr, fq) gets M[k0 + 8 fq + j][c0 + fr], j = 0..7, from a row-permuted image with row stride LD (elements)
+template <typename E>
+__device__ __forceinline__ typename H16<E>::v8 dkv_frag(const E* base, int LD, int k0, int c0, int fq, int tq, int tp) {
+  typedef typename H16<E>::v4 E4;
+  typedef typename H16<E>::v8 E8;
+  const E* p0 = base + (k0 + (fq >> 1) * 16 + (fq & 1) * 4 + tq) * LD + c0 + tp * 4;  // = dkv_prow(k0 + fq*8 + tq)
+  const E4 lo = H16<E>::tr_read(p0);
+  const E4 hi = H16<E>::tr_read(p0 + 8 * LD);                                        // = dkv_prow(k0 + fq*8 + tq + 4)
+  return E8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__host__ __device__ __forceinline__ int dkv_ldw(int nmt) {  // row stride of the W image: columns + 16, an odd number of 16-element units
+  const int u = nmt + 1;
+  return (u | 1) * 16;
+}
+
+template <typename E>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void xattn3_dkv2_kernel(DkvArgs<E> a) {
+  typedef typename H16<E>::v8 E8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dkv_smem[];
+  E* sm = reinterpret_cast<E*>(dkv_smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
+  const int id = blockIdx.x, xcd = id & 7, rr = id >> 3;
+  const int g = rr % a.ngroup, b = (rr / a.ngroup) * 8 + xcd;
+  if (b >= a.B) return;
+  const E* Wg = a.W[g] + b * a.swb;
+  const int64_t ldx = a.ldx[g], ldo = a.ldo[g];
+  const E* Xg = a.X[g] + b * a.sxb[g];
+  E* Og = a.out[g] + b * a.sob[g];
+  const int Kd = a.Kd[g], Md = a.Md[g], trans = a.trans[g], ldw = a.ldw;
+  const int KP = (Kd + 31) / 32 * 32, KS = KP / 32, nmt = (Md + 15) / 16, MPAD = nmt * 16, LDW = dkv_ldw(nmt);
+  const bool two = nmt > 8;  // two output row tiles per wave (then KS <= 4: checked on the host)
+  // ---- Wt (rows >= Kd and columns >= Md zero) -> LDS ------------------------------------------------------------------------------
+  if (!trans) {
+    const int MP8 = MPAD / 8;
+    for (int idx = tid; idx < KP * MP8; idx += 512) {
+      const int row = idx / MP8, ch = idx - row * MP8;
+      const bool ok = row < Kd && ch * 8 < ldw;
+      Pack<E, 8> v = ld_pack<E, 8>(Wg + (ok ? (int64_t)row * ldw + ch * 8 : 0));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v.v[j] = (ok && ch * 8 + j < Md) ? v.v[j] : (E)0.f;
+      st_pack<E, 8>(sm + dkv_prow(row) * LDW + ch * 8, v);
+    }
+  } else {
+    // W is [m][k] in memory: consecutive lanes take consecutive m (2-byte stores of a wave fall into one LDS row per k)
+    const int KP8 = KP / 8;
+    for (int idx = tid; idx < MPAD * KP8; idx += 512) {
+      const int ch = idx / MPAD, m = idx - ch * MPAD;
+      const bool ok = m < Md && ch * 8 < ldw;
+      const Pack<E, 8> v = ld_pack<E, 8>(Wg + (ok ? (int64_t)m * ldw + ch * 8 : 0));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sm[dkv_prow(ch * 8 + j) * LDW + m] = (ok && ch * 8 + j < Kd) ? v.v[j] : (E)0.f;
+    }
+  }
+  __syncthreads();
+  E8 wf[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int i = two ? (f >> 2) : 0, ks = two ? (f & 3) : f;
+    const int n = min(wave + 8 * i, nmt - 1), k0 = min(ks, KS - 1) * 32;  // (clamped: unused fragments read valid LDS)
+    wf[f] = dkv_frag<E>(sm, LDW, k0, n * 16, fq, tq, tp);
+  }
+  __syncthreads();  // the Wt image is dead: the region now holds the X chunks
+  // ---- X in 64-column chunks: registers -> LDS (one chunk ahead in registers), out tile = Wt^T X_chunk ------------------------------
+  constexpr int NPK = DKV_KM * (DKV_XC / 8) / 512;  // 16-byte packs of a chunk per thread (4)
+  Pack<E, 8> xr[NPK];
+  auto xload = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+      const int idx = tid + i * 512, row = idx >> 3, ch = idx & 7;
+      if (row < KP) xr[i] = ld_pack<E, 8>(Xg + (int64_t)min(row, Kd - 1) * ldx + c * DKV_XC + ch * 8);  // rows past Kd: finite, times Wt = 0
+    }
+  };
+  auto xstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+      const int idx = tid + i * 512, row = idx >> 3, ch = idx & 7;
+      if (row < KP) st_pack<E, 8>(sm + dkv_prow(row) * DKV_LDX + ch * 8, xr[i]);
+    }
+  };
+  xload(0);
+  for (int c = 0; c < XE / DKV_XC; ++c) {
+    xstore();
+    __syncthreads();
+    if (c + 1 < XE / DKV_XC) xload(c + 1);
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks < KS) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const E8 af = dkv_frag<E>(sm, DKV_LDX, ks * 32, m * 16, fq, tq, tp);
+          acc[0][m] = H16<E>::mfma32(af, wf[ks], acc[0][m]);
+          if (ks < 4 && two) acc[1][m] = H16<E>::mfma32(af, wf[4 + (ks & 3)], acc[1][m]);
+        }
+      }
+    }
+    // acc[i][m][r] = out[row = n*16 + fr][d = c*64 + m*16 + fq*4 + r]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (wave + 8 * i) * 16 + fr;
+      if ((i == 0 || two) && wave + 8 * i < nmt && row < Md) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          Pack<E, 4> pk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk.v[r] = (E)acc[i][m][r];
+          st_pack<E, 4>(Og + (int64_t)row * ldo + c * DKV_XC + m * 16 + fq * 4, pk);
+        }
+      }
+    }
+    __syncthreads();  // everyone is done reading the chunk before it is overwritten
+  }
+}
+
 unsigned long long* g_x3_stamps = nullptr;  // tests/probes/xattn3_probe.py (d2r_xattn3_debug_stamps): cycle stamps of block 0
 
 template <typename E>
@@ -702,6 +833,20 @@ int x3_dkv_launch(int ngroup, const void* const* W, const void* const* X, void* 
     a.Kd[g] = trans[g] ? Lk : Lq, a.Md[g] = trans[g] ? Lq : Lk;
   }
   a.swb = (int64_t)Lq * lkp, a.ldw = lkp, a.B = B, a.ngroup = ngroup;
+  // the compact kernel (two workgroups per CU) when every group fits its eight fragments per wave and 64 KB of LDS
+  static const int compact_on = getenv("D2R_X3_DKV2") ? atoi(getenv("D2R_X3_DKV2")) : 1;
+  bool compact = compact_on != 0;
+  size_t lds = 0;
+  for (int g = 0; g < ngroup && compact; ++g) {
+    const int KP = (a.Kd[g] + 31) / 32 * 32, KS = KP / 32, nmt = (a.Md[g] + 15) / 16;
+    compact = nmt <= 8 ? KS <= 8 : (nmt <= 16 && KS <= 4);
+    const size_t need = (size_t)KP * (size_t)(dkv_ldw(nmt) > DKV_LDX ? dkv_ldw(nmt) : DKV_LDX) * sizeof(E);
+    lds = need > lds ? need : lds;
+  }
+  if (compact && lds <= 65536) {
+    hipLaunchKernelGGL((xattn3_dkv2_kernel<E>), dim3((B + 7) / 8 * 8 * ngroup), dim3(512), lds, st, a);
+    return 1;
+  }
   hipLaunchKernelGGL((xattn3_dkv_kernel<E>), dim3((B + 7) / 8 * 8 * ngroup), dim3(512), 0, st, a);
   return 1;
 }

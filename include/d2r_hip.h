@@ -126,6 +126,12 @@ void d2r_gemm_tuning(int nbuf, int vepi, int tile);
 int d2r_gemm_timer(int on);
 int d2r_gemm_timer_read(int* family, double* flops, double* bytes, float* ms, int capacity);
 
+/* Data parallelism: there is deliberately NO d2r_comm_* entry point.  The gradient reduction of the path is a sum of the flat
+ * fp32 gradient buffer over ranks; the host side (d2r_amd/dp.py) issues it as bucketed torch.distributed collectives - RCCL
+ * all-reduce, or reduce-scatter + all-gather per bucket - on a communication stream ordered behind the compute streams.  The
+ * data movement is RCCL's over xGMI; nothing of it is arithmetic of this library, so nothing of it sits behind this ABI.  A
+ * binding from another host language calls its own RCCL on the same buffers (the 1 / world factor is d2r_adamw_step's grad_scale). */
+
 /* ------------------------------------------------------------------------------------------------
  * Row kernels (fp32 statistics, wave-shuffle reductions)
  * ------------------------------------------------------------------------------------------------ */

@@ -32,6 +32,31 @@ def family(name: str):
 
     if "splitk_reduce" in name:
         return "gemm_splitk_reduce", True
+    # round 3: <E, LAYOUT, BN, NWN, PIPE, MODE> (MODE 1 grouped weight gradients, 2 grouped + batched 16-bit output); E = bf16 (b) / fp16 (_)
+    m = re.search(r"gemm_glds_kernelIDF16([b_])Li(\d)ELi(\d+)ELi(\d)ELi(\d)ELi(\d)E", name)
+    if m:
+        dt = "bf16" if m.group(1) == "b" else "f16"
+        mode = int(m.group(6))
+        if mode == 1:
+            return "gemm_%s_TN_grouped_ldsdma128x128" % dt, True
+        if mode == 2:
+            return "gemm_%s_TN_grouped_batched16" % dt, True
+        return glds(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), False).replace("bf16", dt), True
+    m = re.search(r"gemm_skinny_h16_kernelIDF16([b_])Li(\d)E", name)
+    if m:
+        return "gemm_%s_%s_skinny" % ("bf16" if m.group(1) == "b" else "f16", lay[int(m.group(2))]), True
+    m = re.search(r"gemm_kernelIDF16_Li(\d)ELi\d+ELi\d+ELi\dELi\dELi\dELb([01])E", name)
+    if m:
+        return "gemm_f16_" + lay[int(m.group(1))] + ("_grouped_tiles64x64" if m.group(2) == "1" else "_tiles"), True
+    # third-generation single-head attention: the backward op = query-side kernel + product kernel (one launch of the op each)
+    if "xattn3_fwd" in name:
+        return "xattn_core_fwd", True
+    if "xattn3_bwd" in name:
+        return "xattn_core_bwd", True
+    if "xattn3_dkv" in name:
+        return "xattn_core_bwd", False
+    if "nonfinite_kernel" in name:
+        return "d2r_grad_nonfinite", True
     m = re.search(r"gemm_glds_kernelIDF16[b_]Li(\d)ELi(\d+)ELi(\d)ELi(\d)ELb([01])E", name)  # <E, LAYOUT, BN, NWN, PIPE, WGRAD>
     if m:
         return glds(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), m.group(5) == "1"), True
@@ -82,7 +107,7 @@ fetch, n_f = load(sys.argv[1], "FETCH_SIZE")
 write, n_w = load(sys.argv[2], "WRITE_SIZE")
 # steps of the profiled command: 1 warm-up + 2 timed + 4 of the fwd+bwd-only leg (bench.py --steps 2 --warmup 1) = 7
 STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 7
-out = {"_doc": "HBM bytes from rocprofv3 --pmc (FETCH_SIZE x2 on gfx950, WRITE_SIZE exact); bench.py --steps 2 --warmup 1, bf16 C2 "
+out = {"_doc": "HBM bytes from rocprofv3 --pmc (FETCH_SIZE x2 on gfx950, WRITE_SIZE exact); bench.py --steps 2 --warmup 1, C2 "
                "workload (%d steps in the run).  *_per_launch: per GEMM kernel of the REAL step (a grouped weight-gradient launch "
                "holds 6-16 problems); hbm_bytes_per_step: family total per training step - bench.py divides it by the launches "
                "per step of its per-kernel pass to compare with the algorithmic bytes per launch." % STEPS,

@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p $OUT
 FLAGS="--no-cpu-baseline --no-roofline --no-fp32-leg --no-alt-leg --no-host-leg"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --steps 6 --warmup 2 $FLAGS > $OUT/kt.log 2>&1 || exit 11
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+python3 profiles/make_step_gaps.py $(find $OUT/kt -name "*kernel_trace.csv" | head -1) $OUT/step_gaps.json > $OUT/step_gaps.log 2>&1 || exit 16
 cp $(find $OUT/kt -name "*domain_stats.csv" | head -1) $OUT/domain_stats.csv 2>/dev/null
 rm -rf $OUT/kt
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 bench.py --steps 2 --warmup 1 $FLAGS > $OUT/fetch.log 2>&1 || exit 12
