@@ -39,7 +39,7 @@ PRECISION_NOTE = {
             "loss and master weights; dynamic loss scale with the overflow check inside the step. Logits/loss within 1e-3 of the "
             "reference at this shape and on every golden fixture (asserted, tests/test_gpu_bench_shapes.py, tests/test_gpu_model.py)",
     "bf16": "bf16 MFMA operands + bf16 activation storage, fp32 elsewhere as in the fp16 mode, no loss scale. NOT within 1e-3: "
-            "2e-3 on the goldens (bf16 operand rounding alone is 0.9e-3, profiles/precision_policy_r03.log)",
+            "2e-3 on the goldens (bf16 operand rounding alone is 0.9e-3, profiles/precision_policy_goldens_r03.log)",
     "f32": "fp32 everywhere (v_mfma_f32_16x16x4_f32); logits within 3e-7 of the reference",
 }
 
