@@ -464,7 +464,16 @@ __global__ __launch_bounds__(256) void agg_bwd6_finish_kernel(const float* __res
   if (tid < 36) {
     const int i = tid / 6, j = tid - i * 6;
     float t = (dprobs && i < nc && j < nc) ? dprobs[(int64_t)b * ldp + i * nc + j] : 0.f;
-    for (int cidx = 0; cidx < nchunk; ++cidx) t += ws_dots[((int64_t)b * nchunk + cidx) * 36 + tid];
+    // eight chunk partials per trip, all loaded before the first add (one memory latency per trip instead of one per chunk;
+    // fixed order of additions)
+    const float* wd = ws_dots + (int64_t)b * nchunk * 36 + tid;
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {
+      float p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] = c0 + u < nchunk ? wd[(int64_t)(c0 + u) * 36] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += p[u];
+    }
     dph[tid] = t;
   }
   __syncthreads();
@@ -617,7 +626,14 @@ __global__ __launch_bounds__(256) void agg_bwd1_finish_kernel(const float* __res
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid < 8) {
     float t = 0.f;
-    for (int k = 0; k < nchunk; ++k) t += ws_dots[((int64_t)b * nchunk + k) * 8 + tid];
+    const float* wd = ws_dots + (int64_t)b * nchunk * 8 + tid;
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {  // (eight partials per trip in flight together, fixed order of additions)
+      float p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] = c0 + u < nchunk ? wd[(int64_t)(c0 + u) * 8] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += p[u];
+    }
     dt[tid] = t;
   }
   __syncthreads();

@@ -1,5 +1,5 @@
 import torch, sys
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from d2r_amd import functional as F
 dev = torch.device("cuda:0")
 for (B, L) in ((32, 197), (32, 128)):
