@@ -81,7 +81,7 @@ def build_parser():
     p.add_argument("--dp_grad_comm", default="f32", choices=["f32", "bf16"], help="dtype of the gradient buckets on the links")
     p.add_argument("--dp_shard_optimizer", action="store_true",
                    help="per bucket: reduce-scatter of the gradients, AdamW on this rank's stripe, all-gather of the updated weights "
-                        "(combines with --dp_overlap)")
+                        "(combines with --dp_overlap; the RCCL reduce-scatter / all-gather calls are rehearsed with gloo only so far)")
     p.add_argument("--dp_algorithm", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
                    help="gradient reduction per bucket: RCCL's all-reduce, or its two phases issued explicitly")
     p.add_argument("--cleanup_output", action="store_true", help="reference behaviour: rmtree('./output') at the end")
