@@ -25,16 +25,17 @@
 // + batch index, operands at grp.A/B/C[group] + batch * g.sAb / sBb / sCb; the reduction length need not be a multiple of 64
 // (as in mode 1); rows are LOADED up to g.M (a multiple of 8) and STORED up to g.m_store.  Serves the key-side products of the
 // cross-attention backward (dV = P^T dO, dK = dS^T Q for every sample of up to four attention problems: one launch).
-template <typename E, int LAYOUT, int BN, int NWN = 2, int PIPE = 0, int MODE = 0>
-__global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, GemmGroup grp) {
+template <typename E, int LAYOUT, int BN, int NWN = 2, int PIPE = 0, int MODE = 0, int NWM = 2>
+__global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, GemmGroup grp) {
   constexpr bool WGRAD = MODE == 1;        // fp32 accumulate epilogue + bias gradient
   constexpr bool RAGGED = MODE != 0;       // grouped launch (3-D tile order), ragged reduction length
   typedef typename H16<E>::v8 h8;  // E: E or f16_t (same tiles and LDS images; the MFMA opcode differs)
   typedef typename H16<E>::v4 h4;
-  constexpr int BM = 128, BK = 64, NW = 2 * NWN;
+  constexpr int BM = 64 * NWM, BK = 64, NW = NWM * NWN;  // NWM waves along M (a wave owns 64 rows): 128-row tiles, or 256 (weight gradients)
   constexpr bool A_KCONT = (LAYOUT != D2R_GEMM_TN);
   constexpr bool B_KCONT = (LAYOUT == D2R_GEMM_NT);
-  constexpr int WM = BM / 2, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
+  constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
+  constexpr int ACH = BM / 8, AROWS = 64 / ACH;  // k-strided A image [64 k][BM m]: 16-byte chunks per k-row, k-rows per DMA instruction
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF = A_BYTES + B_BYTES;
   // LDS-DMA instructions (1 KiB each) per tile and per wave
   constexpr int IA = A_BYTES / 1024 / NW, IB = B_BYTES / 1024 / NW;
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       const int row = ins * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
       const int grow = min(m0 + row, g.M - 1);
       offA[i] = (int64_t)grow * g.lda + c * 8;
-    } else {  // [64 k][128 m]: 4 k-rows x 256 B per instruction
-      const int krow = ins * 4 + (lane >> 4), c = (lane & 15) ^ (krow & 15);
+    } else {  // [64 k][BM m]: AROWS k-rows x BM*2 bytes per instruction (4 x 256 B for the 128-row tile, 2 x 512 B for 256 rows)
+      const int krow = ins * AROWS + lane / ACH, c = (lane % ACH) ^ (krow & (ACH - 1));
       const int col = min(m0 + c * 8, g.M - 8);
       offA[i] = (int64_t)krow * g.lda + col;
     }
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       if constexpr (RAGGED) {
-        const int krow = (wave + NW * i) * 4 + (lane >> 4);
+        const int krow = (wave + NW * i) * AROWS + lane / ACH;
         adjA = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.lda : 0;
       }
       const E* src = A + offA[i] + adjA + (A_KCONT ? (int64_t)k0 : (int64_t)k0 * g.lda);
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
       } else {
         const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
         const int c = col >> 3, h = (col & 7) >> 2;
-        const h4 lo = lds_tr_read<h4>(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8);
-        const h4 hi = lds_tr_read<h4>(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8);
+        const h4 lo = lds_tr_read<h4>(bA + k * (BM * 2) + ((c ^ (k & (ACH - 1))) << 4) + h * 8);
+        const h4 hi = lds_tr_read<h4>(bA + (k + 4) * (BM * 2) + ((c ^ ((k + 4) & (ACH - 1))) << 4) + h * 8);
         af[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(2 * NWN * 64) void gemm_glds_kernel(GemmArgs g, Gem
         } else {
           const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
           const int c = col >> 3, h = (col & 7) >> 2;
-          const h4 lo = lds_tr_read<h4>(bA + k * 256 + ((c ^ (k & 15)) << 4) + h * 8);
-          const h4 hi = lds_tr_read<h4>(bA + (k + 4) * 256 + ((c ^ ((k + 4) & 15)) << 4) + h * 8);
+          const h4 lo = lds_tr_read<h4>(bA + k * (BM * 2) + ((c ^ (k & (ACH - 1))) << 4) + h * 8);
+          const h4 hi = lds_tr_read<h4>(bA + (k + 4) * (BM * 2) + ((c ^ ((k + 4) & (ACH - 1))) << 4) + h * 8);
           af[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       }
@@ -463,8 +464,17 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
 // eligible (then the generic 64 x 64 kernel runs).
 int d2r_gemm_glds_wgrad_try(const GemmArgs& a, const GemmGroup& grp, int n, hipStream_t st) {
   if (!d2r_is16(a.dtype) || a.K < 128 || a.M < 128 || a.N < 128 || !a.vecA || !a.vecB || a.M % 8 != 0 || a.N % 8 != 0) return 0;
-  dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), n);
   d2r_gemm_variant_tl = 20;
+  // 256 x 128 tiles on eight waves (D2R_WGRAD_TILE256): three quarters of the L2 -> LDS bytes per flop of the 128 x 128 tile; these launches
+  // have a thousand tiles and 64-98 K-steps, so neither the grid quantisation nor the longer prologue of the wider tile matters
+  static const int tile256 = getenv("D2R_WGRAD_TILE256") ? atoi(getenv("D2R_WGRAD_TILE256")) : 0;
+  if (tile256 && a.M % 256 == 0) {
+    dim3 grid(d2r_cdiv(a.N, 128), a.M / 256, n);
+    if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, 1, 4>), grid, dim3(512), 0, st, a, grp);
+    else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, 1, 4>), grid, dim3(512), 0, st, a, grp);
+    return 1;
+  }
+  dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), n);
   if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, 1>), grid, dim3(256), 0, st, a, grp);
   else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, 1>), grid, dim3(256), 0, st, a, grp);
   return 1;
