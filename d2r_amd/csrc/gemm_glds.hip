@@ -8,12 +8,25 @@
 //   k-contiguous operand (A of NT/NN, B of NT): image [rows][64 k] (128 B rows); 16-B chunk c of row r sits at
 //       position c ^ (r & 7); fragments are ds_read_b128.
 //   k-strided operand (B of NN, A/B of TN): image [64 k][R rows] (R*2 B rows); chunk c of k-row k sits at position
-//       c ^ (k & (R/8-1)); fragments are two ds_read_b64_tr_b16 (hardware transpose).
+//       c ^ kswz(k) (whole chunk pairs move, see kswz below); fragments are two ds_read_b64_tr_b16 (hardware transpose).
 // Rows / columns past the matrix edge are CLAMPED to a valid address instead of zero-filled: they only feed output
 // elements that are never stored.  Requirements (checked by the host dispatcher, else the generic kernel runs):
 // bf16, batch 1, K % 64 == 0, 16-B aligned operands, and M % 8 == N % 8 == 0 for k-strided operands.
 #include "gemm_args.h"
 
+
+// XOR mask (in 16-byte chunks) of k-row k of a k-strided image with CH chunks per row.  One 32-lane group of ds_read_b64_tr_b16
+// touches the eight k-rows k0 + {0..3, 8..11} (then + 4), 32 contiguous bytes = one chunk PAIR of each.  Rows of 256 or 512 bytes
+// all start on bank 0: the mask moves whole pairs, by a different amount for each of the eight rows (bits 0-1 and bit 3 of k), so
+// that the group covers all 64 banks once.  (Rounds 1-2 XORed single chunks with the low bits of k: rows k and k ^ 1 then share
+// their chunk pair - a two-way conflict on every transposing read, SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles of the
+// weight-gradient kernel, 27-29 % of the NN kernels'.)  Rows of 128 bytes alternate between the two halves of the banks by
+// themselves; the mask then only has to separate the four rows of a half (bits 1 and 3 of k) over its four pairs.
+template <int CH>
+__device__ __forceinline__ int kswz(int k) {
+  if constexpr (CH >= 16) return ((k & 3) | ((k >> 1) & 4)) << 1;
+  else return (((k >> 1) & 1) | ((k >> 2) & 2)) << 1;
+}
 
 // NWN waves along N (2: four waves, 4: eight waves per workgroup); a wave owns 64 rows x BN/NWN columns.
 // PIPE = 1: software-pipelined K-step (all fragment reads of the step issued up front behind counted lgkmcnt waits, the
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       const int grow = min(m0 + row, g.M - 1);
       offA[i] = (int64_t)grow * g.lda + c * 8;
     } else {  // [64 k][BM m]: AROWS k-rows x BM*2 bytes per instruction (4 x 256 B for the 128-row tile, 2 x 512 B for 256 rows)
-      const int krow = ins * AROWS + lane / ACH, c = (lane % ACH) ^ (krow & (ACH - 1));
+      const int krow = ins * AROWS + lane / ACH, c = (lane % ACH) ^ kswz<ACH>(krow);
       const int col = min(m0 + c * 8, g.M - 8);
       offA[i] = (int64_t)krow * g.lda + col;
     }
@@ -98,11 +111,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       const int grow = min(n0 + row, g.N - 1);
       offB[i] = (int64_t)grow * g.ldb + c * 8;
     } else if constexpr (BN == 128) {
-      const int krow = ins * 4 + (lane >> 4), c = (lane & 15) ^ (krow & 15);
+      const int krow = ins * 4 + (lane >> 4), c = (lane & 15) ^ kswz<16>(krow);
       const int col = min(n0 + c * 8, g.N - 8);
       offB[i] = (int64_t)krow * g.ldb + col;
     } else {  // [64 k][64 n]: 8 k-rows x 128 B per instruction
-      const int krow = ins * 8 + (lane >> 3), c = (lane & 7) ^ (krow & 7);
+      const int krow = ins * 8 + (lane >> 3), c = (lane & 7) ^ kswz<8>(krow);
       const int col = min(n0 + c * 8, g.N - 8);
       offB[i] = (int64_t)krow * g.ldb + col;
     }
@@ -156,8 +169,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       } else {
         const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
         const int c = col >> 3, h = (col & 7) >> 2;
-        const h4 lo = lds_tr_read<h4>(bA + k * (BM * 2) + ((c ^ (k & (ACH - 1))) << 4) + h * 8);
-        const h4 hi = lds_tr_read<h4>(bA + (k + 4) * (BM * 2) + ((c ^ ((k + 4) & (ACH - 1))) << 4) + h * 8);
+        const h4 lo = lds_tr_read<h4>(bA + k * (BM * 2) + ((c ^ kswz<ACH>(k)) << 4) + h * 8);
+        const h4 hi = lds_tr_read<h4>(bA + (k + 4) * (BM * 2) + ((c ^ kswz<ACH>(k + 4)) << 4) + h * 8);
         af[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
@@ -167,11 +180,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
         const int row = wn0 + j * 16 + fr, c = kk * 4 + fq;
         bfr[j] = *reinterpret_cast<const h8*>(bB + row * 128 + ((c ^ (row & 7)) << 4));
       } else {
-        constexpr int ROWB = BN * 2, PM = BN / 8 - 1;
+        constexpr int ROWB = BN * 2;
         const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
         const int c = col >> 3, h = (col & 7) >> 2;
-        const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8);
-        const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8);
+        const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ kswz<BN / 8>(k)) << 4) + h * 8);
+        const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ kswz<BN / 8>(k + 4)) << 4) + h * 8);
         bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
@@ -260,8 +273,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
         } else {
           const int k = kk * 32 + fq * 8 + tq, col = wm0 + i * 16 + tp * 4;
           const int c = col >> 3, h = (col & 7) >> 2;
-          const h4 lo = lds_tr_read<h4>(bA + k * (BM * 2) + ((c ^ (k & (ACH - 1))) << 4) + h * 8);
-          const h4 hi = lds_tr_read<h4>(bA + (k + 4) * (BM * 2) + ((c ^ ((k + 4) & (ACH - 1))) << 4) + h * 8);
+          const h4 lo = lds_tr_read<h4>(bA + k * (BM * 2) + ((c ^ kswz<ACH>(k)) << 4) + h * 8);
+          const h4 hi = lds_tr_read<h4>(bA + (k + 4) * (BM * 2) + ((c ^ kswz<ACH>(k + 4)) << 4) + h * 8);
           af[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       }
@@ -271,11 +284,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
           const int row = wn0 + j * 16 + fr, c = kk * 4 + fq;
           bfr[j] = *reinterpret_cast<const h8*>(bB + row * 128 + ((c ^ (row & 7)) << 4));
         } else {
-          constexpr int ROWB = BN * 2, PM = BN / 8 - 1;
+          constexpr int ROWB = BN * 2;
           const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
           const int c = col >> 3, h = (col & 7) >> 2;
-          const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ (k & PM)) << 4) + h * 8);
-          const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ ((k + 4) & PM)) << 4) + h * 8);
+          const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ kswz<BN / 8>(k)) << 4) + h * 8);
+          const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ kswz<BN / 8>(k + 4)) << 4) + h * 8);
           bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       }
@@ -475,6 +488,12 @@ int d2r_gemm_glds_wgrad_try(const GemmArgs& a, const GemmGroup& grp, int n, hipS
     return 1;
   }
   dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), n);
+  static const int w8 = getenv("D2R_WGRAD_W8") ? atoi(getenv("D2R_WGRAD_W8")) : 0;  // the 128 x 128 tile on eight waves (wave tile 64 x 32)
+  if (w8) {
+    if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 4, 1, 1>), grid, dim3(512), 0, st, a, grp);
+    else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 4, 1, 1>), grid, dim3(512), 0, st, a, grp);
+    return 1;
+  }
   if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, 1>), grid, dim3(256), 0, st, a, grp);
   else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, 1>), grid, dim3(256), 0, st, a, grp);
   return 1;
