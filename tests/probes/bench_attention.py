@@ -3,6 +3,9 @@ usage: python tests/probes/bench_attention.py   -> us per launch and algorithmic
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+import d2r_amd._lib as _L
+if os.environ.get("PROBE_LIB"):  # A/B of two builds of the library in one GPU call
+    _L.LIB_PATH = os.path.abspath(os.environ["PROBE_LIB"])
 from d2r_amd import functional as F
 
 dev = torch.device("cuda:0")
