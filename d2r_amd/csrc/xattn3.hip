@@ -543,6 +543,27 @@ __device__ __forceinline__ typename H16<E>::v8 x3_frag_tr(const E* base, int k0,
   return E8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// Row permutation of the LDS images of both product kernels (bit 2 and bit 3 of the row index swap places): the eight rows one
+// 32-lane group of ds_read_b64_tr_b16 touches (k0 + {0..3, 8..11}, then + 4) become consecutive; with a row stride of an odd number of
+// 32-byte units (272 and 80 elements here) their 32-byte segments fall on eight different bank groups.
+__device__ __forceinline__ int dkv_prow(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// lane (fr, fq) gets M[k0 + 8 fq + j][c0 + fr], j = 0..7, from a row-permuted image with row stride LD (elements)
+template <typename E>
+__device__ __forceinline__ typename H16<E>::v8 dkv_frag(const E* base, int LD, int k0, int c0, int fq, int tq, int tp) {
+  typedef typename H16<E>::v4 E4;
+  typedef typename H16<E>::v8 E8;
+  const E* p0 = base + (k0 + (fq >> 1) * 16 + (fq & 1) * 4 + tq) * LD + c0 + tp * 4;  // = dkv_prow(k0 + fq*8 + tq)
+  const E4 lo = H16<E>::tr_read(p0);
+  const E4 hi = H16<E>::tr_read(p0 + 8 * LD);                                        // = dkv_prow(k0 + fq*8 + tq + 4)
+  return E8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__host__ __device__ __forceinline__ int dkv_ldw(int nmt) {  // row stride of the W image: columns + 16, an odd number of 16-element units
+  const int u = nmt + 1;
+  return (u | 1) * 16;
+}
+
 template <typename E>
 __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
   typedef typename H16<E>::v8 E8;
@@ -570,7 +591,7 @@ __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
       Pack<E, 8> v = ld_pack<E, 8>(Wg + (ok ? (int64_t)row * ldw + ch * 8 : 0));
 #pragma unroll
       for (int j = 0; j < 8; ++j) v.v[j] = (ok && ch * 8 + j < Md) ? v.v[j] : (E)0.f;
-      st_pack<E, 8>(sm + row * DKV_LDW + ch * 8, v);
+      st_pack<E, 8>(sm + dkv_prow(row) * DKV_LDW + ch * 8, v);
     }
   } else {
     // W is [m][k] in memory: read 16-byte packs along k, store them transposed (eight 2-byte stores)
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
       const bool ok = m < Md && ch * 8 < ldw;
       const Pack<E, 8> v = ld_pack<E, 8>(Wg + (ok ? (int64_t)m * ldw + ch * 8 : 0));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sm[(ch * 8 + j) * DKV_LDW + m] = (ok && ch * 8 + j < Kd) ? v.v[j] : (E)0.f;
+      for (int j = 0; j < 8; ++j) sm[dkv_prow(ch * 8 + j) * DKV_LDW + m] = (ok && ch * 8 + j < Kd) ? v.v[j] : (E)0.f;
     }
   }
   __syncthreads();
@@ -590,7 +611,7 @@ __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
 #pragma unroll
     for (int ks = 0; ks < KSM; ++ks) {
       const int n = min(wave + 8 * i, nmt - 1), k0 = min(ks, KS - 1) * 32;  // (clamped: unused fragments read valid LDS)
-      wf[i][ks] = x3_frag_tr<E, DKV_LDW>(sm, k0, n * 16, fq, tq, tp);
+      wf[i][ks] = dkv_frag<E>(sm, DKV_LDW, k0, n * 16, fq, tq, tp);
     }
   __syncthreads();  // the Wt image is dead: the region now holds the X chunks
   // ---- X in 64-column chunks: registers -> LDS (one chunk ahead in registers), out^T tile = X_chunk^T Wt ---------------------------
@@ -607,7 +628,7 @@ __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
       const int idx = tid + i * 512, row = idx >> 3, ch = idx & 7;
-      if (row < KP) st_pack<E, 8>(sm + row * DKV_LDX + ch * 8, xr[i]);
+      if (row < KP) st_pack<E, 8>(sm + dkv_prow(row) * DKV_LDX + ch * 8, xr[i]);
     }
   };
   xload(0);
@@ -625,7 +646,7 @@ __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
       if (ks < KS) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          const E8 af = x3_frag_tr<E, DKV_LDX>(sm, ks * 32, m * 16, fq, tq, tp);
+          const E8 af = dkv_frag<E>(sm, DKV_LDX, ks * 32, m * 16, fq, tq, tp);
 #pragma unroll
           for (int i = 0; i < 2; ++i) acc[i][m] = H16<E>::mfma32(af, wf[i][ks], acc[i][m]);
         }
@@ -657,24 +678,6 @@ __global__ __launch_bounds__(512) void xattn3_dkv_kernel(DkvArgs<E> a) {
 // which makes the eight rows one 32-lane group of ds_read_b64_tr_b16 touches (k0 + {0..3, 8..11}, then + 4) consecutive; with a row
 // stride of an odd number of 32-byte units their 32-byte segments fall on eight different bank groups (the natural order put rows
 // r and r + 8 on the same banks: SQ_LDS_BANK_CONFLICT was 55 % of the LDS cycles).
-__device__ __forceinline__ int dkv_prow(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
-
-// lane (fr, fq) gets M[k0 + 8 fq + j][c0 + fr], j = 0..7, from a row-permuted image with row stride LD (elements)
-template <typename E>
-__device__ __forceinline__ typename H16<E>::v8 dkv_frag(const E* base, int LD, int k0, int c0, int fq, int tq, int tp) {
-  typedef typename H16<E>::v4 E4;
-  typedef typename H16<E>::v8 E8;
-  const E* p0 = base + (k0 + (fq >> 1) * 16 + (fq & 1) * 4 + tq) * LD + c0 + tp * 4;  // = dkv_prow(k0 + fq*8 + tq)
-  const E4 lo = H16<E>::tr_read(p0);
-  const E4 hi = H16<E>::tr_read(p0 + 8 * LD);                                        // = dkv_prow(k0 + fq*8 + tq + 4)
-  return E8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-__host__ __device__ __forceinline__ int dkv_ldw(int nmt) {  // row stride of the W image: columns + 16, an odd number of 16-element units
-  const int u = nmt + 1;
-  return (u | 1) * 16;
-}
-
 template <typename E>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void xattn3_dkv2_kernel(DkvArgs<E> a) {
   typedef typename H16<E>::v8 E8;
@@ -843,7 +846,9 @@ int x3_dkv_launch(int ngroup, const void* const* W, const void* const* X, void* 
     const size_t need = (size_t)KP * (size_t)(dkv_ldw(nmt) > DKV_LDX ? dkv_ldw(nmt) : DKV_LDX) * sizeof(E);
     lds = need > lds ? need : lds;
   }
-  if (compact && lds <= 65536) {
+  // (only when the first kernel's one workgroup per CU would need a second round: with at most 256 workgroups it is the faster one,
+  //  54 against 59 us for the three products of one 128 x 128 problem)
+  if (compact && lds <= 65536 && (B + 7) / 8 * 8 * ngroup > 256) {
     hipLaunchKernelGGL((xattn3_dkv2_kernel<E>), dim3((B + 7) / 8 * 8 * ngroup), dim3(512), lds, st, a);
     return 1;
   }
