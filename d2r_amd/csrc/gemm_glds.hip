@@ -246,10 +246,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
     }
   } else {
   issue(0, 0);
+  unsigned long long ph_issue = 0, ph_wait = 0, ph_math = 0, ph_close = 0, ph_t = 0;  // (stamping only) cycles per phase, summed over the K loop
+#define GEMM_PHASE(acc_) do { if (stamping) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - ph_t; ph_t = n_; } } while (0)
+  if (stamping) ph_t = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     if (t + 1 < nk) {
       issue(t + 1, cur ^ 1);  // buffer cur^1 was last read in iteration t-1; every wave has passed its closing barrier
+      GEMM_PHASE(ph_issue);
       if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if constexpr (IA + IB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_barrier" ::: "memory");  // (asm + memory clobber: the compiler may not move LDS reads / DMA issues across it)
+    GEMM_PHASE(ph_wait);
     if (t == 0) GEMM_STAMP(1);
     // tile t has landed for every wave (own counted vmcnt + barrier)
     const unsigned char* bA = smem + cur * BUF;
@@ -306,8 +311,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
         for (int j = 0; j < TN; ++j)  // operands swapped: the accumulator tile is C^T, a lane owns ONE row and 4 consecutive columns
           acc[i][j] = H16<E>::mfma32(bfr[j], af[i], acc[i][j]);
     }
+    GEMM_PHASE(ph_math);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading buffer `cur` before it is refilled at t+1
+    GEMM_PHASE(ph_close);
   }
+  if (stamping && lane == 0) g.ts[wave * 8 + 4] = ph_issue, g.ts[wave * 8 + 5] = ph_wait, g.ts[wave * 8 + 6] = ph_math, g.ts[wave * 8 + 7] = ph_close;
+#undef GEMM_PHASE
 
   }
   GEMM_STAMP(2);

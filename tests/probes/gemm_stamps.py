@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.d2r_gemm_debug_stamps.argtypes = [C.c_void_p]
 lib.d2r_gemm_debug_stamps.restype = None
-buf = torch.zeros(8 * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(8 * 8, dtype=torch.int64, device=dev)  # [wave][0..3 stamps, 4..7 per-phase cycle sums]
 for lay, M, N, K in (("NN", 4096, 768, 768), ("NT", 4096, 768, 768), ("NN", 6304, 768, 3072), ("NT", 6304, 3072, 768), ("NT", 4096, 768, 3072),
                      ("NN", 6304, 3072, 768)):
     a = torch.randn(M, K, device=dev).bfloat16()
@@ -29,6 +29,7 @@ for lay, M, N, K in (("NN", 4096, 768, 768), ("NT", 4096, 768, 768), ("NN", 6304
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 50 * 1e3
+    buf.zero_()
     lib.d2r_gemm_debug_stamps(C.c_void_p(buf.data_ptr()))
     run()
     torch.cuda.synchronize()
@@ -37,4 +38,5 @@ for lay, M, N, K in (("NN", 4096, 768, 768), ("NT", 4096, 768, 768), ("NN", 6304
     r = t[0]
     nk = K // 64
     print(f"{lay} {M}x{N}x{K}: {us:6.1f} us back to back ({2.0 * M * N * K / us * 1e-6:.0f} TFLOP/s) | wave 0 of WG 0: to first tile {int(r[1] - r[0])}, "
-          f"K loop {int(r[2] - r[1])} = {int(r[2] - r[1]) / nk:.0f} per 64-deep step ({nk} steps), epilogue + drain {int(r[3] - r[2])}, total {int(r[3] - r[0])} cycles", flush=True)
+          f"K loop {int(r[2] - r[1])} = {int(r[2] - r[1]) / nk:.0f} per 64-deep step ({nk} steps), epilogue + drain {int(r[3] - r[2])}, total {int(r[3] - r[0])} cycles; "
+          f"per step (non-pipelined kernels): DMA issue {int(r[4]) / nk:.0f}, wait for the tile + barrier {int(r[5]) / nk:.0f}, fragment reads + MFMAs {int(r[6]) / nk:.0f}, closing barrier {int(r[7]) / nk:.0f}", flush=True)
