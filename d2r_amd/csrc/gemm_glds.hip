@@ -251,7 +251,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
   if (stamping) ph_t = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nk) {
+    if (PIPE == 2) {
+      // PIPE = 2: the next tile's DMA is issued BEHIND the first fragment reads of this step (below): the 270-470 cycles the six
+      // DMA instructions take to issue then run under the latency of those reads instead of in front of the step; at this point
+      // tile t is the only DMA in flight
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (t + 1 < nk) {
       issue(t + 1, cur ^ 1);  // buffer cur^1 was last read in iteration t-1; every wave has passed its closing barrier
       GEMM_PHASE(ph_issue);
       if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -295,6 +300,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
           const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ kswz<BN / 8>(k)) << 4) + h * 8);
           const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ kswz<BN / 8>(k + 4)) << 4) + h * 8);
           bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+      if constexpr (PIPE == 2) {
+        if (kk == 0 && t + 1 < nk) {
+          __builtin_amdgcn_sched_barrier(0);  // the reads above are issued; the DMA instructions go out while they are in flight
+          issue(t + 1, cur ^ 1);              // (buffer cur^1 was last read in iteration t-1, behind its closing barrier)
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr (!A_KCONT || !B_KCONT) lds_reads_done();  // (asm transposed reads are not tracked by the compiler)
@@ -425,6 +437,13 @@ static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
   static const GemmGroup no_group = {};
   const bool pipe = bn >= 1000;  // 1064 / 1128 / 1129: the software-pipelined K-loop
   if (pipe) bn -= 1000;
+  static const int late = getenv("D2R_GEMM_ISSUE_LATE") ? atoi(getenv("D2R_GEMM_ISSUE_LATE")) : 0;  // PIPE = 2 (A/B switch)
+  if (late && !pipe) {
+    if (bn == 129) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 4, 2>), dim3(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128)), dim3(512), 0, st, a, no_group);
+    else if (bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 2, 2>), dim3(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128)), dim3(256), 0, st, a, no_group);
+    else hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 64, 2, 2>), dim3(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 128)), dim3(256), 0, st, a, no_group);
+    return;
+  }
   if (bn == 129) {  // 128 x 128 tile on EIGHT waves (2 x 4): per wave as the 128x64 kernel, a third less L2 traffic per flop
     dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
     if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 4, 1>), grid, dim3(512), 0, st, a, no_group);
