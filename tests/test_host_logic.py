@@ -188,3 +188,42 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(ROOT, "d2r_amd", fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_profile_tools_on_a_synthetic_trace(tmp_path):
+    """profiles/make_step_gaps.py and the kernel-name -> row mapping of profiles/make_pmc_summary.py on a hand-made trace: two
+    queues, three optimiser steps, one known gap."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    trace = tmp_path / "t_kernel_trace.csv"
+    rows = []
+    t = 0
+    for step in range(3):
+        for i in range(4):  # queue 1: four back-to-back kernels of 10 us, queue 2: one kernel of 25 us overlapping them
+            rows.append(dict(Kernel_Name="gemm_glds_kernel", Queue_Id="1", Start_Timestamp=t + i * 10_000, End_Timestamp=t + i * 10_000 + 10_000))
+        rows.append(dict(Kernel_Name="xattn3_fwd_kernel", Queue_Id="2", Start_Timestamp=t + 5_000, End_Timestamp=t + 30_000))
+        rows.append(dict(Kernel_Name="adamw_kernel", Queue_Id="1", Start_Timestamp=t + 50_000, End_Timestamp=t + 60_000))  # 10 us idle before it
+        t += 10_000_000
+    with open(trace, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    out = tmp_path / "gaps.json"
+    subprocess.run([sys.executable, os.path.join(root, "profiles", "make_step_gaps.py"), str(trace), str(out)], check=True, capture_output=True)
+    g = json.load(open(out))
+    assert g["full_steps"] == 2 and g["last_step"]["launches"] == 6
+    q1 = g["last_step"]["queues"]["1"]
+    assert q1["launches"] == 5 and abs(q1["gap_sum_ms"] - 0.010) < 1e-9 and q1["gaps_over_5us"] == 1
+    assert abs(g["last_step"]["idle_ms"] - 0.010) < 1e-9 and abs(g["last_step"]["busy_union_ms"] - 0.050) < 1e-9
+    # kernel names as rocprofv3 prints them -> rows of pmc_traffic_*.json
+    src = open(os.path.join(root, "profiles", "make_pmc_summary.py")).read()
+    ns = {}
+    exec(src[:src.index("def load(")], ns)
+    fam = ns["family"]
+    assert fam("_Z16gemm_glds_kernelIDF16_Li2ELi128ELi2ELi1ELi1ELi2EEv8GemmArgs9GemmGroup") == ("gemm_f16_TN_grouped_ldsdma128x128", True)
+    assert fam("_Z16gemm_glds_kernelIDF16bLi1ELi64ELi2ELi0ELi0ELi2EEv8GemmArgs9GemmGroup") == ("gemm_bf16_NN_ldsdma128x64", True)
+    assert fam("_ZN12_GLOBAL__N_118xattn3_dkv2_kernelIDF16_EEvNS_7DkvArgsIT_EE") == ("xattn_core_bwd", False)
+    assert fam("_Z22gemm_skinny_h16_kernelIDF16_Li0EEv8GemmArgs") == ("gemm_f16_NT_skinny", True)
