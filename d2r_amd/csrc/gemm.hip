@@ -503,14 +503,17 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   const int r0 = min(fr, g.M - 1), r1 = min(16 + fr, g.M - 1);
   const bool two = g.M > 16;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const int ksteps = g.K / 64;                         // per wave: K / 4 in steps of 16
-  for (int s0 = 0; s0 < ksteps; s0 += MAXS) {
-    const int ns = min(MAXS, ksteps - s0);
+  // the K / 16 steps of 16 are dealt to the four waves in contiguous runs (round 3: K a multiple of 16, not of 64: Block's 80- and
+  // 1200-deep chunk products took the tiled kernel, 12 and 52 us each on the serial stretch between forward and backward)
+  const int k16 = g.K / 16, per = (k16 + 3) / 4;
+  const int kbeg = min(wave * per, k16), kend = min(kbeg + per, k16);
+  for (int s0 = kbeg; s0 < kbeg + per; s0 += MAXS) {
+    const int ns = max(0, min(MAXS, kend - s0));
     f32x4 a0[MAXS], a1[MAXS], b[MAXS];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
       if (s < ns) {
-        const int k = (wave * ksteps + s0 + s) * 16 + fq * 4;
+        const int k = (s0 + s) * 16 + fq * 4;
         a0[s] = *reinterpret_cast<const f32x4*>(A + (int64_t)r0 * g.lda + k);
         if (two) a1[s] = *reinterpret_cast<const f32x4*>(A + (int64_t)r1 * g.lda + k);
         if constexpr (LAYOUT == D2R_GEMM_NT) {
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
 static int g_skinny = env_int("D2R_GEMM_SKINNY", 1);
 template <int LAYOUT>
 static bool skinny_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
-  if (!g_skinny || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 64 != 0 || a.c_dtype != D2R_F32 || a.G || a.dbias || !a.vecA) return false;
+  if (!g_skinny || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 16 != 0 || a.c_dtype != D2R_F32 || a.G || a.dbias || !a.vecA) return false;
   if (LAYOUT == D2R_GEMM_NT && !a.vecB) return false;
   hipLaunchKernelGGL((gemm_skinny_f32_kernel<LAYOUT>), dim3(d2r_cdiv(a.N, 16), 1, batch), dim3(256), 0, st, a);
   d2r_gemm_variant_tl = 30;
