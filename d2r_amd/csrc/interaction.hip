@@ -599,7 +599,7 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, K.i_dsum, dqkv, E3, sb3,
                     dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
     TRY(dxg(c, T, E, 3 * E, dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
-    TRY(dwg(c, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]));
+    defer(jobs, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]);  // (with the other layers' q|k|v gradients: one grouped launch per module)
   }
   // --- GESC ------------------------------------------------------------------------------------------------------------
   if (nc > 5) {
