@@ -71,8 +71,21 @@ class InteractionDesc(C.Structure):
                 ("scratch", vp), ("scratch_bytes", sz), ("kv_all", LinearParams)]
 
 
+class HeadDesc(C.Structure):
+    _fields_ = [("B", i32), ("E", i32), ("mm", i32), ("chunks", i32), ("rank", i32), ("classes", i32),
+                ("lin0", LinearParams), ("lin1", LinearParams), ("merge0", LinearParams), ("merge1", LinearParams),
+                ("lin_out", LinearParams), ("fc", LinearParams), ("x0", vp), ("x1", vp), ("labels", vp), ("js", vp),
+                ("loss", vp), ("logits", vp), ("pooled", vp), ("arena", vp), ("arena_bytes", sz), ("splitk_ws", vp),
+                ("splitk_bytes", sz), ("d_loss", vp), ("d_x0", vp), ("d_x1", vp), ("d_js", vp), ("scratch", vp),
+                ("scratch_bytes", sz)]
+
+
 # name -> (restype, argtypes); every symbol include/d2r_hip.h declares
 SIGNATURES = {
+    "d2r_head_arena_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "d2r_head_bwd_scratch": (sz, [i32, i32, i32, i32, i32, i32]),
+    "d2r_head_fwd": (i32, [C.POINTER(HeadDesc), vp]),
+    "d2r_head_bwd": (i32, [C.POINTER(HeadDesc), vp]),
     "d2r_version": (C.c_char_p, []),
     "d2r_last_error": (C.c_char_p, []),
     "d2r_gemm": (i32, [C.POINTER(GemmDesc), vp]),

@@ -733,3 +733,140 @@ extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) 
   }
   return flush_jobs(c, jobs);
 }
+
+// ======================================================================================================================================
+// K17: the classification head as one call each way (Block fusion -> fc -> cross entropy -> loss = ce + js), fp32 throughout.
+// The same launches, in the same order, with the same descriptors as the op-by-op path of d2r_amd/modules.py (Block.forward,
+// UnimoModelF.forward) - what goes away is the host time between them: this is the one stretch of a training step where both
+// branch streams are idle (forward of the head, then its backward, ~35 short launches), and it was paced by the host.
+// ======================================================================================================================================
+namespace {
+
+struct HeadDims {
+  int B, E, mm, chunks, rank, size, RS, classes;
+  size_t n_h, n_m;  // floats per [B, mm] and [B, chunks * rank * size] tensor
+};
+int head_dims(const d2r_head_desc* D, HeadDims& h) {
+  D2R_REQUIRE(D && D->B >= 1 && D->E >= 16 && D->mm >= 16 && D->chunks >= 1 && D->rank >= 1 && D->classes >= 1, "d2r_head: bad sizes");
+  D2R_REQUIRE(D->mm % D->chunks == 0, "d2r_head: mm must be a multiple of chunks");
+  h.B = D->B, h.E = D->E, h.mm = D->mm, h.chunks = D->chunks, h.rank = D->rank, h.size = D->mm / D->chunks, h.classes = D->classes;
+  h.RS = h.rank * h.size;
+  h.n_h = (size_t)h.B * h.mm, h.n_m = (size_t)h.B * h.chunks * h.RS;
+  return D2R_OK;
+}
+struct HeadActs {  // forward activations kept for the backward pass (arena)
+  float *h0, *h1, *m0, *m1, *z, *zraw, *ce;
+};
+void head_plan(Arena& A, const HeadDims& h, HeadActs& a) {
+  a.h0 = (float*)A.take(h.n_h * 4), a.h1 = (float*)A.take(h.n_h * 4), a.m0 = (float*)A.take(h.n_m * 4), a.m1 = (float*)A.take(h.n_m * 4);
+  a.z = (float*)A.take(h.n_h * 4), a.zraw = (float*)A.take(h.n_h * 4), a.ce = (float*)A.take(16);
+}
+struct HeadGrads {  // backward scratch
+  float *dlogits, *dpooled, *dz, *dm0, *dm1, *dh0, *dh1, *tmpb;
+  void* csws;
+  size_t cswsb;
+};
+void head_plan_bwd(Arena& Z, const HeadDims& h, HeadGrads& g) {
+  g.dlogits = (float*)Z.take((size_t)h.B * h.classes * 4), g.dpooled = (float*)Z.take((size_t)h.B * h.E * 4), g.dz = (float*)Z.take(h.n_h * 4);
+  g.dm0 = (float*)Z.take(h.n_m * 4), g.dm1 = (float*)Z.take(h.n_m * 4), g.dh0 = (float*)Z.take(h.n_h * 4), g.dh1 = (float*)Z.take(h.n_h * 4);
+  g.tmpb = (float*)Z.take((size_t)h.chunks * h.RS * 4);
+  g.cswsb = d2r_colsum_workspace(h.B, h.chunks * h.RS);
+  g.csws = Z.take(g.cswsb);
+}
+// the `chunks` rank projections of one side as ONE batched product: y[:, c] = x[:, c] W_c^T + b_c  (x [B, mm], W_c [RS, size])
+int head_merge_fwd(const Ctx& c, const HeadDims& h, const float* x, const d2r_linear_params& p, float* y) {
+  G g(D2R_F32, D2R_F32, D2R_GEMM_NT, h.B, h.RS, h.size, x, h.mm, p.w, h.size, y, (int64_t)h.chunks * h.RS);
+  g.batch(h.chunks, h.size, (int64_t)h.RS * h.size, h.RS);
+  g.d.bias = p.b, g.d.s_bias_b = h.RS;
+  return d2r_gemm(&g.d, c.st);
+}
+int head_merge_bwd(const Ctx& c, const HeadDims& h, const float* x, const d2r_linear_params& p, const float* dy, float* dx, const HeadGrads& s) {
+  {
+    G g(D2R_F32, D2R_F32, D2R_GEMM_NN, h.B, h.size, h.RS, dy, (int64_t)h.chunks * h.RS, p.w, h.size, dx, h.mm);
+    g.batch(h.chunks, h.RS, (int64_t)h.RS * h.size, h.size);
+    TRY(d2r_gemm(&g.d, c.st));
+  }
+  {
+    G g(D2R_F32, D2R_F32, D2R_GEMM_TN, h.RS, h.size, h.B, dy, (int64_t)h.chunks * h.RS, x, h.mm, p.gw, h.size);
+    g.batch(h.chunks, h.RS, h.size, (int64_t)h.RS * h.size);
+    g.d.beta = 1.f;
+    TRY(d2r_gemm(&g.d, c.st));
+  }
+  TRY(d2r_colsum(D2R_F32, dy, (int64_t)h.chunks * h.RS, h.B, h.chunks * h.RS, s.tmpb, s.csws, s.cswsb, c.st));
+  return d2r_axpby(D2R_F32, 1.f, s.tmpb, 1.f, p.gb, (int64_t)h.chunks * h.RS, c.st);
+}
+
+}  // namespace
+
+extern "C" size_t d2r_head_arena_bytes(int B, int E, int mm, int chunks, int rank, int classes) {
+  d2r_head_desc D = {};
+  D.B = B, D.E = E, D.mm = mm, D.chunks = chunks, D.rank = rank, D.classes = classes;
+  HeadDims h;
+  if (head_dims(&D, h) != D2R_OK) return 0;
+  Arena A(nullptr);
+  HeadActs a;
+  head_plan(A, h, a);
+  return A.off;
+}
+extern "C" size_t d2r_head_bwd_scratch(int B, int E, int mm, int chunks, int rank, int classes) {
+  d2r_head_desc D = {};
+  D.B = B, D.E = E, D.mm = mm, D.chunks = chunks, D.rank = rank, D.classes = classes;
+  HeadDims h;
+  if (head_dims(&D, h) != D2R_OK) return 0;
+  Arena Z(nullptr);
+  HeadGrads g;
+  head_plan_bwd(Z, h, g);
+  return Z.off;
+}
+
+extern "C" int d2r_head_fwd(const d2r_head_desc* D, void* stream) {
+  HeadDims h;
+  TRY(head_dims(D, h));
+  D2R_REQUIRE(D->x0 && D->x1 && D->labels && D->js && D->loss && D->logits && D->pooled && D->arena, "d2r_head_fwd: null pointer");
+  D2R_REQUIRE(D->arena_bytes >= d2r_head_arena_bytes(h.B, h.E, h.mm, h.chunks, h.rank, h.classes), "d2r_head_fwd: arena too small");
+  const Ctx c{D2R_F32, stream, D->splitk_ws, D->splitk_bytes};
+  Arena A(D->arena);
+  HeadActs a;
+  head_plan(A, h, a);
+  TRY(lin(c, h.B, h.mm, h.E, D->x0, h.E, D->lin0, a.h0));
+  TRY(lin(c, h.B, h.mm, h.E, D->x1, h.E, D->lin1, a.h1));
+  TRY(head_merge_fwd(c, h, a.h0, D->merge0, a.m0));
+  TRY(head_merge_fwd(c, h, a.h1, D->merge1, a.m1));
+  TRY(d2r_block_merge_fwd(D2R_F32, a.m0, a.m1, h.B, h.chunks, h.rank, h.size, a.z, a.zraw, stream));
+  TRY(lin(c, h.B, h.E, h.mm, a.z, h.mm, D->lin_out, D->pooled));
+  TRY(lin(c, h.B, h.classes, h.E, D->pooled, h.E, D->fc, D->logits));
+  TRY(d2r_ce_fwd(D->logits, D->labels, h.B, h.classes, a.ce, stream));
+  const float* xs[2] = {a.ce, D->js};
+  const float coef[2] = {1.f, 1.f};
+  return d2r_lincomb(xs, coef, 2, D->loss, stream);
+}
+
+extern "C" int d2r_head_bwd(const d2r_head_desc* D, void* stream) {
+  HeadDims h;
+  TRY(head_dims(D, h));
+  D2R_REQUIRE(D->x0 && D->x1 && D->labels && D->logits && D->pooled && D->arena && D->d_loss && D->d_x0 && D->d_x1 && D->d_js && D->scratch,
+              "d2r_head_bwd: null pointer");
+  D2R_REQUIRE(D->scratch_bytes >= d2r_head_bwd_scratch(h.B, h.E, h.mm, h.chunks, h.rank, h.classes), "d2r_head_bwd: scratch too small");
+  for (const d2r_linear_params* p : {&D->lin0, &D->lin1, &D->merge0, &D->merge1, &D->lin_out, &D->fc})
+    D2R_REQUIRE(p->gw && p->gb, "d2r_head_bwd: every linear needs its gradient sinks");
+  const Ctx c{D2R_F32, stream, D->splitk_ws, D->splitk_bytes};
+  Arena A(D->arena), Z(D->scratch);
+  HeadActs a;
+  HeadGrads g;
+  head_plan(A, h, a);
+  head_plan_bwd(Z, h, g);
+  TRY(d2r_axpby(D2R_F32, 1.f, D->d_loss, 0.f, D->d_js, 1, stream));  // loss = ce + js
+  TRY(d2r_ce_bwd(D->logits, D->labels, h.B, h.classes, D->d_loss, g.dlogits, stream));
+  TRY(dxg(c, h.B, h.E, h.classes, g.dlogits, h.classes, D->fc.w, g.dpooled, h.E));
+  TRY(dwg(c, h.B, h.classes, h.E, g.dlogits, h.classes, D->pooled, h.E, D->fc));
+  TRY(dxg(c, h.B, h.mm, h.E, g.dpooled, h.E, D->lin_out.w, g.dz, h.mm));
+  TRY(dwg(c, h.B, h.E, h.mm, g.dpooled, h.E, a.z, h.mm, D->lin_out));
+  TRY(d2r_block_merge_bwd(D2R_F32, a.m0, a.m1, a.zraw, g.dz, h.B, h.chunks, h.rank, h.size, g.dm0, g.dm1, stream));
+  TRY(head_merge_bwd(c, h, a.h0, D->merge0, g.dm0, g.dh0, g));
+  TRY(head_merge_bwd(c, h, a.h1, D->merge1, g.dm1, g.dh1, g));
+  TRY(dxg(c, h.B, h.E, h.mm, g.dh0, h.mm, D->lin0.w, D->d_x0, h.E));
+  TRY(dwg(c, h.B, h.mm, h.E, g.dh0, h.mm, D->x0, h.E, D->lin0));
+  TRY(dxg(c, h.B, h.E, h.mm, g.dh1, h.mm, D->lin1.w, D->d_x1, h.E));
+  return dwg(c, h.B, h.mm, h.E, g.dh1, h.mm, D->x1, h.E, D->lin1);
+}
+

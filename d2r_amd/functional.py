@@ -1029,6 +1029,89 @@ class _Interaction(torch.autograd.Function):
         return d_own, d_other, None, None, None
 
 
+class HeadBundle:
+    """Parameter table of the classification head (Block fusion + fc) for the one-call path (d2r_head_fwd / d2r_head_bwd): fp32
+    weights and their fp32 gradient sinks.  linears: (weight, bias) pairs in the order lin0, lin1, merge0, merge1, lin_out, fc
+    (merge0 / merge1: the fused [chunks * rank * size, size] groups of Block's rank projections)."""
+
+    def __init__(self, linears, mm: int, chunks: int, rank: int):
+        self.params = []
+        self.lp = []
+        for w, b in linears:
+            for t in (w, b):
+                if t.dtype != torch.float32 or not t.is_cuda or getattr(t, "_d2r_grad", None) is None:
+                    raise _lib.D2RError("HeadBundle: fp32 parameters prepared by ParamStore (gradient sinks) are required")
+            self.lp.append(_lib.LinearParams(w.data_ptr(), b.data_ptr(), w._d2r_grad.data_ptr(), b._d2r_grad.data_ptr()))
+            self.params += [w, b]
+        (w0, _), (wm, _), (wo, _), (wf, _) = linears[0], linears[2], linears[4], linears[5]
+        self.E, self.mm, self.chunks, self.rank, self.classes = w0.shape[1], int(mm), int(chunks), int(rank), wf.shape[0]
+        size = self.mm // self.chunks
+        if w0.shape != (self.mm, self.E) or wm.shape != (self.chunks * self.rank * size, size) or wo.shape != (self.E, self.mm):
+            raise _lib.D2RError("HeadBundle: unexpected parameter shapes")
+        self.key = (w0.data_ptr(), w0._d2r_grad.data_ptr())
+
+
+class _Head(torch.autograd.Function):
+    """(loss, logits, pooled) = head(text_pooled, vision_pooled, js_loss, labels): ONE C call each way.  Only `loss` carries a
+    gradient (the end of the training graph); a gradient arriving at logits / pooled is refused."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, js, labels, anchor, bundle):
+        x0, x1, js = x0.contiguous(), x1.contiguous(), js.contiguous()
+        labels = labels.contiguous().long()
+        B = x0.shape[0]
+        lib = _lib.load()
+        d = _lib.HeadDesc()
+        d.B, d.E, d.mm, d.chunks, d.rank, d.classes = B, bundle.E, bundle.mm, bundle.chunks, bundle.rank, bundle.classes
+        d.lin0, d.lin1, d.merge0, d.merge1, d.lin_out, d.fc = bundle.lp
+        loss = torch.empty((), dtype=torch.float32, device=x0.device)
+        logits = torch.empty(B, bundle.classes, dtype=torch.float32, device=x0.device)
+        pooled = torch.empty(B, bundle.E, dtype=torch.float32, device=x0.device)
+        arena = torch.empty(lib.d2r_head_arena_bytes(B, bundle.E, bundle.mm, bundle.chunks, bundle.rank, bundle.classes), dtype=torch.uint8,
+                            device=x0.device)
+        ws = _workspace(64 << 20, x0.device)
+        d.x0, d.x1, d.labels, d.js = x0.data_ptr(), x1.data_ptr(), labels.data_ptr(), js.data_ptr()
+        d.loss, d.logits, d.pooled = loss.data_ptr(), logits.data_ptr(), pooled.data_ptr()
+        d.arena, d.arena_bytes, d.splitk_ws, d.splitk_bytes = arena.data_ptr(), arena.numel(), ws.data_ptr(), ws.numel()
+        _lib.call("d2r_head_fwd", C.byref(d), _stream(), meta=dict(group="head_fwd"))
+        ctx.save_for_backward(x0, x1, labels, logits, pooled)
+        ctx.d, ctx.keep, ctx.bundle = d, arena, bundle
+        ctx.set_materialize_grads(False)
+        return loss, logits, pooled
+
+    @staticmethod
+    def backward(ctx, g_loss, g_logits, g_pooled):
+        _ensure_backward_join()
+        if g_logits is not None or g_pooled is not None:
+            raise NotImplementedError("the one-call head differentiates the loss only; set D2R_COMPOSITE_HEAD=0 to backpropagate "
+                                      "through logits or the pooled output")
+        x0, x1, labels, logits, pooled = ctx.saved_tensors
+        d, bundle = ctx.d, ctx.bundle
+        d_x0, d_x1 = torch.empty_like(x0), torch.empty_like(x1)
+        d_js = torch.empty((), dtype=torch.float32, device=x0.device)
+        if g_loss is None:
+            return d_x0.zero_(), d_x1.zero_(), d_js.zero_(), None, None, None
+        g_loss = g_loss.contiguous()
+        lib = _lib.load()
+        scratch = torch.empty(lib.d2r_head_bwd_scratch(d.B, d.E, d.mm, d.chunks, d.rank, d.classes), dtype=torch.uint8, device=x0.device)
+        ws = _workspace(64 << 20, x0.device)
+        d.splitk_ws, d.splitk_bytes = ws.data_ptr(), ws.numel()
+        d.d_loss, d.d_x0, d.d_x1, d.d_js = g_loss.data_ptr(), d_x0.data_ptr(), d_x1.data_ptr(), d_js.data_ptr()
+        d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
+        _lib.call("d2r_head_bwd", C.byref(d), _stream(), meta=dict(group="head_bwd"))
+        ctx.keep = None
+        for p in bundle.params:  # data-parallel bucket readiness: every sink of the head is written now
+            cb = getattr(p, "_d2r_ready_cb", None)
+            if cb is not None:
+                cb(p)
+        return d_x0, d_x1, d_js, None, None, None
+
+
+def head(x0, x1, js, labels, bundle: HeadBundle):
+    """Block fusion + fc + cross entropy + (ce + js) as a single autograd node: -> (loss, logits [B, classes], pooled [B, 768])."""
+    return _Head.apply(x0, x1, js, labels, bundle.params[0], bundle)
+
+
 def interaction(own, other, bundle: InteractionBundle, train: bool):
     """One whole (Reversed_)InteractionModule as a single autograd node: -> (emb [B,Lq,768], paths fp32 [B,total_paths])."""
     return _Interaction.apply(own, other, bundle.params[0], bundle, bool(train))

@@ -556,6 +556,7 @@ class Reversed_InteractionModule(_InteractionBase):
 # ------------------------------------------------------------------------------------------------------
 INTERLEAVE_ENCODERS = os.environ.get("D2R_INTERLEAVE", "1") != "0"  # issue the two encoders layer by layer in alternation
 COMPOSITE_LAYERS = os.environ.get("D2R_COMPOSITE", "1") != "0"  # whole encoder layers as one C call (bf16 only)
+COMPOSITE_HEAD = os.environ.get("D2R_COMPOSITE_HEAD", "1") != "0"  # Block fusion + fc + cross entropy + loss as one C call each way (fp32)
 COMPOSITE_ROUTING = os.environ.get("D2R_COMPOSITE_ROUTING", "1") != "0"  # whole interaction modules as one C call (bf16 only)
 
 
@@ -854,8 +855,31 @@ class UnimoModel(D2RModule):
         self._streams = None
         self._param_gate = None  # set by FusedAdamW.overlap_with_forward(model)
 
-    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, pixel_values=None):
-        """-> (pooler_output [B,768], js_loss, aux) — models/modeling_unimo.py:786-894."""
+    def _head_bundle(self, fc):
+        """The cached HeadBundle when the one-call head applies (fp32 parameters with gradient sinks, the 20 + 20 merge groups
+        fused by ParamStore), else None."""
+        if not COMPOSITE_HEAD:
+            return None
+        blk = self.block_fusion
+        f0, f1 = blk._fused_linear("m0"), blk._fused_linear("m1")
+        w0 = blk.linear0.weight
+        if f0 is None or f1 is None or getattr(w0, "_d2r_grad", None) is None or not w0.is_cuda:
+            return None
+        b = getattr(self, "_head_cache", None)
+        if b is None or b[0] is not fc or b[1].key != (w0.data_ptr(), w0._d2r_grad.data_ptr()):
+            try:
+                hb = F.HeadBundle([(blk.linear0.weight, blk.linear0.bias), (blk.linear1.weight, blk.linear1.bias), (f0.weight, f0.bias),
+                                   (f1.weight, f1.bias), (blk.linear_out.weight, blk.linear_out.bias), (fc.weight, fc.bias)],
+                                  blk.mm_dim, blk.chunks, blk.rank)
+            except F._lib.D2RError:
+                return None
+            b = self._head_cache = (fc, hb)
+        return b[1]
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, pixel_values=None, head=None):
+        """-> (pooler_output [B,768], js_loss, aux) — models/modeling_unimo.py:786-894.
+        head = (fc Linear, labels): UnimoModelF's classifier and loss are computed here, together with Block, as one C call
+        (aux["loss"], aux["logits"]) when the one-call head applies."""
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if token_type_ids is None:
@@ -953,9 +977,15 @@ class UnimoModel(D2RModule):
             for x in (js1, js2, tp, vp_, emb_t, emb_v, sim_paths, rev_sim_paths, t_enc, v_enc):
                 x.record_stream(main)
         js_loss = F.lincomb([-self.args.weight_js_1, -self.args.weight_js_2], [js1, js2])
-        pooled = self.block_fusion([tp, vp_])
         aux = dict(emb_text=emb_t, emb_image=emb_v, sim_paths=sim_paths, rev_sim_paths=rev_sim_paths,
                    text_encode_out=t_enc, vision_encode_out=v_enc, text_pooled=tp, vision_pooled=vp_)
+        hb = self._head_bundle(head[0]) if head is not None and tp.dtype == torch.float32 and tp.is_cuda else None
+        if hb is not None:
+            # the one stretch of a step where both branch streams wait for the launching stream: ~35 short launches of the
+            # head's forward and backward, paced by the host when issued op by op -> one call each way
+            aux["loss"], aux["logits"], pooled = F.head(tp, vp_, js_loss, head[1], hb)
+        else:
+            pooled = self.block_fusion([tp, vp_])
         return pooled, js_loss, aux
 
 
@@ -971,9 +1001,12 @@ class UnimoModelF(D2RModule):
 
     def forward(self, input_ids, attention_mask, token_type_ids, labels, images):
         pooled, js_loss, aux = self.model(input_ids=input_ids, attention_mask=attention_mask,
-                                          token_type_ids=token_type_ids, pixel_values=images)
-        logits = self.fc(pooled, fp32=True)
-        loss = F.lincomb([1.0, 1.0], [F.cross_entropy(logits, labels), js_loss])
+                                          token_type_ids=token_type_ids, pixel_values=images, head=(self.fc, labels))
+        if "loss" in aux:  # Block, fc, cross entropy and the sum were one call inside the model
+            loss, logits = aux.pop("loss"), aux.pop("logits")
+        else:
+            logits = self.fc(pooled, fp32=True)
+            loss = F.lincomb([1.0, 1.0], [F.cross_entropy(logits, labels), js_loss])
         aux["js_loss"] = js_loss
         self.last_aux = aux
         return loss, logits

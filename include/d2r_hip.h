@@ -456,6 +456,33 @@ int d2r_interaction_fwd(const d2r_interaction_desc* d, void* stream);
 int d2r_interaction_bwd(const d2r_interaction_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K17 the classification head as ONE call each way, fp32: Block fusion of the two pooled vectors (models/XModules.py:478-555:
+ * linear0 / linear1 [mm, E], `chunks` rank-`rank` merge projections per side, product, sum over the rank, signed square root,
+ * per-chunk l2 normalisation, linear_out [E, mm]), fc [classes, E] (models/unimo_model.py:156-158), cross entropy and
+ * loss = ce + js (models/unimo_model.py:160).  The same launches in the same order as the single-op entry points
+ * (d2r_gemm, d2r_block_merge_*, d2r_ce_*, d2r_lincomb); parameter gradients ACCUMULATE into the caller's fp32 sinks.
+ * merge0 / merge1: the `chunks` projections of a side back to back, [chunks * rank * (mm / chunks), mm / chunks].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int B, E, mm, chunks, rank, classes;
+  d2r_linear_params lin0, lin1, merge0, merge1, lin_out, fc;   /* fp32 weights */
+  const float* x0; const float* x1;     /* fp32 [B, E]: pooled text / image vectors (Block's two inputs) */
+  const int64_t* labels;                /* [B] */
+  const float* js;                      /* fp32 [1]: the JS term of the loss */
+  float* loss; float* logits; float* pooled;   /* [1], [B, classes], [B, E] (Block's output)  OVERWRITTEN */
+  void* arena; size_t arena_bytes;      /* forward activations kept for the backward call: >= d2r_head_arena_bytes() */
+  void* splitk_ws; size_t splitk_bytes; /* split-K scratch of the weight-gradient GEMMs (may be NULL) */
+  /* backward only */
+  const float* d_loss;                  /* fp32 [1] */
+  float* d_x0; float* d_x1; float* d_js;       /* [B, E], [B, E], [1]  OVERWRITTEN */
+  void* scratch; size_t scratch_bytes;  /* >= d2r_head_bwd_scratch() */
+} d2r_head_desc;
+size_t d2r_head_arena_bytes(int B, int E, int mm, int chunks, int rank, int classes);
+size_t d2r_head_bwd_scratch(int B, int E, int mm, int chunks, int rank, int classes);
+int d2r_head_fwd(const d2r_head_desc* d, void* stream);
+int d2r_head_bwd(const d2r_head_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K12 embeddings (models/modeling_unimo.py:87-118, 272-331)
  * ------------------------------------------------------------------------------------------------ */
 /* out[b,l,:] = word[ids[b,l]] + pos[l] + type[tt[b,l]]   (tables fp32, out dtype T; LayerNorm separately) */

@@ -664,6 +664,43 @@ def test_interaction_module_one_call_matches_op_by_op(gpu, cfg, lowp):
     print(f"[{cfg}] one-call vs op-by-op: d_own {rel(do1, do0):.2e} d_other {rel(dt1, dt0):.2e} worst parameter gradient {worst[0]} {worst[1]:.2e}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "fp16"])
+def test_head_one_call_matches_op_by_op(gpu, dtype):
+    """d2r_head_fwd / d2r_head_bwd (K17: Block fusion + fc + cross entropy + loss as one C call each way) against the op-by-op path
+    on a whole tiny model: the same launches with the same descriptors, so loss, logits and EVERY parameter gradient are
+    bit-identical (the head runs in fp32 in every compute mode)."""
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    from oracle import d2r_oracle as O
+    cfg = O.OracleConfig(text_layers=1, vision_layers=1, image_size=64, patch_size=32)
+    sd = O.seeded_state_dict(cfg, seed=3, router_bias="normal")
+    batch = tuple(t.to(gpu) for t in O.synthetic_batch(cfg, 5, 12, seed=4))
+    res = {}
+    for composite in (False, True):
+        M.COMPOSITE_HEAD = composite
+        try:
+            tc = TextConfig(num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+            vc = VisionConfig(num_hidden_layers=1, image_size=64, patch_size=32)
+            model = M.UnimoModelF(default_args(), vc, tc)
+            model.load_state_dict(sd, strict=True)
+            model.to(gpu).set_compute_dtype(dtype).train()
+            model.model.use_streams = False
+            store = ParamStore(model, dtype)
+            loss, logits = model(*batch)
+            assert ("_HeadBackward" in repr(loss.grad_fn)) == composite, loss.grad_fn
+            (loss * 64.0).backward()
+            torch.cuda.synchronize()
+            res[composite] = (loss.detach().clone(), logits.detach().clone(), store.flat_g.clone(), [(n, o, k) for n, _, o, k, _ in store.entries])
+        finally:
+            M.COMPOSITE_HEAD = True
+    (l0, g0, f0, ent), (l1, g1, f1, _) = res[False], res[True]
+    assert torch.equal(l0, l1) and torch.equal(g0, g1), (float(l0), float(l1))
+    bad = [n for n, o, k in ent if not torch.equal(f0[o:o + k], f1[o:o + k])]
+    assert not bad, f"{len(bad)} parameter gradients differ, first {bad[:5]}"
+    assert float(f1.abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_dropout_kernel(gpu, dtype):
     """nn.Dropout semantics: keep fraction 1-p, survivors scaled by 1/(1-p), residual add fused, mask = pure function
