@@ -68,7 +68,8 @@ class InteractionDesc(C.Structure):
                 ("heads_imrc", i32), ("hid_imrc", i32), ("train", i32), ("layers", C.POINTER(RoutingLayerParams)),
                 ("own", vp), ("other", vp), ("out", vp), ("paths", vp), ("arena", vp), ("arena_bytes", sz),
                 ("splitk_ws", vp), ("splitk_bytes", sz), ("d_out", vp), ("d_paths", vp), ("d_own", vp), ("d_other", vp),
-                ("scratch", vp), ("scratch_bytes", sz), ("kv_all", LinearParams)]
+                ("scratch", vp), ("scratch_bytes", sz), ("kv_all", LinearParams),
+                ("n_aux", i32), ("aux_stream", vp * 3), ("aux_ws", vp * 3), ("aux_ws_bytes", sz)]
 
 
 class HeadDesc(C.Structure):

@@ -16,6 +16,9 @@ typedef _Float16 f16_t;
 extern thread_local char d2r_err_buf[512];
 int d2r_fail(int code, const char* fmt, ...);
 int d2r_check_launch(const char* what);
+int d2r_event_record(void* stream, void** ev);  // core.hip: the two halves of d2r_stream_fork (events from a library-owned ring)
+int d2r_stream_wait(void* stream, void* ev);
+int d2r_stream_fork(void* from, void* to);  // core.hip: `to` waits for what is enqueued on `from` (no-op when they are the same stream)
 
 #define D2R_REQUIRE(cond, ...)                                  \
   do {                                                          \

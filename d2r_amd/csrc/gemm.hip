@@ -479,6 +479,7 @@ static void launch_tile(const GemmArgs& a, int gz, hipStream_t st) {
 
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st);  // gemm_glds.hip
 static int g_glds = env_int("D2R_GEMM_GLDS", 1);
+static int g_wide = env_int("D2R_GEMM_WIDE", 1);
 
 // ---- skinny fp32 GEMM: M <= 32 rows (router MLPs, poolers, Block head: per-sample vectors, batch-size rows) ------------------
 // C[M,N] = act(alpha * A[M,K] op(B) + bias) (+ R) (+ beta * C), fp32 in and out, NT (B [N,K]) or NN (B [K,N]), batched.
@@ -695,7 +696,13 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     // less from L2 per flop (NT 6304x3072x768: 561 vs 526, NN: 515 vs 452 TFLOP/s); narrow outputs keep the 128x64 tile
     // (a deep reduction amortises the wider tile's longer prologue also for narrow outputs: NT 6304x768x3072 722 vs 671 TFLOP/s,
     //  tests/probes/gemm_variants.py; not so in the NN direction, 616 vs 654)
-    else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN) bn = (a.N >= 1536 || (LAYOUT == D2R_GEMM_NT && a.K >= 2048 && a.N >= 128)) ? 129 : 64;
+    // Round 3: the comparison above was made with every launch ALONE on the GPU.  In the training step two branch streams keep
+    // two launches in flight most of the time, the chip is saturated, and what counts is bytes per flop: with the 128x128 tile for
+    // every output of at least 128 columns the step is 2 % faster (1361-1366 against 1317-1342 samples/s on one box,
+    // profiles/tile_balance_r03.log; alone on the GPU a 4096x768x768 product takes 13 us with either tile).  D2R_GEMM_WIDE=0
+    // restores the shape-dependent choice.
+    else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN)
+      bn = ((g_wide && a.N >= 128) || a.N >= 1536 || (LAYOUT == D2R_GEMM_NT && a.K >= 2048 && a.N >= 128)) ? 129 : 64;
     if (a.dbias) bn = 0;
     if (bn) {
       GemmArgs b = a;

@@ -237,33 +237,72 @@ int xat_bwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t l
                              d.B, d.Lq, Lk, E, scale, c.st);
 }
 
+// ---- cell-level concurrency ---------------------------------------------------------------------------------------------
+// The cells of a routing layer are independent between the layer's inputs and its aggregation, and most of them are chains of
+// launches that each fill a fraction of the chip (768-wide products over 4-6 thousand rows: one and a half workgroups per CU;
+// per-sample vector ops: a handful of workgroups).  With d2r_interaction_desc.n_aux = 3 the chains go to the call's stream and
+// three auxiliary streams, forked from and joined into the call's stream by events.  Every buffer has ONE writer stream at a
+// time and every accumulation into a shared buffer keeps the order of the single-stream schedule (the results are
+// bit-identical); all auxiliary work is joined before the call returns, in stream order.  cs[0] is the call's stream; without
+// auxiliary streams the four contexts are the same and the forks are no-ops.
+int fork(const Ctx& from, const Ctx& to) { return d2r_stream_fork(from.st, to.st); }
+
 // ---- forward of one routing layer --------------------------------------------------------------------------
-int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
+int layer_fwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
               const void* const* refs, const void* other, LayerF& L, void* out_final, float* probs, int64_t ldp) {
+  const Ctx &c0 = cs[0], &c1 = cs[1], &c2 = cs[2], &c3 = cs[3];
   const int B = d.B, T = d.T, nc = d.nc, hid = d.hid, n = d.n;
   const int64_t TEe = (int64_t)d.Lq * E, SEe = (int64_t)d.Lk * E;
   const d2r_linear_params* lp = p.lin;
-  // --- routers (fp32 end to end: routing decisions are exact) -------------------------------------------------
-  if (first) {  // the cells of layer 0 read the same tensor: pool once, ONE plain GEMM with N = ncell*hid
-    TRY(d2r_meanpool_fwd(c.dt, refs, 1, B, d.Lq, E, L.pooled, c.st));
-    TRY(lin(c, B, nc * hid, E, L.pooled, E, lp[D2R_RL_R0], L.h, D2R_ACT_RELU, nullptr, D2R_F32));
-  } else {
-    TRY(d2r_meanpool_fwd(c.dt, refs, nc, B, d.Lq, E, L.pooled, c.st));
-    G g(D2R_F32, D2R_F32, D2R_GEMM_NT, B, hid, E, L.pooled, E, lp[D2R_RL_R0].w, E, L.h, (int64_t)nc * hid);
-    g.batch(nc, (int64_t)B * E, (int64_t)hid * E, hid);
-    g.d.bias = lp[D2R_RL_R0].b, g.d.s_bias_b = hid, g.d.act = D2R_ACT_RELU;
-    TRY(d2r_gemm(&g.d, c.st));
+  TRY(fork(c0, c1));  // the layer's inputs are complete on the call's stream
+  TRY(fork(c0, c2));
+  TRY(fork(c0, c3));
+  // --- IMRC (cell 2): four large launches of its own --------------------------------------------------------------- stream 1
+  if (nc > 2) {
+    const Ctx& c = c1;
+    const void* x = refs[2];
+    const int dh = E / d.heads;
+    const char* qkv = (const char*)L.qkv;
+    TRY(lin(c, T, 3 * E, E, x, E, lp[D2R_RL_IMRC_QKV], L.qkv));
+    TRY(d2r_mha_fwd(c.dt, qkv, 3 * E, (int64_t)d.Lq * 3 * E, qkv + E * d.es, 3 * E, (int64_t)d.Lq * 3 * E, qkv + 2 * E * d.es, 3 * E,
+                    (int64_t)d.Lq * 3 * E, L.y, E, TEe, x, E, TEe, nullptr, L.lse_i, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
+    TRY(lin(c, T, d.hidi, E, L.y, E, lp[D2R_RL_IMRC_FC1], L.f1, D2R_ACT_RELU));
+    TRY(lin(c, T, E, d.hidi, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2], L.e2, D2R_ACT_NONE, L.y));
   }
+  // --- routers (fp32 end to end: routing decisions are exact) -------------------------------------------------- stream 2
   {
+    const Ctx& c = c2;
+    if (first) {  // the cells of layer 0 read the same tensor: pool once, ONE plain GEMM with N = ncell*hid
+      TRY(d2r_meanpool_fwd(c.dt, refs, 1, B, d.Lq, E, L.pooled, c.st));
+      TRY(lin(c, B, nc * hid, E, L.pooled, E, lp[D2R_RL_R0], L.h, D2R_ACT_RELU, nullptr, D2R_F32));
+    } else {
+      TRY(d2r_meanpool_fwd(c.dt, refs, nc, B, d.Lq, E, L.pooled, c.st));
+      G g(D2R_F32, D2R_F32, D2R_GEMM_NT, B, hid, E, L.pooled, E, lp[D2R_RL_R0].w, E, L.h, (int64_t)nc * hid);
+      g.batch(nc, (int64_t)B * E, (int64_t)hid * E, hid);
+      g.d.bias = lp[D2R_RL_R0].b, g.d.s_bias_b = hid, g.d.act = D2R_ACT_RELU;
+      TRY(d2r_gemm(&g.d, c.st));
+    }
     G g(D2R_F32, D2R_F32, D2R_GEMM_NT, B, P, hid, L.h, (int64_t)nc * hid, lp[D2R_RL_R2].w, hid, L.gates, (int64_t)nc * P);
     g.batch(nc, hid, (int64_t)P * hid, P);
     g.d.bias = lp[D2R_RL_R2].b, g.d.s_bias_b = P, g.d.act = D2R_ACT_TANH_RELU;
     TRY(d2r_gemm(&g.d, c.st));
   }
+  // --- GLAC (cell 1), global branch: per-sample vectors ------------------------------------------------------------ stream 2
+  if (nc > 1) {
+    const Ctx& c = c2;
+    const void* x = refs[1];
+    TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GLAC_TPOOL], L.g_pt, D2R_ACT_TANH));
+    TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GLAC_IPOOL], L.g_pi, D2R_ACT_TANH));
+    TRY(d2r_sqdiff_fwd(c.dt, L.g_pt, L.g_pi, L.g_dg, (int64_t)B * E, c.st));
+    TRY(lin(c, B, E, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO], L.g_glo));
+    TRY(d2r_l2norm_fwd(c.dt, L.g_glo, L.g_l2g, L.g_nglo, B, E, c.st));
+    TRY(lin(c, B, E, E, L.g_l2g, E, lp[D2R_RL_GLAC_FC2], L.g_sg));
+  }
   // --- the alignment cores of GLAC / CMRC / CRCMC: their query projections, then ONE attention launch for all of them (same
   //     shapes, same softmax(100 q k^T / sqrt(768)) v: three times the workgroups of a single core).  Keys and values are column
-  //     blocks of the module-wide k|v projection of `other` computed before the first layer. ---------------------------------
+  //     blocks of the module-wide k|v projection of `other` computed before the first layer. ------------------------ stream 0
   {
+    const Ctx& c = c0;
     const void *qa[3], *ka[3], *va[3];
     void* oa[3];
     float* la[3];
@@ -281,19 +320,26 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
       TRY(d2r_xattn_fwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, (int64_t)d.Lk * d.ldkv, va, d.ldkv, (int64_t)d.Lk * d.ldkv, oa, E, TEe, nullptr, E,
                               TEe, nullptr, la, B, d.Lq, d.Lk, E, XSCALE, c.st));
   }
-  // --- GLAC (cell 1) ---------------------------------------------------------------------------------------------
+  TRY(fork(c0, c2));  // the cores' outputs
+  TRY(fork(c0, c3));
+  // --- CRCMC (cell 4) behind its core ----------------------------------------------------------------------------- stream 3
+  if (nc > 4) {
+    const Ctx& c = c3;
+    const void* x = refs[4];
+    TRY(lin(c, T, E, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1], L.r_Qs, D2R_ACT_TANH));
+    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CRCMC_MLP2], L.r_Ks, D2R_ACT_TANH));
+    TRY(lin(c, T, E, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1], L.r_a));
+    TRY(lin(c, T, E, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2], L.r_b));
+    TRY(xat_fwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, L.e4, L.r_Qs, L.r_lse2, 1.0f));  // unscaled softmax(Q K^T), + Qs
+  }
+  // --- GLAC, local branch behind its core, then the SAF gate over [global | local] ------------------------------- stream 2
   if (nc > 1) {
+    const Ctx& c = c2;
     const void* x = refs[1];
     TRY(d2r_sqdiff_fwd(c.dt, x, L.g_c, L.g_sq, (int64_t)T * E, c.st));
     TRY(lin(c, T, E, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC], L.g_loc));
     TRY(d2r_l2norm_fwd(c.dt, L.g_loc, L.g_l2, L.g_nloc, T, E, c.st));
     TRY(lin(c, T, E, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1], L.g_sl));
-    TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GLAC_TPOOL], L.g_pt, D2R_ACT_TANH));
-    TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GLAC_IPOOL], L.g_pi, D2R_ACT_TANH));
-    TRY(d2r_sqdiff_fwd(c.dt, L.g_pt, L.g_pi, L.g_dg, (int64_t)B * E, c.st));
-    TRY(lin(c, B, E, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO], L.g_glo));
-    TRY(d2r_l2norm_fwd(c.dt, L.g_glo, L.g_l2g, L.g_nglo, B, E, c.st));
-    TRY(lin(c, B, E, E, L.g_l2g, E, lp[D2R_RL_GLAC_FC2], L.g_sg));
     // S = cat([sg[:,None], sl], 1)  [B, n, E]
     const size_t row = (size_t)E * d.es;
     TRY(copy2d(L.g_S, (size_t)n * row, L.g_sg, row, row, B, c.st));
@@ -306,19 +352,9 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(d2r_gemm(&g.d, c.st));
     TRY(d2r_l2norm_fwd(c.dt, L.g_wsum, L.e1, L.g_ne1, B, E, c.st));
   }
-  // --- IMRC (cell 2) -----------------------------------------------------------------------------------------------
-  if (nc > 2) {
-    const void* x = refs[2];
-    const int dh = E / d.heads;
-    const char* qkv = (const char*)L.qkv;
-    TRY(lin(c, T, 3 * E, E, x, E, lp[D2R_RL_IMRC_QKV], L.qkv));
-    TRY(d2r_mha_fwd(c.dt, qkv, 3 * E, (int64_t)d.Lq * 3 * E, qkv + E * d.es, 3 * E, (int64_t)d.Lq * 3 * E, qkv + 2 * E * d.es, 3 * E,
-                    (int64_t)d.Lq * 3 * E, L.y, E, TEe, x, E, TEe, nullptr, L.lse_i, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
-    TRY(lin(c, T, d.hidi, E, L.y, E, lp[D2R_RL_IMRC_FC1], L.f1, D2R_ACT_RELU));
-    TRY(lin(c, T, E, d.hidi, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2], L.e2, D2R_ACT_NONE, L.y));
-  }
-  // --- CMRC (cell 3) -----------------------------------------------------------------------------------------------
+  // --- CMRC (cell 3) behind its core ------------------------------------------------------------------------------ stream 0
   if (nc > 3) {
+    const Ctx& c = c0;
     const void* x = refs[3];
     TRY(lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE], L.c_s, D2R_ACT_TANH));
     TRY(lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT], L.c_h));
@@ -326,17 +362,9 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(lin(c, T, E, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1], L.c_f, D2R_ACT_RELU));
     TRY(lin(c, T, E, E, L.c_f, E, lp[D2R_RL_CMRC_FC2], L.e3, D2R_ACT_NONE, x));
   }
-  // --- CRCMC (cell 4) ----------------------------------------------------------------------------------------------
-  if (nc > 4) {
-    const void* x = refs[4];
-    TRY(lin(c, T, E, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1], L.r_Qs, D2R_ACT_TANH));
-    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CRCMC_MLP2], L.r_Ks, D2R_ACT_TANH));
-    TRY(lin(c, T, E, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1], L.r_a));
-    TRY(lin(c, T, E, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2], L.r_b));
-    TRY(xat_fwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, L.e4, L.r_Qs, L.r_lse2, 1.0f));  // unscaled softmax(Q K^T), + Qs
-  }
-  // --- GESC (cell 5) -----------------------------------------------------------------------------------------------
+  // --- GESC (cell 5): per-sample vectors ------------------------------------------------------------------------------ stream 1
   if (nc > 5) {
+    const Ctx& c = c1;
     const void* x = refs[5];
     TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GESC_TPOOL], L.s_a, D2R_ACT_TANH));
     TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GESC_IPOOL], L.s_b, D2R_ACT_TANH));
@@ -346,11 +374,14 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(d2r_softmax_fwd(c.dt, c.dt, L.s_z, L.s_g, E, B, E, 1.0f, nullptr, 1, c.st));
     TRY(d2r_lerp_fwd(c.dt, L.s_g, L.s_a, L.s_b, L.e5, (int64_t)B * E, c.st));
   }
+  TRY(fork(c1, c0));  // join
+  TRY(fork(c2, c0));
+  TRY(fork(c3, c0));
   // --- K8: path normalisation, gates, aggregation ------------------------------------------------------------------
   const void* embs[6] = {refs[0], L.e1, L.e2, L.e3, L.e4, L.e5};
   void* outs[6];
   for (int i = 0; i < 6; ++i) outs[i] = final ? (i == 0 ? out_final : nullptr) : L.outs[i];
-  return d2r_route_aggregate_fwd(c.dt, embs, final ? refs : nullptr, L.gates, B, d.Lq, E, nc, P, outs, probs, ldp, c.st);
+  return d2r_route_aggregate_fwd(c0.dt, embs, final ? refs : nullptr, L.gates, B, d.Lq, E, nc, P, outs, probs, ldp, c0.st);
 }
 
 // ---- backward scratch of one layer -----------------------------------------------------------------------------
@@ -423,14 +454,23 @@ int acc32(const Ctx& c, const float* tmp, float* sink, int64_t nel) { return d2r
 // ---- backward of one routing layer --------------------------------------------------------------------------------
 // douts[i]: gradient of output i (NULL = zero; only legal for the final layer's single output);  dx[j]: gradient w.r.t.
 // input j, OVERWRITTEN (layer 0: all six alias d_own);  d_other: ACCUMULATED (zeroed by the caller).
-int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
+// Streams (see "cell-level concurrency" above): 0 aggregation, CMRC, CRCMC, the cores' backward, the query-side products;
+// 1 routers, IMRC; 2 GLAC's gate and global branch, GESC (the per-sample vector chains; both accumulate into the cls rows of
+// d_other, in this order); 3 GLAC's local branch.  The launches that ACCUMULATE into an input gradient dx[j] ("tails") come
+// last in every chain: behind the routers' pooled gradient (which initialises dx[j]) in layers whose dx[j] are six buffers,
+// and - layer 0, where all six alias d_own - on the call's stream after the join, in the order of the single-stream schedule.
+int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
               const void* const* refs, const void* other, const LayerF& L, LayerB& K, const void* const* douts, const void* out_final,
               const float* dprobs, int64_t ldp, void* const* dx, void* d_other, Jobs& jobs) {
+  const Ctx &c0 = cs[0], &c1 = cs[1], &c2 = cs[2], &c3 = cs[3];
   const int B = d.B, T = d.T, nc = d.nc, hid = d.hid, n = d.n;
   const int64_t TEe = (int64_t)d.Lq * E, SEe = (int64_t)d.Lk * E, TEn = (int64_t)T * E, BEn = (int64_t)B * E;
   const d2r_linear_params* lp = p.lin;
-  // --- K8 backward ---------------------------------------------------------------------------------------------------
+  const bool serial_tails = first;  // layer 0: the tails run on stream 0 after the join, in the order of the single-stream schedule
+  const bool multi = c1.st != c0.st;
+  // --- K8 backward -------------------------------------------------------------------------------------------- stream 0
   {
+    const Ctx& c = c0;
     const void* embs[6] = {refs[0], L.e1, L.e2, L.e3, L.e4, L.e5};
     void* dembs[6];
     void* drefs[6];
@@ -445,8 +485,11 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
                                 dembs, final ? drefs : nullptr, K.dgates, K.agg_ws, K.agg_bytes, c.st));
     if (final) TRY(d2r_axpby(c.dt, 1.f, K.de[0], 1.f, dx[0], TEn, c.st));  // x0 is ref_0: relu path + skip path
   }
-  // --- routers ---------------------------------------------------------------------------------------------------------
+  TRY(fork(c0, c1));
+  TRY(fork(c0, c2));
+  // --- routers ---------------------------------------------------------------------------------------------------- stream 1
   {
+    const Ctx& c = c1;
     TRY(d2r_act_bwd(D2R_F32, D2R_ACT_TANH_RELU, K.dgates, L.gates, K.dG, (int64_t)B * nc * P, c.st));
     G gx(D2R_F32, D2R_F32, D2R_GEMM_NN, B, hid, P, K.dG, (int64_t)nc * P, lp[D2R_RL_R2].w, hid, K.dh, (int64_t)nc * hid);
     gx.batch(nc, P, (int64_t)P * hid, hid);
@@ -477,12 +520,39 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
         TRY(d2r_meanpool_bwd(c.dt, K.dpooled + (size_t)j * B * E, B, d.Lq, E, dx[j], (j == 0 || final) ? 1 : 0, c.st));
     }
   }
-  // from here on every dx[j] is initialised: the cells ACCUMULATE into it (GEMM epilogues, beta = 1)
+  void* ev_routers = nullptr;  // recorded HERE (not behind IMRC, which follows on the same stream); stream 2 waits for it in front of its tails
+  if (multi) TRY(d2r_event_record(c1.st, &ev_routers));
+  // from here on (in stream 1's order) every dx[j] is initialised: the cells ACCUMULATE into it (GEMM epilogues, beta = 1)
+  // --- IMRC ------------------------------------------------------------------------------------------------------- stream 1
+  auto imrc_tail = [&](const Ctx& c) -> int {
+    TRY(dxg(c, T, E, 3 * E, K.i_dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
+    return D2R_OK;
+  };
+  if (nc > 2) {
+    const Ctx& c = c1;
+    const void* x = refs[2];
+    const int dh = E / d.heads;
+    const char* qkv = (const char*)L.qkv;
+    char* dqkv = (char*)K.i_dqkv;
+    const int64_t E3 = 3 * E, sb3 = (int64_t)d.Lq * 3 * E;
+    TRY(dxg(c, T, d.hidi, E, K.de[2], E, lp[D2R_RL_IMRC_FC2].w, K.i_df1, d.hidi, 0.f, nullptr, L.f1, D2R_ACT_RELU));  // d f1_pre
+    defer(jobs, T, E, d.hidi, K.de[2], E, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2]);
+    TRY(dxg(c, T, E, d.hidi, K.i_df1, d.hidi, lp[D2R_RL_IMRC_FC1].w, K.i_dy, E, 0.f, K.de[2]));  // + skip y -> e2
+    defer(jobs, T, d.hidi, E, K.i_df1, d.hidi, L.y, E, lp[D2R_RL_IMRC_FC1]);
+    TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, K.i_dsum, dqkv, E3, sb3,
+                    dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
+    if (!serial_tails) TRY(imrc_tail(c));
+    defer(jobs, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]);  // (with the other layers' q|k|v gradients: one grouped launch per module)
+  }
   // ===== part 1: every cell down to the gradient of its alignment core's output (d c) =================================================
-  // --- GLAC ------------------------------------------------------------------------------------------------------------
+  // --- GLAC: gate, then (stream 3) the local branch, then the global branch --------------------------------------- stream 2
+  auto glac_tail = [&](const Ctx& c) -> int {
+    TRY(dxg(c, B, E, E, K.g_dptp, E, lp[D2R_RL_GLAC_TPOOL].w, dx[1], TEe, 1.f));  // token 0 of every sample
+    return D2R_OK;
+  };
   if (nc > 1) {
+    const Ctx& c = c2;
     const void* x = refs[1];
-    void* dxj = dx[1];
     TRY(d2r_l2norm_bwd(c.dt, K.de[1], L.g_wsum, L.g_ne1, K.g_dwsum, B, E, c.st));
     G gw(c.dt, c.dt, D2R_GEMM_NT, 1, n, E, K.g_dwsum, E, L.g_S, E, K.g_dw16, n);  // d w[b] = d wsum[b] S[b]^T
     gw.batch(B, E, (int64_t)n * E, n);
@@ -501,13 +571,16 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     const size_t row = (size_t)E * d.es;
     TRY(copy2d(K.g_dsl, (size_t)d.Lq * row, (char*)K.g_dS + row, (size_t)n * row, (size_t)d.Lq * row, B, c.st));
     const int64_t ldsg = (int64_t)n * E;
-    // local path
-    TRY(dxg(c, T, E, E, K.g_dsl, E, lp[D2R_RL_GLAC_FC1].w, K.g_dl2, E));
-    defer(jobs, T, E, E, K.g_dsl, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1]);
-    TRY(d2r_l2norm_bwd(c.dt, K.g_dl2, L.g_loc, L.g_nloc, K.g_dloc, T, E, c.st));
-    TRY(dxg(c, T, E, E, K.g_dloc, E, lp[D2R_RL_GLAC_LOC].w, K.g_dsq, E));
-    defer(jobs, T, E, E, K.g_dloc, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC]);
-    TRY(d2r_sqdiff_bwd(c.dt, x, L.g_c, K.g_dsq, K.g_da, K.g_dc, TEn, c.st));
+    TRY(fork(c2, c3));
+    {  // local path --------------------------------------------------------------------------------------------------- stream 3
+      const Ctx& c = c3;
+      TRY(dxg(c, T, E, E, K.g_dsl, E, lp[D2R_RL_GLAC_FC1].w, K.g_dl2, E));
+      defer(jobs, T, E, E, K.g_dsl, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1]);
+      TRY(d2r_l2norm_bwd(c.dt, K.g_dl2, L.g_loc, L.g_nloc, K.g_dloc, T, E, c.st));
+      TRY(dxg(c, T, E, E, K.g_dloc, E, lp[D2R_RL_GLAC_LOC].w, K.g_dsq, E));
+      defer(jobs, T, E, E, K.g_dloc, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC]);
+      TRY(d2r_sqdiff_bwd(c.dt, x, L.g_c, K.g_dsq, K.g_da, K.g_dc, TEn, c.st));
+    }
     // global path
     TRY(dxg(c, B, E, E, K.g_dS, ldsg, lp[D2R_RL_GLAC_FC2].w, K.g_dl2g, E));
     defer(jobs, B, E, E, K.g_dS, ldsg, L.g_l2g, E, lp[D2R_RL_GLAC_FC2]);
@@ -517,27 +590,54 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(d2r_sqdiff_bwd(c.dt, L.g_pt, L.g_pi, K.g_ddg, K.g_dpt, K.g_dpi, BEn, c.st));
     TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.g_dpt, L.g_pt, K.g_dptp, BEn, c.st));
     TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.g_dpi, L.g_pi, K.g_dpip, BEn, c.st));
-    TRY(dxg(c, B, E, E, K.g_dptp, E, lp[D2R_RL_GLAC_TPOOL].w, dxj, TEe, 1.f));      // token 0 of every sample
+    if (multi) TRY(d2r_stream_wait(c2.st, ev_routers));  // the routers' pooled gradient has initialised dx[1] (and dx[5], below)
+    if (!serial_tails) TRY(glac_tail(c));
     defer(jobs, B, E, E, K.g_dptp, E, x, TEe, lp[D2R_RL_GLAC_TPOOL]);
     TRY(dxg(c, B, E, E, K.g_dpip, E, lp[D2R_RL_GLAC_IPOOL].w, d_other, SEe, 1.f));
     defer(jobs, B, E, E, K.g_dpip, E, other, SEe, lp[D2R_RL_GLAC_IPOOL]);
+  } else if (multi) {
+    TRY(d2r_stream_wait(c2.st, ev_routers));
   }
-  // --- CMRC ------------------------------------------------------------------------------------------------------------
+  // --- GESC ------------------------------------------------------------------------------------------------------- stream 2
+  auto gesc_tail = [&](const Ctx& c) -> int {
+    TRY(dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f));
+    return D2R_OK;
+  };
+  if (nc > 5) {
+    const Ctx& c = c2;
+    const void* x = refs[5];
+    TRY(d2r_lerp_bwd(c.dt, L.s_g, L.s_a, L.s_b, K.de[5], K.s_dg, K.s_da1, K.s_db1, BEn, c.st));
+    TRY(d2r_softmax_bwd(c.dt, c.dt, L.s_g, K.s_dg, K.s_dz, E, B, E, 1.0f, c.st));
+    TRY(dxg(c, B, E, E, K.s_dz, E, lp[D2R_RL_GESC_MLP2].w, K.s_dz1p, E, 0.f, nullptr, L.s_z1, D2R_ACT_TANH));
+    defer(jobs, B, E, E, K.s_dz, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2]);
+    TRY(dxg(c, B, E, E, K.s_dz1p, E, lp[D2R_RL_GESC_MLP0].w, K.s_dab, E));
+    defer(jobs, B, E, E, K.s_dz1p, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0]);
+    TRY(d2r_add(c.dt, K.s_da1, K.s_dab, K.s_dat, BEn, c.st));
+    TRY(d2r_add(c.dt, K.s_db1, K.s_dab, K.s_dbt, BEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dat, L.s_a, K.s_dap, BEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dbt, L.s_b, K.s_dbp, BEn, c.st));
+    if (!serial_tails) TRY(gesc_tail(c));
+    defer(jobs, B, E, E, K.s_dap, E, x, TEe, lp[D2R_RL_GESC_TPOOL]);
+    TRY(dxg(c, B, E, E, K.s_dbp, E, lp[D2R_RL_GESC_IPOOL].w, d_other, SEe, 1.f));
+    defer(jobs, B, E, E, K.s_dbp, E, other, SEe, lp[D2R_RL_GESC_IPOOL]);
+  }
+  // --- CMRC ------------------------------------------------------------------------------------------------------- stream 0
   if (nc > 3) {
-    const void* x = refs[3];
+    const Ctx& c = c0;
     TRY(dxg(c, T, E, E, K.de[3], E, lp[D2R_RL_CMRC_FC2].w, K.c_dfp, E, 0.f, nullptr, L.c_f, D2R_ACT_RELU));
     defer(jobs, T, E, E, K.de[3], E, L.c_f, E, lp[D2R_RL_CMRC_FC2]);
     TRY(dxg(c, T, E, E, K.c_dfp, E, lp[D2R_RL_CMRC_FC1].w, K.c_dmod, E));
     defer(jobs, T, E, E, K.c_dfp, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1]);
-    TRY(d2r_muladd_bwd(c.dt, x, L.c_s, K.c_dmod, K.c_da, K.c_ds, TEn, c.st));
+    TRY(d2r_muladd_bwd(c.dt, refs[3], L.c_s, K.c_dmod, K.c_da, K.c_ds, TEn, c.st));
     TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.c_ds, L.c_s, K.c_dsp, TEn, c.st));
     TRY(dxg(c, T, E, E, K.c_dsp, E, lp[D2R_RL_CMRC_SCALE].w, K.c_dc, E));
     defer(jobs, T, E, E, K.c_dsp, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE]);
     TRY(dxg(c, T, E, E, K.c_dmod, E, lp[D2R_RL_CMRC_SHIFT].w, K.c_dc, E, 1.f));
     defer(jobs, T, E, E, K.c_dmod, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT]);
   }
-  // --- CRCMC -----------------------------------------------------------------------------------------------------------
+  // --- CRCMC ------------------------------------------------------------------------------------------------------ stream 0
   if (nc > 4) {
+    const Ctx& c = c0;
     TRY(xat_bwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, K.de[4], L.e4, L.r_Qs, L.r_lse2, K.r_da, K.r_db, E, K.r_dKv, E, K.r_P2, K.r_dS2, 1.0f));
     TRY(dxg(c, T, E, E, K.r_da, E, lp[D2R_RL_CRCMC_FC1].w, K.r_dQs, E, 0.f, K.de[4]));  // + residual Qs -> e4
     defer(jobs, T, E, E, K.r_da, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1]);
@@ -548,9 +648,11 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(dxg(c, T, E, E, K.r_dQsp, E, lp[D2R_RL_CRCMC_MLP1].w, K.r_dc, E));
     defer(jobs, T, E, E, K.r_dQsp, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1]);
   }
+  TRY(fork(c3, c0));  // GLAC's d c (and d(sqdiff)/dx for part 2)
   // ===== ONE backward launch for the alignment cores: dS, P, dQ; then dV / dK of every sample and core (one grouped launch)
-  //       straight into the column blocks of the module-wide k|v gradient ======================================================
+  //       straight into the column blocks of the module-wide k|v gradient ====================================== stream 0
   {
+    const Ctx& c = c0;
     const void *qa[3], *ka[3], *va[3], *ga[3], *oa[3];
     const float* la[3];
     void *dqa[3], *dka[3], *dva[3], *pa[3], *dsa[3];
@@ -568,67 +670,51 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
       TRY(d2r_xattn_bwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, skv, va, d.ldkv, skv, ga, E, TEe, oa, E, TEe, nullptr, E, TEe, nullptr, la, dqa, E, TEe, dka, d.ldkv, skv, dva,
                               d.ldkv, skv, pa, dsa, d.lkp, B, d.Lq, d.Lk, E, XSCALE, c.st));
   }
+  TRY(fork(c1, c0));  // join: routers (dx[j] initialised), IMRC
+  TRY(fork(c2, c0));  //       GLAC's cls-row gradient is in dx[1] before the query-side product accumulates into it; GESC
+  if (serial_tails && nc > 1) TRY(glac_tail(c0));
   // ===== part 2: the query-side projections (the key / value side of every cell and layer is one product at the end of the module) ===
   if (nc > 1) {
-    TRY(dxg(c, T, E, E, K.g_dq, E, lp[D2R_RL_GLAC_Q].w, dx[1], E, 1.f, K.g_da));  // += dq Wq + d(sqdiff)/dx
+    TRY(dxg(c0, T, E, E, K.g_dq, E, lp[D2R_RL_GLAC_Q].w, dx[1], E, 1.f, K.g_da));  // += dq Wq + d(sqdiff)/dx
     defer(jobs, T, E, E, K.g_dq, E, refs[1], E, lp[D2R_RL_GLAC_Q]);
   }
   if (nc > 3) {
-    TRY(d2r_add(c.dt, K.c_da, K.de[3], K.c_tmp, TEn, c.st));  // FiLM path + skip x -> e3
-    TRY(dxg(c, T, E, E, K.c_dq, E, lp[D2R_RL_CMRC_Q].w, dx[3], E, 1.f, K.c_tmp));
+    TRY(d2r_add(c0.dt, K.c_da, K.de[3], K.c_tmp, TEn, c0.st));  // FiLM path + skip x -> e3
+    TRY(dxg(c0, T, E, E, K.c_dq, E, lp[D2R_RL_CMRC_Q].w, dx[3], E, 1.f, K.c_tmp));
     defer(jobs, T, E, E, K.c_dq, E, refs[3], E, lp[D2R_RL_CMRC_Q]);
   }
   if (nc > 4) {
     const void* x = refs[4];
-    TRY(dxg(c, T, E, E, K.r_dq, E, lp[D2R_RL_CRCMC_Q].w, dx[4], E, 1.f));
+    TRY(dxg(c0, T, E, E, K.r_dq, E, lp[D2R_RL_CRCMC_Q].w, dx[4], E, 1.f));
     defer(jobs, T, E, E, K.r_dq, E, x, E, lp[D2R_RL_CRCMC_Q]);
-    TRY(dxg(c, T, E, E, K.r_dKsp, E, lp[D2R_RL_CRCMC_MLP2].w, dx[4], E, 1.f));
+    TRY(dxg(c0, T, E, E, K.r_dKsp, E, lp[D2R_RL_CRCMC_MLP2].w, dx[4], E, 1.f));
     defer(jobs, T, E, E, K.r_dKsp, E, x, E, lp[D2R_RL_CRCMC_MLP2]);
   }
-  // --- IMRC ------------------------------------------------------------------------------------------------------------
-  if (nc > 2) {
-    const void* x = refs[2];
-    const int dh = E / d.heads;
-    const char* qkv = (const char*)L.qkv;
-    char* dqkv = (char*)K.i_dqkv;
-    const int64_t E3 = 3 * E, sb3 = (int64_t)d.Lq * 3 * E;
-    TRY(dxg(c, T, d.hidi, E, K.de[2], E, lp[D2R_RL_IMRC_FC2].w, K.i_df1, d.hidi, 0.f, nullptr, L.f1, D2R_ACT_RELU));  // d f1_pre
-    defer(jobs, T, E, d.hidi, K.de[2], E, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2]);
-    TRY(dxg(c, T, E, d.hidi, K.i_df1, d.hidi, lp[D2R_RL_IMRC_FC1].w, K.i_dy, E, 0.f, K.de[2]));  // + skip y -> e2
-    defer(jobs, T, d.hidi, E, K.i_df1, d.hidi, L.y, E, lp[D2R_RL_IMRC_FC1]);
-    TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, K.i_dsum, dqkv, E3, sb3,
-                    dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
-    TRY(dxg(c, T, E, 3 * E, dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
-    defer(jobs, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]);  // (with the other layers' q|k|v gradients: one grouped launch per module)
-  }
-  // --- GESC ------------------------------------------------------------------------------------------------------------
-  if (nc > 5) {
-    const void* x = refs[5];
-    TRY(d2r_lerp_bwd(c.dt, L.s_g, L.s_a, L.s_b, K.de[5], K.s_dg, K.s_da1, K.s_db1, BEn, c.st));
-    TRY(d2r_softmax_bwd(c.dt, c.dt, L.s_g, K.s_dg, K.s_dz, E, B, E, 1.0f, c.st));
-    TRY(dxg(c, B, E, E, K.s_dz, E, lp[D2R_RL_GESC_MLP2].w, K.s_dz1p, E, 0.f, nullptr, L.s_z1, D2R_ACT_TANH));
-    defer(jobs, B, E, E, K.s_dz, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2]);
-    TRY(dxg(c, B, E, E, K.s_dz1p, E, lp[D2R_RL_GESC_MLP0].w, K.s_dab, E));
-    defer(jobs, B, E, E, K.s_dz1p, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0]);
-    TRY(d2r_add(c.dt, K.s_da1, K.s_dab, K.s_dat, BEn, c.st));
-    TRY(d2r_add(c.dt, K.s_db1, K.s_dab, K.s_dbt, BEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dat, L.s_a, K.s_dap, BEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dbt, L.s_b, K.s_dbp, BEn, c.st));
-    TRY(dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f));
-    defer(jobs, B, E, E, K.s_dap, E, x, TEe, lp[D2R_RL_GESC_TPOOL]);
-    TRY(dxg(c, B, E, E, K.s_dbp, E, lp[D2R_RL_GESC_IPOOL].w, d_other, SEe, 1.f));
-    defer(jobs, B, E, E, K.s_dbp, E, other, SEe, lp[D2R_RL_GESC_IPOOL]);
-  }
+  if (serial_tails && nc > 2) TRY(imrc_tail(c0));
+  if (serial_tails && nc > 5) TRY(gesc_tail(c0));
   return D2R_OK;
 }
 
-int check(const d2r_interaction_desc* D, const char* fn, bool bwd) {
+// cs[0]: the call's stream; cs[1..3]: the auxiliary streams with their own split-K scratch, or copies of cs[0]
+void make_ctx(const d2r_interaction_desc* D, void* stream, Ctx* cs) {
+  cs[0] = Ctx{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
+  for (int i = 1; i < 4; ++i)
+    cs[i] = D->n_aux == 3 ? Ctx{D->dtype, D->aux_stream[i - 1], D->aux_ws[i - 1], D->aux_ws_bytes} : cs[0];
+}
+
+int check(const d2r_interaction_desc* D, const char* fn, bool bwd, void* stream) {
   D2R_REQUIRE(D != nullptr, "%s: null descriptor", fn);
   D2R_REQUIRE(D->B >= 1 && D->Lq >= 1 && D->Lk >= 1 && D->nlayer >= 2 && D->hid_router >= 1 && D->hid_imrc >= 8 && D->heads_imrc >= 1,
               "%s: bad shape", fn);
   D2R_REQUIRE(d2r_interaction_supported(D->dtype, D->Lq, D->Lk, D->ncell, D->heads_imrc),
               "%s: unsupported (bf16, 2..6 cells, token counts within the fused attention cores' limits)", fn);
   D2R_REQUIRE(D->layers && D->own && D->other && D->out && D->paths && D->arena && d2r_aligned16(D->arena), "%s: null / unaligned pointer", fn);
+  D2R_REQUIRE(D->n_aux == 0 || D->n_aux == 3, "%s: n_aux must be 0 or 3", fn);
+  if (D->n_aux == 3)
+    for (int i = 0; i < 3; ++i)
+      D2R_REQUIRE(D->aux_stream[i] && D->aux_stream[i] != stream && D->aux_stream[i] != D->aux_stream[(i + 1) % 3] && D->aux_ws[i] && D->aux_ws[i] != D->splitk_ws &&
+                      D->aux_ws[i] != D->aux_ws[(i + 1) % 3] && D->aux_ws_bytes >= ((size_t)1 << 20),
+                  "%s: three distinct auxiliary streams, each with its own split-K scratch (>= 1 MiB), are required with n_aux = 3", fn);
   D2R_REQUIRE(D->kv_all.w && D->kv_all.b && (!bwd || (D->kv_all.gw && D->kv_all.gb)), "%s: kv_all (the fused k|v projections of `other`) missing", fn);
   D2R_REQUIRE(D->arena_bytes >= d2r_interaction_arena_bytes(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc),
               "%s: arena too small", fn);
@@ -670,9 +756,11 @@ extern "C" size_t d2r_interaction_bwd_scratch(int B, int Lq, int Lk, int ncell, 
 }
 
 extern "C" int d2r_interaction_fwd(const d2r_interaction_desc* D, void* stream) {
-  TRY(check(D, "d2r_interaction_fwd", false));
+  TRY(check(D, "d2r_interaction_fwd", false, stream));
   const Dims d = make_dims(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc, D->heads_imrc);
-  const Ctx c{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
+  Ctx cs[4];
+  make_ctx(D, stream, cs);
+  const Ctx& c = cs[0];
   Arena A(D->arena);
   const int nc = d.nc, total = nc * nc * (d.nl - 1) + nc;
   // keys | values of every alignment cell of every layer: `other` is the same tensor in all of them
@@ -686,16 +774,18 @@ extern "C" int d2r_interaction_fwd(const d2r_interaction_desc* D, void* stream) 
     const bool first = l == 0, final = l == d.nl - 1;
     const int P = final ? 1 : nc;
     plan_fwd(A, d, P, first, final, L, kvall, l);
-    TRY(layer_fwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, L, D->out, D->paths + (size_t)l * nc * nc, total));
+    TRY(layer_fwd(cs, d, D->layers[l], P, first, final, D->train, refs, D->other, L, D->out, D->paths + (size_t)l * nc * nc, total));
     for (int j = 0; j < nc && !final; ++j) refs[j] = L.outs[j];
   }
   return D2R_OK;
 }
 
 extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) {
-  TRY(check(D, "d2r_interaction_bwd", true));
+  TRY(check(D, "d2r_interaction_bwd", true, stream));
   const Dims d = make_dims(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc, D->heads_imrc);
-  const Ctx c{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
+  Ctx cs[4];
+  make_ctx(D, stream, cs);
+  const Ctx& c = cs[0];
   const int nc = d.nc, nl = d.nl, total = nc * nc * (nl - 1) + nc;
   const size_t TE = (size_t)d.T * E * d.es;
   std::vector<LayerF> F(nl);
@@ -722,7 +812,7 @@ extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) 
       douts[j] = final ? (j == 0 ? (D->d_out ? D->d_out : zero_out) : nullptr) : K[l + 1].dx[j];
     }
     const float* dprobs = D->d_paths ? D->d_paths + (size_t)l * nc * nc : nullptr;
-    TRY(layer_bwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, F[l], K[l], douts, D->out, dprobs, total, dx, D->d_other, jobs));
+    TRY(layer_bwd(cs, d, D->layers[l], P, first, final, D->train, refs, D->other, F[l], K[l], douts, D->out, dprobs, total, dx, D->d_other, jobs));
   }
   if (d.nkv) {
     // every cell and layer wrote its dK | dV block: the gradient w.r.t. `other` through ALL key / value projections is one product

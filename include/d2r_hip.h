@@ -448,6 +448,14 @@ typedef struct {
    * (`other` is the same tensor in every layer, models/DynamicInteraction.py:95-102): one GEMM with N = 13,824 at DR_step 3 in
    * the forward pass, one dX and one dW product in the backward pass.  The D2R_RL_*_KV entries of `layers` are then unused. */
   d2r_linear_params kv_all;
+  /* Optional cell-level concurrency (round 3).  The cells of a routing layer are independent between the layer's inputs and its
+   * aggregation (models/DynamicInteraction.py:41-48,95-102) and most of them are chains of launches that fill a fraction of the
+   * chip: with n_aux = 3 the calls issue them on `stream` and on these three auxiliary streams, forked from and joined back into
+   * `stream` by events (all auxiliary work is joined before the call returns, in stream order; results are bit-identical to
+   * n_aux = 0).  Each auxiliary stream needs its own split-K scratch of aux_ws_bytes. */
+  int n_aux;                 /* 0 or 3 */
+  void* aux_stream[3];
+  void* aux_ws[3]; size_t aux_ws_bytes;
 } d2r_interaction_desc;
 int d2r_interaction_supported(int dtype, int Lq, int Lk, int ncell, int heads_imrc);
 size_t d2r_interaction_arena_bytes(int B, int Lq, int Lk, int ncell, int nlayer, int hid_router, int hid_imrc);
