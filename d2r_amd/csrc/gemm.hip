@@ -689,6 +689,7 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     else if (g_tile == 7) bn = 1128;  // software-pipelined K-loop: 128x128 on four waves
     else if (g_tile == 8) bn = 1064;  //                             128x64
     else if (g_tile == 9) bn = 1129;  //                             128x128 on eight waves
+    else if (g_tile == 10) bn = (LAYOUT != D2R_GEMM_TN && a.N % 192 == 0) ? 193 : 129;  // 128x192 on eight waves
     // measured (profiles/gemm_ab_r01_e.log): the 128x64 LDS-DMA kernel beats the register-staged 64x64 tiles on every
     // NT / NN shape of the workload (351 vs 275, 548 vs 422, 616 vs 343 TFLOP/s ...); weight-gradient GEMMs that carry
     // the bias-gradient side product stay on the generic kernel

@@ -28,6 +28,20 @@ __device__ __forceinline__ int kswz(int k) {
   else return (((k >> 1) & 1) | ((k >> 2) & 2)) << 1;
 }
 
+// Rows of 384 bytes (the 192-column tile: 24 chunks, not a power of two): chunk c of k-row k sits at position (c + kswz<8>(k)) mod 24.
+// Such rows alternate between the two halves of the banks like the 128-byte rows; the pair rotation by bits 1 and 3 of k puts the
+// eight rows of a transposing read on eight different 8-bank groups for every column (four consecutive pair positions mod 12 are
+// distinct mod 8, and never four apart).
+template <int CH>
+__device__ __forceinline__ int kpos(int c, int k) {
+  if constexpr (CH == 24) {
+    const int p = c + kswz<8>(k);
+    return p >= 24 ? p - 24 : p;
+  } else {
+    return c ^ kswz<CH>(k);
+  }
+}
+
 // NWN waves along N (2: four waves, 4: eight waves per workgroup); a wave owns 64 rows x BN/NWN columns.
 // PIPE = 1: software-pipelined K-step (all fragment reads of the step issued up front behind counted lgkmcnt waits, the
 // closing barrier in the MIDDLE of the MFMA block, the DMA of tile t+2 issued right behind it: two tiles in flight).
@@ -110,6 +124,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       const int row = ins * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
       const int grow = min(n0 + row, g.N - 1);
       offB[i] = (int64_t)grow * g.ldb + c * 8;
+    } else if constexpr (BN == 192) {  // [64 k][192 n]: 384-byte rows, an instruction (1 KiB) covers two and two thirds of them
+      const int o = ins * 64 + lane;   // 16-byte chunk index in the linear image
+      const int krow = o / 24, pos = o - krow * 24;
+      int c = pos - kswz<8>(krow);     // inverse of kpos<24>
+      if (c < 0) c += 24;
+      const int col = min(n0 + c * 8, g.N - 8);
+      offB[i] = (int64_t)krow * g.ldb + col;
     } else if constexpr (BN == 128) {
       const int krow = ins * 4 + (lane >> 4), c = (lane & 15) ^ kswz<16>(krow);
       const int col = min(n0 + c * 8, g.N - 8);
@@ -183,8 +204,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
         constexpr int ROWB = BN * 2;
         const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
         const int c = col >> 3, h = (col & 7) >> 2;
-        const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ kswz<BN / 8>(k)) << 4) + h * 8);
-        const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ kswz<BN / 8>(k + 4)) << 4) + h * 8);
+        const h4 lo = lds_tr_read<h4>(bB + k * ROWB + (kpos<BN / 8>(c, k) << 4) + h * 8);
+        const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + (kpos<BN / 8>(c, k + 4) << 4) + h * 8);
         bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
@@ -198,6 +219,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       if (t + 1 < nk) {
         if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if constexpr (IA + IB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (IA + IB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
@@ -261,6 +283,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       GEMM_PHASE(ph_issue);
       if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if constexpr (IA + IB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (IA + IB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       else if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -297,8 +320,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
           constexpr int ROWB = BN * 2;
           const int k = kk * 32 + fq * 8 + tq, col = wn0 + j * 16 + tp * 4;
           const int c = col >> 3, h = (col & 7) >> 2;
-          const h4 lo = lds_tr_read<h4>(bB + k * ROWB + ((c ^ kswz<BN / 8>(k)) << 4) + h * 8);
-          const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + ((c ^ kswz<BN / 8>(k + 4)) << 4) + h * 8);
+          const h4 lo = lds_tr_read<h4>(bB + k * ROWB + (kpos<BN / 8>(c, k) << 4) + h * 8);
+          const h4 hi = lds_tr_read<h4>(bB + (k + 4) * ROWB + (kpos<BN / 8>(c, k + 4) << 4) + h * 8);
           bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       }
@@ -444,6 +467,11 @@ static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 64, 2, 2>), dim3(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 128)), dim3(256), 0, st, a, no_group);
     return;
   }
+  if (bn == 193) {  // 128 x 192 tile on eight waves (2 x 4, wave tile 64 x 48): a sixth less L2 -> LDS traffic per flop than 128 x 128
+    dim3 grid(d2r_cdiv(a.N, 192), d2r_cdiv(a.M, 128));
+    if constexpr (LAYOUT != D2R_GEMM_TN) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 192, 4>), grid, dim3(512), 0, st, a, no_group);
+    return;
+  }
   if (bn == 129) {  // 128 x 128 tile on EIGHT waves (2 x 4): per wave as the 128x64 kernel, a third less L2 traffic per flop
     dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
     if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 4, 1>), grid, dim3(512), 0, st, a, no_group);
@@ -470,6 +498,7 @@ extern "C" void d2r_gemm_debug_stamps(unsigned long long* dst) { g_gemm_stamps =
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st) {
   if (!d2r_is16(a.dtype) || batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
   if ((bn % 1000) == 129 && a.N < 128) return 0;
+  if (bn == 193 && (a.N < 192 || layout == D2R_GEMM_TN)) return 0;
   if (!a.vecA || !a.vecB) return 0;
   if (a.G && !(a.vecC && a.c_dtype == a.dtype)) return 0;  // the activation-gradient epilogue is in the vectorised path only
   const bool a_strided = layout == D2R_GEMM_TN, b_strided = layout != D2R_GEMM_NT;
@@ -479,7 +508,7 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
   ab.ts = g_gemm_stamps;
   {
     // column bands for wide outputs: the B panels of a band (band x BN x K x 2 bytes) should take about a third of the 4 MB L2
-    const int bnw = (bn % 1000) == 64 ? 64 : 128;
+    const int bnw = (bn % 1000) == 64 ? 64 : bn == 193 ? 192 : 128;
     const int gx = d2r_cdiv(a.N, bnw);
     const int64_t panel = (int64_t)bnw * a.K * 2;
     int band = (int)((int64_t)(1536 << 10) / (panel > 0 ? panel : 1));
@@ -489,7 +518,7 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
     //  alone on the GPU and +2 GB per step past L2 for the 128x64 dX kernel)
     ab.band = (band_on && a.K <= 1536 && gx > band && gx * panel > (3 << 20)) ? band : 0;
   }
-  d2r_gemm_variant_tl = ((bn % 1000) == 64 ? 1 : (bn % 1000) == 128 ? 2 : 3) + (bn >= 1000 ? 10 : 0);
+  d2r_gemm_variant_tl = bn == 193 ? 4 : ((bn % 1000) == 64 ? 1 : (bn % 1000) == 128 ? 2 : 3) + (bn >= 1000 ? 10 : 0);
   switch (layout) {
     case D2R_GEMM_NT: f16 ? launch_glds<f16_t, D2R_GEMM_NT>(ab, bn, st) : launch_glds<bf16_t, D2R_GEMM_NT>(ab, bn, st); break;
     case D2R_GEMM_NN: f16 ? launch_glds<f16_t, D2R_GEMM_NN>(ab, bn, st) : launch_glds<bf16_t, D2R_GEMM_NN>(ab, bn, st); break;
