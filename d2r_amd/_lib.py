@@ -44,7 +44,7 @@ class EncoderLayerDesc(C.Structure):
                                      "gln2_g", "gln2_b", "x", "y", "qkv", "ctx", "h1", "n1", "f_pre", "f", "h2", "lse",
                                      "mean1", "rstd1", "mean2", "rstd2", "dy", "dx", "scratch")]
                 + [("scratch_bytes", sz), ("splitk_ws", vp), ("splitk_bytes", sz), ("wgrad_stream", vp),
-                   ("defer_wgrad", i32), ("o_dy", vp * 4), ("p_attn", f32), ("p_hidden", f32), ("seed_attn", C.c_uint64),
+                   ("defer_wgrad", i32), ("o_dy", vp * 4), ("defer_ln", i32), ("o_lnws", vp * 2), ("p_attn", f32), ("p_hidden", f32), ("seed_attn", C.c_uint64),
                    ("seed_hidden", C.c_uint64 * 2)])
 
 
@@ -113,6 +113,7 @@ SIGNATURES = {
     "d2r_layernorm_fwd": (i32, [i32, vp, vp, vp, f32, i64, i32, vp, vp, vp, vp]),
     "d2r_layernorm_bwd_workspace": (sz, [i64, i32]),
     "d2r_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "d2r_layernorm_bwd_sum_grouped": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, i32, i32, vp]),
     "d2r_layernorm_bwd_ex": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, sz, vp]),
     "d2r_encoder_layer_bwd_scratch": (sz, [i32, i32, i32, i32]),
     "d2r_encoder_layer_fwd": (i32, [C.POINTER(EncoderLayerDesc), vp]),

@@ -90,7 +90,7 @@ extern "C" size_t d2r_encoder_layer_bwd_scratch(int B, int L, int E, int F) {
   // every intermediate gradient has its own buffer (none is reused inside the layer): the weight-gradient GEMMs
   // that read them may still be running on the side stream when the main chain has moved on
   const size_t T = (size_t)B * L, es = 2;
-  return 7 * align256(T * E * es) + align256(T * F * es) + align256(T * 3 * E * es) + align256(d2r_layernorm_bwd_workspace((int64_t)T, E)) +
+  return 7 * align256(T * E * es) + align256(T * F * es) + align256(T * 3 * E * es) + 2 * align256(d2r_layernorm_bwd_workspace((int64_t)T, E)) +
          align256(T * (size_t)(E / 32) * sizeof(float));  // + D scratch of the long-sequence attention backward (<= E/32 heads)
 }
 
@@ -168,7 +168,12 @@ extern "C" int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* L, void* stream) {
   char* dqkv = (char*)take((size_t)T * 3 * E);
   void* lnws = p;
   const size_t lnws_bytes = d2r_layernorm_bwd_workspace(T, E);
-  float* dsum = reinterpret_cast<float*>(p + align256(lnws_bytes));
+  void* lnws1 = p + align256(lnws_bytes);  // LayerNorm 1's partial sums when their summation is deferred (else both use lnws)
+  float* dsum = reinterpret_cast<float*>(p + 2 * align256(lnws_bytes));
+  const bool dln = L->defer_wgrad && L->defer_ln;
+  float *g1g = dln ? nullptr : L->gln1_g, *g1b = dln ? nullptr : L->gln1_b, *g2g = dln ? nullptr : L->gln2_g, *g2b = dln ? nullptr : L->gln2_b;
+  void* ws1 = dln ? lnws1 : lnws;
+  L->o_lnws[0] = dln ? lnws1 : nullptr, L->o_lnws[1] = dln ? lnws : nullptr;
   const char* qkv = (const char*)L->qkv;
   // gradient entering a dense layer whose output was dropped: mask(g) / (1-p); the unmasked g still feeds the skip connection
   const bool drop = L->p_hidden > 0.f;
@@ -183,11 +188,11 @@ extern "C" int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* L, void* stream) {
     // y = LN2(h2), h2 = n1 + drop(ffn(n1)), n1 = LN1(h1), h1 = x + drop(attn(x))
     void *d_h2 = a0, *d_n1 = a1, *d_h1 = a2, *d_ctx = a3;
     (void)a4;
-    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, L->dy, L->h2, L->ln2_g, L->mean2, L->rstd2, T, E, d_h2, nullptr, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, L->dy, L->h2, L->ln2_g, L->mean2, L->rstd2, T, E, d_h2, nullptr, g2g, g2b, 1, lnws, lnws_bytes, stream));
     D2R_TRY(masked(d_h2, a5, L->seed_hidden[1], &g_ffn));
     D2R_TRY(linear_bwd(L, 3, T, E, F, g_ffn, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
     D2R_TRY(linear_bwd(L, 2, T, F, E, df, L->n1, L->w_1, d_n1, d_h2, L->gw_1, L->gb_1, stream));  // ffn path + skip
-    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, d_h1, nullptr, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->h1, L->ln1_g, L->mean1, L->rstd1, T, E, d_h1, nullptr, g1g, g1b, 1, ws1, lnws_bytes, stream));
     D2R_TRY(masked(d_h1, a6, L->seed_hidden[0], &g_att));
     D2R_TRY(linear_bwd(L, 1, T, E, E, g_att, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
     D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
@@ -201,14 +206,14 @@ extern "C" int d2r_encoder_layer_bwd(d2r_encoder_layer_desc* L, void* stream) {
     D2R_TRY(masked(L->dy, a5, L->seed_hidden[1], &g_ffn));
     D2R_TRY(linear_bwd(L, 3, T, E, F, g_ffn, L->f, L->w_2, df, nullptr, L->gw_2, L->gb_2, stream, L->f_pre, L->act));  // df = d f_pre
     D2R_TRY(linear_bwd(L, 2, T, F, E, df, L->h2, L->w_1, d_h2, nullptr, L->gw_1, L->gb_1, stream));
-    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_h2, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, d_h1, L->dy, L->gln2_g, L->gln2_b, 1, lnws, lnws_bytes, stream));  // + skip
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_h2, L->h1, L->ln2_g, L->mean2, L->rstd2, T, E, d_h1, L->dy, g2g, g2b, 1, lnws, lnws_bytes, stream));  // + skip
     D2R_TRY(masked(d_h1, a6, L->seed_hidden[0], &g_att));
     D2R_TRY(linear_bwd(L, 1, T, E, E, g_att, L->ctx, L->w_o, d_ctx, nullptr, L->gw_o, L->gb_o, stream));
     D2R_TRY(d2r_mha_bwd(L->dtype, qkv, E3, L->L * E3, qkv + 2 * E, E3, L->L * E3, qkv + 4 * E, E3, L->L * E3, d_ctx, E, (int64_t)L->L * E,
                         L->mask, L->lse, dsum, dqkv, E3, L->L * E3, dqkv + 2 * E, E3, L->L * E3, dqkv + 4 * E, E3, L->L * E3, L->B, L->H,
                         L->L, L->L, dh, L->scale, L->p_attn, L->seed_attn, stream));
     D2R_TRY(linear_bwd(L, 0, T, 3 * E, E, dqkv, L->n1, L->w_qkv, d_n1, nullptr, L->gw_qkv, L->gb_qkv, stream));
-    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->x, L->ln1_g, L->mean1, L->rstd1, T, E, L->dx, d_h1, L->gln1_g, L->gln1_b, 1, lnws, lnws_bytes, stream));  // + skip
+    D2R_TRY(d2r_layernorm_bwd_ex(L->dtype, d_n1, L->x, L->ln1_g, L->mean1, L->rstd1, T, E, L->dx, d_h1, g1g, g1b, 1, ws1, lnws_bytes, stream));  // + skip
   }
   return D2R_OK;
 }

@@ -198,6 +198,43 @@ __global__ __launch_bounds__(256) void ln_sum_partials_kernel(const float* __res
   }
 }
 
+// The same sum for up to 32 LayerNorms of one shape in ONE launch (blockIdx.y = problem): the encoder layers' backward calls leave
+// their partials in scratch that outlives the call and the caller sums them with the grouped weight gradients (round 3: 52 launches
+// of a 7 us latency chain per training step -> 4).  Same walk, same order of additions per problem: bit-identical to the single sum.
+struct LnSumGroup {
+  const float* ws[32];
+  float* dg[32];
+  float* db[32];
+};
+__global__ __launch_bounds__(256) void ln_sum_partials_grouped_kernel(LnSumGroup grp, int nparts, int D, int accumulate) {
+  __shared__ float sh[16][17];
+  const float* __restrict__ ws = grp.ws[blockIdx.y];
+  const int l = threadIdx.x & 15, g16 = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + l, stride = 2 * D;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < stride) {
+    for (int p = g16; p < nparts; p += 128) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = p + u * 16;
+        t[u] = ws[(int64_t)(q < nparts ? q : g16) * stride + c] * (q < nparts ? 1.f : 0.f);
+      }
+      a0 += (t[0] + t[2]) + (t[4] + t[6]);
+      a1 += (t[1] + t[3]) + (t[5] + t[7]);
+    }
+  }
+  sh[g16][l] = a0 + a1;
+  __syncthreads();
+  if (g16 == 0 && c < stride) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += sh[g][l];
+    float* dst = c < D ? grp.dg[blockIdx.y] + c : grp.db[blockIdx.y] + (c - D);
+    *dst = accumulate ? *dst + t : t;
+  }
+}
+
 // =====================================================================================================
 // LayerNorm: wave per row, row kept in registers as 16-byte packs (D % VEC == 0, D <= 64*VEC*MAXP)
 // =====================================================================================================
@@ -422,7 +459,7 @@ extern "C" int d2r_layernorm_fwd(int dtype, const void* X, const float* gamma, c
 extern "C" int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, const float* gamma, const float* mean,
                                     const float* rstd, int64_t rows, int D, void* dX, const void* dres, float* dgamma,
                                     float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-  D2R_REQUIRE(dY && X && gamma && mean && rstd && dX && dgamma && dbeta, "d2r_layernorm_bwd: null pointer");
+  D2R_REQUIRE(dY && X && gamma && mean && rstd && dX && ((dgamma != nullptr) == (dbeta != nullptr)), "d2r_layernorm_bwd: null pointer");
   D2R_REQUIRE(d2r_aligned16(X) && d2r_aligned16(dY) && d2r_aligned16(dX) && d2r_aligned16(dres), "d2r_layernorm_bwd: tensors must be 16-byte aligned");
   if (workspace_bytes < d2r_layernorm_bwd_workspace(rows, D) || !workspace)
     return d2r_fail(D2R_ERR_WORKSPACE, "d2r_layernorm_bwd: workspace %zu < %zu", workspace_bytes, d2r_layernorm_bwd_workspace(rows, D));
@@ -448,8 +485,26 @@ extern "C" int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, co
     return d2r_fail(D2R_ERR_INVALID, "d2r_layernorm_bwd: bad dtype %d", dtype);
   }
   if (int rc = d2r_check_launch("d2r_layernorm_bwd")) return rc;
+  if (!dgamma) return D2R_OK;  // deferred: the partials stay in `workspace` for d2r_layernorm_bwd_sum_grouped
   hipLaunchKernelGGL(ln_sum_partials_kernel, dim3(d2r_cdiv(2 * D, 16)), dim3(256), 0, st, ws, nb, D, dgamma, dbeta, accumulate);
   return d2r_check_launch("d2r_layernorm_bwd(sum)");
+}
+
+extern "C" int d2r_layernorm_bwd_sum_grouped(const void* const* partials, float* const* dgamma, float* const* dbeta, int n, int64_t rows,
+                                             int D, int accumulate, void* stream) {
+  D2R_REQUIRE(partials && dgamma && dbeta && n >= 0 && rows >= 1 && D >= 1, "d2r_layernorm_bwd_sum_grouped: bad argument");
+  const int nb = ln_blocks(rows);
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    const int m = n - i0 < 32 ? n - i0 : 32;
+    LnSumGroup grp;
+    for (int i = 0; i < m; ++i) {
+      D2R_REQUIRE(partials[i0 + i] && dgamma[i0 + i] && dbeta[i0 + i], "d2r_layernorm_bwd_sum_grouped: null pointer in problem %d", i0 + i);
+      grp.ws[i] = (const float*)partials[i0 + i], grp.dg[i] = dgamma[i0 + i], grp.db[i] = dbeta[i0 + i];
+    }
+    hipLaunchKernelGGL(ln_sum_partials_grouped_kernel, dim3(d2r_cdiv(2 * D, 16), m), dim3(256), 0, (hipStream_t)stream, grp, nb, D, accumulate);
+    if (int rc = d2r_check_launch("d2r_layernorm_bwd_sum_grouped")) return rc;
+  }
+  return D2R_OK;
 }
 
 extern "C" int d2r_layernorm_bwd(int dtype, const void* dY, const void* X, const float* gamma, const float* mean,

@@ -149,7 +149,37 @@ def _iparr(ptrs):
     return arr
 
 
+DEFER_LN = os.environ.get("D2R_DEFER_LN", "1") != "0"  # second stage of the encoder layers' LayerNorm backward: one launch per group of layers
+
+
+def _defer_ln_sum(rows, D, ws_ptr, g_sink, b_sink, params, keepalive, flush_at=None):
+    """Queue the summation of one LayerNorm's per-block partial gradients (left in scratch by d2r_encoder_layer_bwd) into its
+    gamma / beta sinks; launched with the grouped weight gradients of the same layers (d2r_layernorm_bwd_sum_grouped)."""
+    cur = torch.cuda.current_stream()
+    q = _WGRAD_Q.get(cur.cuda_stream)
+    if q is None:
+        q = _WGRAD_Q[cur.cuda_stream] = {"stream": cur, "jobs": {}}
+    key = ("ln", int(rows), int(D))
+    jobs = q["jobs"].setdefault(key, [])
+    if any(j[1] == g_sink for j in jobs):  # one LayerNorm used at two call sites: its sums must not share a launch
+        _flush_wgrad_group(key, q["jobs"].pop(key))
+        jobs = q["jobs"].setdefault(key, [])
+    jobs.append((ws_ptr, g_sink, b_sink, None, params, keepalive))
+    if len(jobs) >= (flush_at or _WGRAD_FLUSH_AT):
+        _flush_wgrad_group(key, q["jobs"].pop(key))
+
+
 def _flush_wgrad_group(key, jobs):
+    if key[0] == "ln":
+        _, rows, D = key
+        _lib.call("d2r_layernorm_bwd_sum_grouped", _iparr([j[0] for j in jobs]), _iparr([j[1] for j in jobs]), _iparr([j[2] for j in jobs]),
+                  len(jobs), rows, D, 1, _stream(), meta=dict(group="d2r_layernorm_bwd_sum"))
+        for j in jobs:  # data-parallel bucket readiness (d2r_amd.dp)
+            for p in j[4]:
+                cb = getattr(p, "_d2r_ready_cb", None) if p is not None else None
+                if cb is not None:
+                    cb(p)
+        return
     dt, N, K, M, lda_x, has_b = key
     n = len(jobs)
     A, B, Cc = _iparr([j[0] for j in jobs]), _iparr([j[1] for j in jobs]), _iparr([j[2] for j in jobs])
@@ -862,6 +892,7 @@ class _EncoderLayer(torch.autograd.Function):
         side = wgrad_side_stream_handle()
         defer = DEFER_WGRAD and side is None
         d.defer_wgrad = int(defer)
+        d.defer_ln = int(defer and DEFER_LN)
         if defer:  # the four weight gradients are launched later, grouped with the other layers': scratch must survive
             scratch = torch.empty(need, dtype=torch.uint8, device=g.device)
             ws = _workspace(64 << 20, g.device)
@@ -890,7 +921,12 @@ class _EncoderLayer(torch.autograd.Function):
                                                           (Fi, E, ffn_in, d.gw_1, d.gb_1), (E, Fi, d.f, d.gw_2, d.gb_2))):
                 _defer_wgrad_raw(d.dtype, N, K, T, K, d.o_dy[which], xin, gw, gb, (P[2 * which], P[2 * which + 1]), keep,
                                  flush_at=D2R_LAYER_GROUP)
-            ready = bundle.params[8:]  # LayerNorm gradients were accumulated inside the call
+            if d.defer_ln:  # ... and the two LayerNorms' gamma / beta gradients: their partial sums sit in `scratch`
+                for i, (gs, bs) in enumerate(((d.gln1_g, d.gln1_b), (d.gln2_g, d.gln2_b))):
+                    _defer_ln_sum(T, E, d.o_lnws[i], gs, bs, (P[8 + 2 * i], P[9 + 2 * i]), keep, flush_at=2 * D2R_LAYER_GROUP)
+                ready = ()
+            else:
+                ready = bundle.params[8:]  # LayerNorm gradients were accumulated inside the call
         else:
             ready = bundle.params
         ctx.keep = None

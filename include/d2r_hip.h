@@ -266,6 +266,11 @@ int d2r_block_merge_bwd(int dtype, const void* m0, const void* m1, const float* 
 int d2r_layernorm_bwd_ex(int dtype, const void* dY, const void* X, const float* gamma, const float* mean,
                          const float* rstd, int64_t rows, int D, void* dX, const void* dres, float* dgamma,
                          float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* dgamma == dbeta == NULL in d2r_layernorm_bwd_ex DEFERS the second stage: the per-block partial sums stay in `workspace` (which
+ * then has to outlive the call) and this entry point sums them for n LayerNorms of one shape (rows, D) in one launch per 32
+ * problems; dgamma[i] / dbeta[i] overwritten, or accumulated when accumulate != 0.  Bit-identical to the undeferred sum. */
+int d2r_layernorm_bwd_sum_grouped(const void* const* partials, float* const* dgamma, float* const* dbeta, int n, int64_t rows,
+                                  int D, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3 fused multi-head attention core (16-bit dtypes, head_dim 64 or 48, Lq, Lk <= 1024: up to 256 tokens with the whole
@@ -374,6 +379,11 @@ typedef struct {
   /* bwd, written by the call: the output gradients of the qkv / out / fc1 / fc2 linears ([T,3E] [T,E] [T,F] [T,E], inside
    * `scratch` or dy itself) — dW = o_dy^T x with x = x|n1, ctx, n1|h2, f. */
   const void* o_dy[4];
+  /* bwd, with defer_wgrad: != 0 also defers the second stage of the two LayerNorm backward passes (their gamma / beta gradients):
+   * the call writes the per-block partial sums into `scratch` and reports them in o_lnws[0] (LayerNorm 1) / o_lnws[1] (LayerNorm 2);
+   * the caller sums them later with d2r_layernorm_bwd_sum_grouped(rows = B*L, D = E, accumulate = 1) into gln{1,2}_{g,b}. */
+  int defer_ln;
+  const void* o_lnws[2];
   /* training-time dropout of the BERT layer (models/modeling_unimo.py:388 on the attention probabilities, :413 / :468 on
    * the two dense outputs in front of their residual adds); 0 disables.  The masks are functions of (seed, element index)
    * as in d2r_dropout: the probabilities use seed_attn inside the fused attention core, the dense outputs seed_hidden[0]

@@ -592,6 +592,63 @@ def test_encoder_layer_one_call_matches_op_by_op(gpu, kind, lowp, monkeypatch):
         assert r < 2e-2, (n, r)
 
 
+@pytest.mark.parametrize("kind", ["bert", "clip"])
+def test_encoder_layers_deferred_layernorm_sums_are_bit_identical(gpu, kind):
+    """The second stage of the LayerNorm backward (per-block partial sums -> gamma / beta gradients) deferred out of
+    d2r_encoder_layer_bwd and launched once per group of layers (d2r_layernorm_bwd_sum_grouped) against the sum inside the call:
+    the same additions in the same order - every gradient of a three-layer stack is bit-identical."""
+    from d2r_amd import functional as F
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig
+    from d2r_amd.params import ParamStore
+    torch.manual_seed(5)
+    if kind == "bert":
+        layers = [M.BertLayer(TextConfig(num_hidden_layers=3, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)) for _ in range(3)]
+        B, L = 3, 37
+    else:
+        layers = [M.CLIPEncoderLayer(VisionConfig(num_hidden_layers=3, image_size=64, patch_size=32)) for _ in range(3)]
+        B, L = 2, 50
+
+    class Stack(M.D2RModule):
+        def __init__(self, layers):
+            super().__init__()
+            self.layers = torch.nn.ModuleList(layers)
+
+    model = Stack(layers).to(gpu)
+    model.set_compute_dtype(torch.float16).train()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "LayerNorm" in n or "layer_norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    store = ParamStore(model, torch.float16)
+    x0 = torch.randn(B, L, 768, device=gpu).half()
+    gy = torch.randn(B, L, 768, device=gpu).half()
+    mask = torch.zeros(B, L, device=gpu)
+    res = {}
+    saved = F.DEFER_LN
+    try:
+        for defer in (False, True):
+            F.DEFER_LN = defer
+            store.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = x
+            for layer in model.layers:
+                y = layer(y, mask) if kind == "bert" else layer(y)
+            assert type(y.grad_fn).__name__ == "_EncoderLayerBackward"
+            y.backward(gy)
+            F.flush_wgrads()
+            torch.cuda.synchronize()
+            res[defer] = (x.grad.clone(), store.flat_g.clone())
+    finally:
+        F.DEFER_LN = saved
+    assert torch.equal(res[False][0], res[True][0]), "input gradient differs"
+    g0, g1 = res[False][1], res[True][1]
+    ln = [(n, o, k) for n, p, o, k, _ in store.entries if "LayerNorm" in n or "layer_norm" in n]
+    assert len(ln) == 12 and all(float(g0[o:o + k].abs().max()) > 0 for _, o, k in ln), "the LayerNorm gradients were not produced"
+    bad = [n for n, p, o, k, _ in store.entries if not torch.equal(g0[o:o + k], g1[o:o + k])]
+    assert not bad, f"gradients differ: {bad[:6]} ({len(bad)} tensors)"
+
+
 @pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [("text", 6, 3, 3, 24, 10, True), ("image", 6, 4, 2, 10, 24, True), ("text", 4, 3, 2, 16, 7, True),
                                  ("image", 6, 3, 2, 12, 9, False), ("text", 6, 2, 2, 9, 5, True)],
