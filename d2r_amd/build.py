@@ -23,6 +23,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 
 # per-file additions to FLAGS
 EXTRA_FLAGS = {"routing.hip": ["-fno-slp-vectorize"]}
+if os.environ.get("D2R_GEMM_PROBES", "0") != "0":  # measurement build: cycle stamps / ablation switches inside the LDS-DMA GEMM kernel
+    EXTRA_FLAGS["gemm_glds.hip"] = ["-DD2R_GEMM_PROBES=1"]
+if os.environ.get("D2R_GEMM_ILV", "1") == "0":  # A/B build: DMA instructions of the pipelined K-loop issued in one run
+    EXTRA_FLAGS["gemm_glds.hip"] = EXTRA_FLAGS.get("gemm_glds.hip", []) + ["-DD2R_GEMM_ILV=0"]
 
 
 def _hipcc() -> str:

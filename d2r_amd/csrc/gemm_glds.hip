@@ -14,6 +14,13 @@
 // bf16, batch 1, K % 64 == 0, 16-B aligned operands, and M % 8 == N % 8 == 0 for k-strided operands.
 #include "gemm_args.h"
 
+#ifndef D2R_GEMM_PROBES
+#define D2R_GEMM_PROBES 0
+#endif
+#ifndef D2R_GEMM_ILV  // software-pipelined K-loop: DMA instructions of tile t+2 interleaved with the MFMAs (0: issued in one run; A/B by rebuild)
+#define D2R_GEMM_ILV 1
+#endif
+
 
 // XOR mask (in 16-byte chunks) of k-row k of a k-strided image with CH chunks per row.  One 32-lane group of ds_read_b64_tr_b16
 // touches the eight k-rows k0 + {0..3, 8..11} (then + 4), 32 contiguous bytes = one chunk PAIR of each.  Rows of 256 or 512 bytes
@@ -74,7 +81,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
-  const bool stamping = g.ts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  // the probes' hooks (cycle stamps of workgroup (0,0), ablation switches g.dbg: tests/probes/gemm_stamps.py, gemm_ablation.py) exist only
+  // in a library built with -DD2R_GEMM_PROBES=1 (D2R_GEMM_PROBES=1 python -m d2r_amd.build): as run-time branches they cut the K-loop
+  // into a dozen basic blocks per step, which kept the compiler from moving the second half-step's fragment reads over the first
+  // half-step's MFMAs
+  constexpr bool PROBES = D2R_GEMM_PROBES != 0;
+  const int dbg = PROBES ? g.dbg : 0;
+  const bool stamping = PROBES && g.ts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
 #define GEMM_STAMP(i) do { if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g.ts[wave * 8 + (i)] = t_; } } while (0)
   GEMM_STAMP(0);
   int tile_m, tile_n, z = 0;
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
   // the end are CLAMPED to the last valid row here and the A rows are zeroed in LDS before they are read (see the K-loop)
   const int nk_w = (g.K + BK - 1) / BK, rem_w = g.K - (nk_w - 1) * BK;
   auto issue = [&](int t, int buf) {
-    if (g.dbg == 2) return;
+    if (dbg == 2) return;
     const int k0 = t * BK;
     unsigned char* base = smem + buf * BUF;
     int64_t adjA = 0, adjB = 0;
@@ -169,6 +182,32 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       const E* src = B + offB[i] + adjB + (B_KCONT ? (int64_t)k0 : (int64_t)k0 * g.ldb);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  // one DMA instruction of tile t (idx < IA: A piece idx, else B piece idx - IA); called with compile-time indices from unrolled loops
+  auto issue_one = [&](int t, int buf, int idx) {
+    const int k0 = t * BK;
+    unsigned char* base = smem + buf * BUF;
+    if (idx < IA) {
+      int64_t adjA = 0;
+      if constexpr (RAGGED) {
+        const int krow = (wave + NW * idx) * AROWS + lane / ACH;
+        adjA = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.lda : 0;
+      }
+      const E* src = A + offA[idx] + adjA + (A_KCONT ? (int64_t)k0 : (int64_t)k0 * g.lda);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + (wave + NW * idx) * 1024), 16, 0, 0);
+    } else {
+      const int ib = idx - IA;
+      int64_t adjB = 0;
+      if constexpr (RAGGED) {
+        const int krow = (wave + NW * ib) * 4 + (lane >> 4);
+        adjB = (t == nk_w - 1 && krow >= rem_w) ? (int64_t)(rem_w - 1 - krow) * g.ldb : 0;
+      }
+      const E* src = B + offB[ib] + adjB + (B_KCONT ? (int64_t)k0 : (int64_t)k0 * g.ldb);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * ib) * 1024), 16, 0, 0);
     }
   };
 
@@ -259,12 +298,34 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       __builtin_amdgcn_sched_barrier(0);
       // every wave has its fragments in registers: buffer `cur` is free -> refill it with tile t+2 while the second half runs
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (t + 2 < nk) issue(t + 2, cur);
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!D2R_GEMM_ILV) {
+        if (t + 2 < nk) issue(t + 2, cur);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = H16<E>::mfma32(bf1[j], af1[i], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = H16<E>::mfma32(bf1[j], af1[i], acc[i][j]);
+      } else {
+        // the DMA instructions of tile t+2 go out BETWEEN the MFMAs of the second half-step (one per STRIDE MFMAs): issued in one
+        // run they queue up behind the texture addresser (1 KiB = 16 cycles each, eight waves at once) and the wave's MFMAs wait
+        constexpr int NM = TM * TN, ND = IA + IB, STRIDE = NM / ND > 0 ? NM / ND : 1;
+        const bool more = t + 2 < nk;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const int i = m / TN, j = m % TN;
+          acc[i][j] = H16<E>::mfma32(bf1[j], af1[i], acc[i][j]);
+          if (m % STRIDE == STRIDE - 1 && m / STRIDE < ND) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_one(t + 2, cur, m / STRIDE);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if constexpr (ND > NM / STRIDE) {
+#pragma unroll
+          for (int r = NM / STRIDE; r < ND; ++r)
+            if (more) issue_one(t + 2, cur, r);
+        }
+      }
     }
   } else {
   issue(0, 0);
@@ -325,15 +386,32 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
           bfr[j] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       }
+      if constexpr (!A_KCONT || !B_KCONT) lds_reads_done();  // (asm transposed reads are not tracked by the compiler)
       if constexpr (PIPE == 2) {
-        if (kk == 0 && t + 1 < nk) {
-          __builtin_amdgcn_sched_barrier(0);  // the reads above are issued; the DMA instructions go out while they are in flight
-          issue(t + 1, cur ^ 1);              // (buffer cur^1 was last read in iteration t-1, behind its closing barrier)
-          __builtin_amdgcn_sched_barrier(0);
+        if (kk == 0) {
+          // the DMA instructions of tile t+1 go out BETWEEN the MFMAs of the first half-step (buffer cur^1 was last read in
+          // iteration t-1, behind its closing barrier): one per STRIDE MFMAs, see the pipelined loop above
+          constexpr int NM = TM * TN, ND = IA + IB, STRIDE = NM / ND > 0 ? NM / ND : 1;
+          const bool more = t + 1 < nk;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {
+            const int i = m / TN, j = m % TN;
+            acc[i][j] = H16<E>::mfma32(bfr[j], af[i], acc[i][j]);
+            if (m % STRIDE == STRIDE - 1 && m / STRIDE < ND) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (more) issue_one(t + 1, cur ^ 1, m / STRIDE);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if constexpr (ND > NM / STRIDE) {
+#pragma unroll
+            for (int r = NM / STRIDE; r < ND; ++r)
+              if (more) issue_one(t + 1, cur ^ 1, r);
+          }
+          continue;
         }
       }
-      if constexpr (!A_KCONT || !B_KCONT) lds_reads_done();  // (asm transposed reads are not tracked by the compiler)
-      if (g.dbg == 1) {
+      if (dbg == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
@@ -382,7 +460,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
     }
     return;
   }
-  if (g.dbg == 3) {  // (every accumulator kept live: the MFMAs must not be eliminated with the epilogue)
+  if (dbg == 3) {  // (every accumulator kept live: the MFMAs must not be eliminated with the epilogue)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -403,7 +481,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
         Pack<E, 4> pk;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float bv = (g.bias && g.dbg != 4 && col + r < g.N) ? g.bias[col + r] : 0.f;
+          const float bv = (g.bias && dbg != 4 && col + r < g.N) ? g.bias[col + r] : 0.f;
           pk.v[r] = (E)(g.alpha * acc[i][j][r] + bv);
         }
         st_pack<E, 4>(Cs + (i * 16 + fr) * LDE + j * 16 + fq * 4, pk);
@@ -424,7 +502,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       const Pack<E, 8> pv = ld_pack<E, 8>(Cs + rl * LDE + ch * 8);
       const int64_t ci = (int64_t)row * g.ldc + col;
       const int64_t ri = (int64_t)row * g.ldr + col;
-      if (g.dbg == 5) continue;
+      if (dbg == 5) continue;
       epilogue_pack8(g, pv, Cg, Pg, Rg, Gg, ci, ri, g.N - col);
     }
     if (stamping) {
