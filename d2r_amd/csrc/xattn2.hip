@@ -24,6 +24,12 @@
 
 #include "gemm_args.h"
 
+// the ablation switches (D2R_X2_DBG) are compiled in only with -DD2R_X3_PROBES=1 (run-time branches in the tile loops otherwise)
+#ifndef D2R_X3_PROBES
+#define D2R_X3_PROBES 0
+#endif
+#define X2_DBG(a) (D2R_X3_PROBES ? (a).dbg : 0)
+
 namespace {
 
 constexpr int X2_MAXCORE = 4;  // attention problems ("cores") of one launch: same shapes and strides, own tensors
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
     const int o = (wave * 3 + i) * 1024 + lane * 16;
     const int row = o / ROWB, cp = (o - row * ROWB) >> 4;
     prow[i] = row;
-    pcol[i] = (a.dbg == 3 ? cp : swz(cp, row)) * 8;  // the swizzle is an involution: image position cp of row `row` holds source chunk swz(cp,row)
+    pcol[i] = (X2_DBG(a) == 3 ? cp : swz(cp, row)) * 8;  // the swizzle is an involution: image position cp of row `row` holds source chunk swz(cp,row)
   }
   auto issue = [&](int g) {
     const bool isv = g >= nkc;
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
     const int64_t ld = isv ? a.ldv : a.ldk;
     const int key0 = (isv ? g - nkc : g) * CH;
     unsigned char* base = smem + L::RING + (g & (NB - 1)) * CB;
-    if (a.dbg == 1) return;
+    if (X2_DBG(a) == 1) return;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int key = min(key0 + prow[i], a.Lk - 1);  // clamped: masked (-inf) scores / zero probabilities for keys >= Lk
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
     wait_chunk(g);
     if (g + 3 < G) issue(g + 3);  // slot (g+3)&3 = (g-1)&3: every wave finished chunk g-1 before the barrier above
     const unsigned char* slot = smem + L::RING + (g & (NB - 1)) * CB;
-    if (a.dbg == 2) continue;
+    if (X2_DBG(a) == 2) continue;
     f32x4 s[NQT];
 #pragma unroll
     for (int t = 0; t < NQT; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(512) void xattn2_fwd_kernel(X2Args<E> a) {
     if (g + 3 < G) issue(g + 3);
     const unsigned char* slot = smem + L::RING + (g & (NB - 1)) * CB;
     const int key0 = (g - nkc) * CH;
-    if (a.dbg == 2) continue;
+    if (X2_DBG(a) == 2) continue;
     E4 pf[NQT];
 #pragma unroll
     for (int t = 0; t < NQT; ++t) pf[t] = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(Sm + (t * 16 + fr) * LSS) + key0 + fq * 4);

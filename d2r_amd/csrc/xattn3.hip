@@ -35,6 +35,11 @@
 
 #include "gemm_args.h"
 
+#ifndef D2R_X3_PROBES
+#define D2R_X3_PROBES 0
+#endif
+constexpr bool X3_PROBES = D2R_X3_PROBES != 0;
+
 namespace {
 
 constexpr int X3_MAXCORE = 4;
@@ -165,9 +170,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const E* Vg = x3_pick(a.v, core) + b * a.svb;
   float* Ms = reinterpret_cast<float*>(smem + NS * CB);
   const int nkc = (a.Lk + CH - 1) / CH, G = 2 * nkc;
-  unsigned long long tsv[40];
-  const bool stamping = a.ts != nullptr && blockIdx.x == 0;
-#define X3_STAMP(i) do { if (stamping) tsv[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  // (the probes' hooks - cycle stamps, ablation switches - are compiled in only with -DD2R_X3_PROBES=1, D2R_X3_PROBES=1 python -m
+  //  d2r_amd.build: as run-time branches they cost forty 64-bit registers and a basic-block boundary per tile in the production kernel)
+  unsigned long long tsv[X3_PROBES ? 40 : 1];
+  const int dbg = X3_PROBES ? a.dbg : 0;
+  const bool stamping = X3_PROBES && a.ts != nullptr && blockIdx.x == 0;
+#define X3_STAMP(i) do { if (X3_PROBES && stamping) tsv[X3_PROBES ? (i) : 0] = __builtin_amdgcn_s_memtime(); } while (0)
   X3_STAMP(0);
 
   for (int key = tid; key < LKMAX; key += 256) Ms[key] = key < a.Lk ? (a.mask ? a.mask[(int64_t)b * a.Lk + key] : 0.f) : -INFINITY;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // pieces [i0, i1) of chunk g  (issuing the six pieces of a chunk two at a time between the MFMA batches of a step measured SLOWER
   // than all six right behind the barrier: 48 vs 40 us for three problems of the text branch)
   auto issue_pieces = [&](int g, int i0, int i1) {
-    if (a.dbg == 1 || g >= G) return;
+    if (dbg == 1 || g >= G) return;
     const bool isv = g >= nkc;
     const E* src = isv ? Vg : Kg;
     const int ld = (int)(isv ? a.ldv : a.ldk);  // (per-sample offsets fit 32 bits: checked on the host)
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       ring_wait(t);
       const int gn = t + NS - 1;  // next chunk, into the slot of chunk t - 1: every wave left it before the barrier above
       const unsigned slot = sbase + (t % NS) * CB;
-      if (a.dbg == 2) { issue(gn); s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+      if (dbg == 2) { issue(gn); s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
       const f32x4 m4 = lds_b128<f32x4>(mbase + t * CH * 4);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       E8 kf[2][8];  // three batches of eight k-steps, the next batch in flight behind the MFMAs of the current one
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       asm volatile("s_barrier" ::: "memory");    // ... for every wave, and everybody has left the chunks before g0
       for (int gn = issued + 1; gn <= g0 + NS - 1; ++gn) issue(gn);  // chunk x goes into the slot chunk x - NS has left
       issued = max(issued, g0 + NS - 1);
-      if (a.dbg == 2 || a.dbg == 3) continue;
+      if (dbg == 2 || dbg == 3) continue;
       const unsigned slot0 = sbase + (g0 % NS) * CB, slot1 = sbase + (g1 % NS) * CB;
       E8 pp;
 #pragma unroll
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     st_pack<E, 8>(Og + (int64_t)qrow * a.ldo + ch * 8, v);
   }
   if (fq == 0 && q0 + fr < a.Lq) x3_pick(a.lse, core)[(int64_t)b * a.Lq + q0 + fr] = mx + logf(sum);
-  if (stamping) {
+  if constexpr (X3_PROBES) if (stamping) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tsv[36] = __builtin_amdgcn_s_memtime();
     if (lane == 0)
