@@ -1,5 +1,6 @@
 """Where does workgroup (0,0) of the LDS-DMA GEMM kernel spend its cycles?  (s_memtime stamps, d2r_gemm_debug_stamps)
-    python tests/probes/gemm_stamps.py"""
+    python tests/probes/gemm_stamps.py
+NOTE: the stamps exist only in a measurement build of the library: D2R_GEMM_PROBES=1 python -m d2r_amd.build (then rebuild without it)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
