@@ -1,3 +1,5 @@
+"""Ablation of the LDS-DMA GEMM kernel (D2R_GEMM_DBG: 1 = no MFMA, 2 = no DMA issue, 3 = no epilogue stores) on the workload's shapes.
+NOTE: the switches exist only in a measurement build of the library: D2R_GEMM_PROBES=1 python -m d2r_amd.build (then rebuild without it)."""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from d2r_amd import _lib

@@ -1,5 +1,6 @@
 """Timing probe of the cross-attention kernels at the C2 shapes (three problems per launch, as the routing layers issue them).
-    D2R_X3_DBG=<mode> python tests/probes/xattn3_probe.py        (modes: see xattn3.hip; 0 = the real kernel)"""
+    D2R_X3_DBG=<mode> python tests/probes/xattn3_probe.py        (modes: see xattn3.hip; 0 = the real kernel)
+NOTE: D2R_X3_DBG / D2R_X3_STAMPS act only on a measurement build of the library: D2R_X3_PROBES=1 python -m d2r_amd.build (then rebuild without it)."""
 import os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
