@@ -571,6 +571,73 @@ static bool skinny_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
   return true;
 }
 
+// ---- short-reduction fp32 TN product: C[M,N] = alpha * A[K,M]^T B[K,N] (+ beta * C), dbias[m] += sum_k A[k,m], K <= 64 ---------------
+// The weight gradients of the linears that see one row per SAMPLE (Block fusion head, routers, poolers: K = batch size) are
+// rank-K updates of matrices with up to 1600 x 768 elements: an output-bandwidth problem (read-modify-write of C), which the tiled
+// MFMA kernel served with 64 x 64 tiles of a K-loop that is two steps long (20 us per product, five of them on the serial stretch
+// between forward and backward).  Here a workgroup owns a 64 x 64 tile of C, stages the K x 64 slices of both operands in LDS
+// (coalesced 256-byte rows) and every thread accumulates a 4 x 4 block with k ascending - plain FMAs, a fixed order - then
+// read-modify-writes its four float4.  Batched like the other kernels (blockIdx.z).
+__global__ __launch_bounds__(256) void gemm_rank_tn_f32_kernel(GemmArgs g) {
+  constexpr int KMAX = 64;
+  __shared__ float As[KMAX][64 + 4], Bs[KMAX][64 + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int z = blockIdx.z, zb = z / g.nh, zh = z - zb * g.nh;
+  const float* A = reinterpret_cast<const float*>(g.A) + zb * g.sAb + zh * g.sAh;
+  const float* B = reinterpret_cast<const float*>(g.B) + zb * g.sBb + zh * g.sBh;
+  float* C = reinterpret_cast<float*>(g.C) + zb * g.sCb + zh * g.sCh;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  for (int e = tid; e < g.K * 64; e += 256) {
+    const int k = e >> 6, c = e & 63;
+    As[k][c] = (m0 + c < g.M) ? A[(int64_t)k * g.lda + m0 + c] : 0.f;
+    Bs[k][c] = (n0 + c < g.N) ? B[(int64_t)k * g.ldb + n0 + c] : 0.f;
+  }
+  __syncthreads();
+  float acc[4][4] = {};
+  for (int k = 0; k < g.K; ++k) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(&Bs[k][tx * 4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+  }
+  const bool vec = (g.ldc & 3) == 0 && n0 + tx * 4 + 4 <= g.N && (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= g.M) continue;
+    float* p = C + (int64_t)m * g.ldc + n0 + tx * 4;
+    if (vec) {
+      f32x4 o = {g.alpha * acc[i][0], g.alpha * acc[i][1], g.alpha * acc[i][2], g.alpha * acc[i][3]};
+      if (g.beta != 0.f) {
+        const f32x4 old = *reinterpret_cast<const f32x4*>(p);
+        o = f32x4{o[0] + g.beta * old[0], o[1] + g.beta * old[1], o[2] + g.beta * old[2], o[3] + g.beta * old[3]};
+      }
+      *reinterpret_cast<f32x4*>(p) = o;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + tx * 4 + j < g.N) p[j] = g.alpha * acc[i][j] + (g.beta != 0.f ? g.beta * p[j] : 0.f);
+    }
+  }
+  if (g.dbias && blockIdx.x == 0 && tid < 64 && m0 + tid < g.M) {  // (batch 1 only: checked by the dispatcher)
+    float sum = 0.f;
+    for (int k = 0; k < g.K; ++k) sum += As[k][tid];
+    g.dbias[m0 + tid] += sum;
+  }
+}
+
+static bool rank_tn_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
+  static const int on = env_int("D2R_GEMM_RANK_TN", 1);
+  if (!on || a.K < 1 || a.K > 64 || a.c_dtype != D2R_F32 || a.dtype != D2R_F32 || a.G || a.R || a.P || a.bias || a.act != D2R_ACT_NONE) return false;
+  if (a.dbias && batch != 1) return false;
+  if ((int64_t)a.M * a.N < 4096) return false;  // (tiny outputs: the tiled kernel's 32 x 64 tiles do as well)
+  hipLaunchKernelGGL(gemm_rank_tn_f32_kernel, dim3(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 64), batch), dim3(256), 0, st, a);
+  d2r_gemm_variant_tl = 32;
+  return true;
+}
+
 // ---- skinny 16-bit GEMM: M <= 32 rows of 16-bit operands (the per-sample vectors of the routing cells: GLAC's global branch,
 // GESC, the cells' cls poolers and their dX) -------------------------------------------------------------------------------------
 // Same decomposition as the fp32 kernel above - a workgroup owns 16 output columns, its four waves split K, all loads of a pass in
@@ -679,6 +746,9 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
   }
   if constexpr (sizeof(T) == 2 && LAYOUT != D2R_GEMM_TN) {
     if (skinny_h16_try<T, LAYOUT>(a, batch, st)) return d2r_check_launch("d2r_gemm(skinny 16-bit)");
+  }
+  if constexpr (sizeof(T) == 4 && LAYOUT == D2R_GEMM_TN) {
+    if (rank_tn_f32_try(a, batch, st)) return d2r_check_launch("d2r_gemm(rank-K TN)");
   }
   if constexpr (sizeof(T) == 2) {
     // large bf16 shapes: LDS-DMA pipelined 128xBN kernel (forced with tile 4 = 128x128, 5 = 128x64 for A/B runs)

@@ -467,6 +467,35 @@ def test_skinny_fp32_gemm(gpu, cfg):
     assert float((c.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("cfg", [(1600, 768, 32, 1), (768, 1600, 32, 1), (3, 768, 32, 1), (128, 768, 32, 6), (60, 80, 32, 20), (100, 70, 5, 1), (64, 64, 64, 2),
+                                 (777, 130, 17, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_rank_k_fp32_tn_gemm(gpu, cfg):
+    """The fp32 TN kernel for short reductions (K <= 64: weight gradients of the linears that see one row per sample - Block fusion head,
+    routers, poolers): C = alpha A^T B (+ beta C) and dbias[m] += sum_k A[k,m], batched, ragged edges, against fp64."""
+    from d2r_amd import functional as F
+    from d2r_amd._lib import F32, GEMM_TN
+    M, N, K, nb = cfg
+    a = rnd(nb, K, M, seed=1).to(gpu)
+    b = rnd(nb, K, N, seed=2).to(gpu)
+    c0 = rnd(nb, M, N, seed=3).to(gpu)
+    prod = a.double().transpose(1, 2) @ b.double()
+    c = torch.empty(nb, M, N, device=gpu)
+    F.gemm(GEMM_TN, M, N, K, a.data_ptr(), M, b.data_ptr(), N, c.data_ptr(), N, dtype=F32, c_dtype=F32, nb=nb, sA=(K * M, 0), sB=(K * N, 0), sC=(M * N, 0))
+    assert float((c.double() - prod).abs().max()) <= 2e-6 * float(prod.abs().max()) + 1e-6
+    c = c0.clone()
+    F.gemm(GEMM_TN, M, N, K, a.data_ptr(), M, b.data_ptr(), N, c.data_ptr(), N, dtype=F32, c_dtype=F32, nb=nb, sA=(K * M, 0), sB=(K * N, 0), sC=(M * N, 0),
+           alpha=0.5, beta=1.0)
+    want = 0.5 * prod + c0.double()
+    assert float((c.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
+    if nb == 1:  # bias gradient: accumulated into its sink
+        db0 = rnd(M, seed=4).to(gpu)
+        db, c = db0.clone(), c0.clone()
+        F.gemm(GEMM_TN, M, N, K, a.data_ptr(), M, b.data_ptr(), N, c.data_ptr(), N, dtype=F32, c_dtype=F32, beta=1.0, dbias=db.data_ptr())
+        want_b = db0.double() + a[0].double().sum(0)
+        assert float((db.double() - want_b).abs().max()) <= 2e-6 * float(want_b.abs().max()) + 1e-6
+        assert float((c.double() - (prod + c0.double())).abs().max()) <= 2e-6 * float((prod + c0.double()).abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("lowp", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [("NT", 32, 768, 768), ("NT", 8, 768, 768), ("NT", 17, 96, 1600), ("NT", 1, 16, 64), ("NN", 32, 768, 768),
                                  ("NN", 3, 128, 768), ("NN", 32, 1600, 96)], ids=lambda c: "-".join(map(str, c)))
