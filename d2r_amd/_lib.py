@@ -147,6 +147,8 @@ SIGNATURES = {
     "d2r_route_aggregate_bwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), vp, i64,
                                       i32, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), vp, vp, sz, vp]),
     "d2r_saf_gate_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "d2r_saf_dweights": (i32, [i32, vp, vp, i32, i32, i32, vp, vp]),
+    "d2r_saf_dscores": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "d2r_saf_gate_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "d2r_jsdiv_fwd": (i32, [vp, vp, i32, vp, vp]),
     "d2r_jsdiv_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp]),

@@ -578,19 +578,31 @@ static bool skinny_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
 // between forward and backward).  Here a workgroup owns a 64 x 64 tile of C, stages the K x 64 slices of both operands in LDS
 // (coalesced 256-byte rows) and every thread accumulates a 4 x 4 block with k ascending - plain FMAs, a fixed order - then
 // read-modify-writes its four float4.  Batched like the other kernels (blockIdx.z).
-__global__ __launch_bounds__(256) void gemm_rank_tn_f32_kernel(GemmArgs g) {
+// T: operand type (fp32, or a 16-bit type converted on the way into LDS); GROUPED: blockIdx.z selects one of the problems of `grp`
+// (d2r_gemm_tn_grouped: the deferred rank-B updates of the routing cells' per-sample linears), else a batch index.
+template <typename T, bool GROUPED>
+__global__ __launch_bounds__(256) void gemm_rank_tn_kernel(GemmArgs g, GemmGroup grp) {
   constexpr int KMAX = 64;
   __shared__ float As[KMAX][64 + 4], Bs[KMAX][64 + 4];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int z = blockIdx.z, zb = z / g.nh, zh = z - zb * g.nh;
-  const float* A = reinterpret_cast<const float*>(g.A) + zb * g.sAb + zh * g.sAh;
-  const float* B = reinterpret_cast<const float*>(g.B) + zb * g.sBb + zh * g.sBh;
-  float* C = reinterpret_cast<float*>(g.C) + zb * g.sCb + zh * g.sCh;
+  const int z = blockIdx.z;
+  const T *A, *B;
+  float* C;
+  float* dbias = g.dbias;
+  if constexpr (GROUPED) {
+    A = reinterpret_cast<const T*>(grp.A[z]), B = reinterpret_cast<const T*>(grp.B[z]), C = reinterpret_cast<float*>(grp.C[z]);
+    dbias = g.dbias ? grp.dbias[z] : nullptr;
+  } else {
+    const int zb = z / g.nh, zh = z - zb * g.nh;
+    A = reinterpret_cast<const T*>(g.A) + zb * g.sAb + zh * g.sAh;
+    B = reinterpret_cast<const T*>(g.B) + zb * g.sBb + zh * g.sBh;
+    C = reinterpret_cast<float*>(g.C) + zb * g.sCb + zh * g.sCh;
+  }
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   for (int e = tid; e < g.K * 64; e += 256) {
     const int k = e >> 6, c = e & 63;
-    As[k][c] = (m0 + c < g.M) ? A[(int64_t)k * g.lda + m0 + c] : 0.f;
-    Bs[k][c] = (n0 + c < g.N) ? B[(int64_t)k * g.ldb + n0 + c] : 0.f;
+    As[k][c] = (m0 + c < g.M) ? (float)A[(int64_t)k * g.lda + m0 + c] : 0.f;
+    Bs[k][c] = (n0 + c < g.N) ? (float)B[(int64_t)k * g.ldb + n0 + c] : 0.f;
   }
   __syncthreads();
   float acc[4][4] = {};
@@ -621,10 +633,10 @@ __global__ __launch_bounds__(256) void gemm_rank_tn_f32_kernel(GemmArgs g) {
         if (n0 + tx * 4 + j < g.N) p[j] = g.alpha * acc[i][j] + (g.beta != 0.f ? g.beta * p[j] : 0.f);
     }
   }
-  if (g.dbias && blockIdx.x == 0 && tid < 64 && m0 + tid < g.M) {  // (batch 1 only: checked by the dispatcher)
+  if (dbias && blockIdx.x == 0 && tid < 64 && m0 + tid < g.M) {  // (ungrouped: batch 1 only, checked by the dispatcher)
     float sum = 0.f;
     for (int k = 0; k < g.K; ++k) sum += As[k][tid];
-    g.dbias[m0 + tid] += sum;
+    dbias[m0 + tid] += sum;
   }
 }
 
@@ -633,7 +645,8 @@ static bool rank_tn_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
   if (!on || a.K < 1 || a.K > 64 || a.c_dtype != D2R_F32 || a.dtype != D2R_F32 || a.G || a.R || a.P || a.bias || a.act != D2R_ACT_NONE) return false;
   if (a.dbias && batch != 1) return false;
   if ((int64_t)a.M * a.N < 4096) return false;  // (tiny outputs: the tiled kernel's 32 x 64 tiles do as well)
-  hipLaunchKernelGGL(gemm_rank_tn_f32_kernel, dim3(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 64), batch), dim3(256), 0, st, a);
+  static const GemmGroup no_group = {};
+  hipLaunchKernelGGL((gemm_rank_tn_kernel<float, false>), dim3(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 64), batch), dim3(256), 0, st, a, no_group);
   d2r_gemm_variant_tl = 32;
   return true;
 }
@@ -941,6 +954,14 @@ static int launch_grouped_tn(const GemmArgs& base, const void* const* A, const v
       }
     }
     dim3 grid(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 64), n);
+    static const int rank_on = env_int("D2R_GEMM_RANK_TN", 1);
+    if (rank_on && a.K >= 1 && a.K <= 64 && (int64_t)a.M * a.N >= 4096) {
+      // reduction over one row per SAMPLE (pooled-vector linears of the routing cells): rank-K updates, see gemm_rank_tn_kernel
+      d2r_gemm_variant_tl = 33;
+      hipLaunchKernelGGL((gemm_rank_tn_kernel<T, true>), grid, dim3(256), 0, st, a, grp);
+      if (int rc = d2r_check_launch("d2r_gemm_tn_grouped(rank-K)")) return rc;
+      continue;
+    }
     // Operand strips fetched past L2 per round of resident workgroups (profiles/gemm_grouped_pmc_r01.txt): with whole
     // problems per XCD a round covers (resident / grid.x) row strips + grid.x column strips - right for 12 tile columns
     // (1.5x the operand bytes fetched vs 4.5x), wrong for 48 (6.3x): there the plain round-robin order, which gives an

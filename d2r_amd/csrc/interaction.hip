@@ -554,18 +554,14 @@ int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
     const Ctx& c = c2;
     const void* x = refs[1];
     TRY(d2r_l2norm_bwd(c.dt, K.de[1], L.g_wsum, L.g_ne1, K.g_dwsum, B, E, c.st));
-    G gw(c.dt, c.dt, D2R_GEMM_NT, 1, n, E, K.g_dwsum, E, L.g_S, E, K.g_dw16, n);  // d w[b] = d wsum[b] S[b]^T
-    gw.batch(B, E, (int64_t)n * E, n);
-    TRY(d2r_gemm(&gw.d, c.st));
-    G gs(c.dt, c.dt, D2R_GEMM_TN, n, E, 1, L.g_w16, n, K.g_dwsum, E, K.g_dS, E);  // d S[b] = w[b]^T d wsum[b]
-    gs.batch(B, n, E, (int64_t)n * E);
-    TRY(d2r_gemm(&gs.d, c.st));
-    TRY(d2r_cast(c.dt, K.g_dw16, D2R_F32, K.g_dwf, (int64_t)B * n, c.st));
+    // d w[b] = d wsum[b] S[b]^T (fp32), the gate's backward, then d S[b] = w[b]^T d wsum[b] + d a w_saf in ONE pass (rank-one products:
+    // as GEMMs on the tiled kernel they took 19 + 32-47 + 9 us per layer, and two casts)
+    TRY(d2r_saf_dweights(c.dt, K.g_dwsum, L.g_S, B, n, E, K.g_dwf, c.st));
     TRY(d2r_saf_gate_bwd(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, K.bn2, K.bn2 + 1, c.st));
     TRY(acc32(c, K.bn2, p.g_bn_weight, 1));
     TRY(acc32(c, K.bn2 + 1, p.g_bn_bias, 1));
-    TRY(d2r_cast(D2R_F32, K.g_daf, c.dt, K.g_da16, (int64_t)B * n, c.st));
-    TRY(dxg(c, B * n, E, 1, K.g_da16, 1, lp[D2R_RL_GLAC_SAFW].w, K.g_dS, E, 1.f));  // + d a w_saf
+    TRY(d2r_cast(D2R_F32, K.g_daf, c.dt, K.g_da16, (int64_t)B * n, c.st));  // (the weight gradient of attn_sim_w below reads it as a GEMM operand)
+    TRY(d2r_saf_dscores(c.dt, L.g_w16, K.g_dwsum, K.g_daf, lp[D2R_RL_GLAC_SAFW].w, B, n, E, K.g_dS, c.st));
     TRY(dwg(c, B * n, 1, E, K.g_da16, 1, L.g_S, E, lp[D2R_RL_GLAC_SAFW]));
     // split dS: row 0 of every sample = d sg (used in place, row stride n*E), rows 1.. = d sl (made contiguous)
     const size_t row = (size_t)E * d.es;

@@ -127,6 +127,68 @@ extern "C" int d2r_saf_gate_bwd(const float* a, const float* dw, int B, int n, c
   return d2r_check_launch("d2r_saf_gate_bwd");
 }
 
+// ---- the two rank-one products around the gate in the backward pass of the SAF-weighted sum wsum[b] = w[b] @ S[b] (S [B,n,E]) ----
+// As GEMMs (a [1,E] x [E,n] product per sample; an outer product with a reduction of ONE) they took 19-47 us each on the tiled kernel.
+//   d2r_saf_dweights: dw[b,i] = <dwsum[b,:], S[b,i,:]>                      fp32 out, a wave per row, fixed reduction order
+//   d2r_saf_dscores:  dS[b,i,:] = w[b,i] * dwsum[b,:] + da[b,i] * w_saf[:]  one pass, rounded once
+template <typename T>
+__global__ __launch_bounds__(256) void saf_dweights_kernel(const T* __restrict__ dwsum, const T* __restrict__ S, int B, int n, int E,
+                                                           float* __restrict__ dw) {
+  constexpr int VEC = PackOf<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * n) return;
+  const int b = (int)(row / n);
+  const T* s = S + row * E;
+  const T* d = dwsum + (int64_t)b * E;
+  float acc = 0.f;
+  for (int pk = lane; pk * VEC < E; pk += 64) {
+    const Pack<T, VEC> sv = ld_pack<T, VEC>(s + pk * VEC), dv = ld_pack<T, VEC>(d + pk * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc += to_f<T>(sv.v[j]) * to_f<T>(dv.v[j]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dw[row] = acc;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void saf_dscores_kernel(const T* __restrict__ w, const T* __restrict__ dwsum, const float* __restrict__ da,
+                                                          const T* __restrict__ w_saf, int B, int n, int E, T* __restrict__ dS) {
+  constexpr int VEC = PackOf<T>::N;
+  const int npk = E / VEC;
+  const int64_t total = (int64_t)B * n * npk;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t row = e / npk;
+    const int pk = (int)(e - row * npk), b = (int)(row / n);
+    const float wi = to_f<T>(w[row]), dai = da[row];
+    const Pack<T, VEC> dv = ld_pack<T, VEC>(dwsum + (int64_t)b * E + pk * VEC), sv = ld_pack<T, VEC>(w_saf + pk * VEC);
+    Pack<T, VEC> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(wi * to_f<T>(dv.v[j]) + dai * to_f<T>(sv.v[j]));
+    st_pack<T, VEC>(dS + row * E + pk * VEC, o);
+  }
+}
+
+extern "C" int d2r_saf_dweights(int dtype, const void* dwsum, const void* S, int B, int n, int E, float* dw, void* stream) {
+  D2R_REQUIRE(dwsum && S && dw && B >= 1 && n >= 1 && E >= 8 && E % 8 == 0, "d2r_saf_dweights: bad argument");
+  D2R_REQUIRE(d2r_is16(dtype) && d2r_aligned16(dwsum) && d2r_aligned16(S), "d2r_saf_dweights: 16-bit, 16-byte aligned operands");
+  const dim3 grid((unsigned)(((int64_t)B * n + 3) / 4));
+  if (dtype == D2R_BF16) hipLaunchKernelGGL(saf_dweights_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dwsum, (const bf16_t*)S, B, n, E, dw);
+  else hipLaunchKernelGGL(saf_dweights_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const f16_t*)dwsum, (const f16_t*)S, B, n, E, dw);
+  return d2r_check_launch("d2r_saf_dweights");
+}
+extern "C" int d2r_saf_dscores(int dtype, const void* w, const void* dwsum, const float* da, const void* w_saf, int B, int n, int E, void* dS,
+                               void* stream) {
+  D2R_REQUIRE(w && dwsum && da && w_saf && dS && B >= 1 && n >= 1 && E >= 8 && E % 8 == 0, "d2r_saf_dscores: bad argument");
+  D2R_REQUIRE(d2r_is16(dtype) && d2r_aligned16(dwsum) && d2r_aligned16(w_saf) && d2r_aligned16(dS), "d2r_saf_dscores: 16-bit, 16-byte aligned operands");
+  const int64_t total = (int64_t)B * n * (E / 8);
+  const dim3 grid((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256));
+  if (dtype == D2R_BF16)
+    hipLaunchKernelGGL(saf_dscores_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (const bf16_t*)dwsum, da, (const bf16_t*)w_saf, B, n, E, (bf16_t*)dS);
+  else
+    hipLaunchKernelGGL(saf_dscores_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const f16_t*)w, (const f16_t*)dwsum, da, (const f16_t*)w_saf, B, n, E, (f16_t*)dS);
+  return d2r_check_launch("d2r_saf_dscores");
+}
+
 // =====================================================================================================
 // K9 js_div (models/XModules.py:32-41) on [B,B] logits; one workgroup, wave per row
 // =====================================================================================================

@@ -241,6 +241,13 @@ int d2r_saf_gate_fwd(const float* a, int B, int n, const float* bn_weight, const
 int d2r_saf_gate_bwd(const float* a, const float* dw, int B, int n, const float* bn_weight, const float* bn_bias,
                      const float* saved, int train, float* da, float* d_bn_weight, float* d_bn_bias, void* stream);
 
+/* The two rank-one products around the gate in the BACKWARD pass of the SAF-weighted sum wsum[b] = w[b] @ S[b]
+ * (models/XModules.py:382-384; S [B,n,E], 16-bit): dw[b,i] = <dwsum[b,:], S[b,i,:]> (fp32 [B,n]) and
+ * dS[b,i,:] = w[b,i] * dwsum[b,:] + da[b,i] * w_saf[:] (w 16-bit [B,n], da fp32 [B,n], w_saf = attn_sim_w.weight [E], 16-bit). */
+int d2r_saf_dweights(int dtype, const void* dwsum, const void* S, int B, int n, int E, float* dw, void* stream);
+int d2r_saf_dscores(int dtype, const void* w, const void* dwsum, const float* da, const void* w_saf, int B, int n, int E, void* dS,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K9  js_div on two [B,B] logit matrices (models/XModules.py:32-41) and K13 cross-entropy
  * (models/unimo_model.py:147,160).  All fp32; single-workgroup latency kernels.

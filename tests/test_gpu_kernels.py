@@ -467,6 +467,31 @@ def test_skinny_fp32_gemm(gpu, cfg):
     assert float((c.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
+def test_saf_rank_one_backward_products(gpu, lowp):
+    """d2r_saf_dweights / d2r_saf_dscores (the rank-one products around the SAF gate in the backward pass of wsum[b] = w[b] @ S[b])
+    against fp64 on the rounded operands: dw[b,i] = <dwsum[b], S[b,i]>, dS[b,i] = w[b,i] dwsum[b] + da[b,i] w_saf."""
+    from d2r_amd import _lib
+    from d2r_amd.functional import _stream
+    code = _lib.BF16 if lowp == torch.bfloat16 else _lib.F16
+    eps = 2.0 ** -8 if lowp == torch.bfloat16 else 2.0 ** -11
+    for B, n in ((3, 17), (32, 129), (5, 198)):
+        E = 768
+        S = rnd(B, n, E, seed=1).to(lowp).to(gpu)
+        dwsum = rnd(B, E, seed=2).to(lowp).to(gpu)
+        w = rnd(B, n, seed=3).to(lowp).to(gpu)
+        da = rnd(B, n, seed=4).to(gpu)
+        w_saf = rnd(E, seed=5).to(lowp).to(gpu)
+        dw = torch.empty(B, n, device=gpu)
+        _lib.call("d2r_saf_dweights", code, dwsum.data_ptr(), S.data_ptr(), B, n, E, dw.data_ptr(), _stream())
+        want = torch.einsum("be,bie->bi", dwsum.double(), S.double())
+        assert float((dw.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6
+        dS = torch.empty_like(S)
+        _lib.call("d2r_saf_dscores", code, w.data_ptr(), dwsum.data_ptr(), da.data_ptr(), w_saf.data_ptr(), B, n, E, dS.data_ptr(), _stream())
+        want = w.double()[:, :, None] * dwsum.double()[:, None, :] + da.double()[:, :, None] * w_saf.double()[None, None, :]
+        assert float((dS.double() - want).abs().max()) <= eps * float(want.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("cfg", [(1600, 768, 32, 1), (768, 1600, 32, 1), (3, 768, 32, 1), (128, 768, 32, 6), (60, 80, 32, 20), (100, 70, 5, 1), (64, 64, 64, 2),
                                  (777, 130, 17, 1)], ids=lambda c: "x".join(map(str, c)))
 def test_rank_k_fp32_tn_gemm(gpu, cfg):
@@ -918,13 +943,15 @@ def test_bert_layer_with_dropout_backward_is_consistent(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(19, 300, 136, 72), (3, 200, 72, 1536), (3, 1576, 256, 384), (2, 200, 136, 264), (17, 192, 128, 128)],
-                         ids=["19x136x72", "3x72x1536", "3x256x384-T1576", "2x136x264-T200", "17x128x128"])
+@pytest.mark.parametrize("shape", [(19, 300, 136, 72), (3, 200, 72, 1536), (3, 1576, 256, 384), (2, 200, 136, 264), (17, 192, 128, 128),
+                                   (9, 32, 768, 768), (3, 5, 130, 77)],
+                         ids=["19x136x72", "3x72x1536", "3x256x384-T1576", "2x136x264-T200", "17x128x128", "9x768x768-T32", "3x130x77-T5"])
 def test_grouped_weight_gradient_gemm(gpu, dtype, shape):
     """d2r_gemm_tn_grouped: same-shape dW = dY^T X problems (19: two launches, 16 + 3; 24 tile columns: the launch order
     without the whole-problem-per-XCD remap) with bias-gradient side product and accumulation into pre-filled sinks,
     against torch.  Outputs >= 128 x 128 in bf16 run on the 128x128 LDS-DMA weight-gradient kernel: ragged output edges
-    (136 x 264), token counts that are not a multiple of the 64-row K tile (1576 = 8 x 197, 200), 17 problems (16 + 1)."""
+    (136 x 264), token counts that are not a multiple of the 64-row K tile (1576 = 8 x 197, 200), 17 problems (16 + 1); at most 64
+    token rows (one row per sample: the pooled-vector linears) run on the rank-K kernel."""
     from d2r_amd import _lib
     from d2r_amd.functional import _parr, _stream
     n, T, N, K = shape
