@@ -468,6 +468,29 @@ def test_skinny_fp32_gemm(gpu, cfg):
 
 
 @pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
+def test_matrix_vector_16bit_gemm(gpu, lowp):
+    """N = 1 products of 16-bit operands (the SAF scores a = S w over B*(Lq+1) rows) take the wave-per-row kernel: fp32 and 16-bit
+    output, bias, tanh, a row stride larger than K, against fp64 on the rounded operands."""
+    from d2r_amd import functional as F
+    from d2r_amd._lib import BF16, F16, F32, GEMM_NT, ACT_TANH
+    code = BF16 if lowp == torch.bfloat16 else F16
+    eps = 2.0 ** -8 if lowp == torch.bfloat16 else 2.0 ** -11
+    for M, K, lda in ((4128, 768, 768), (70, 768, 1536), (6336, 96, 96)):
+        a = rnd(M, lda, seed=1).to(lowp).to(gpu)
+        b = rnd(1, K, seed=2, scale=0.1).to(lowp).to(gpu)
+        bias = rnd(1, seed=3).to(gpu)
+        prod = a[:, :K].double() @ b.double().t()
+        c = torch.empty(M, 1, device=gpu)
+        F.gemm(GEMM_NT, M, 1, K, a.data_ptr(), lda, b.data_ptr(), K, c.data_ptr(), 1, dtype=code, c_dtype=F32, bias=bias.data_ptr())
+        want = prod + bias.double()
+        assert float((c.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6, (M, K)
+        c16 = torch.empty(M, 1, dtype=lowp, device=gpu)
+        F.gemm(GEMM_NT, M, 1, K, a.data_ptr(), lda, b.data_ptr(), K, c16.data_ptr(), 1, dtype=code, c_dtype=code, alpha=0.5, act=ACT_TANH)
+        want = torch.tanh(0.5 * prod)
+        assert float((c16.double() - want).abs().max()) <= eps + 1e-6, (M, K)
+
+
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
 def test_saf_rank_one_backward_products(gpu, lowp):
     """d2r_saf_dweights / d2r_saf_dscores (the rank-one products around the SAF gate in the backward pass of wsum[b] = w[b] @ S[b])
     against fp64 on the rounded operands: dw[b,i] = <dwsum[b], S[b,i]>, dS[b,i] = w[b,i] dwsum[b] + da[b,i] w_saf."""
