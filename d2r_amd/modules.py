@@ -554,6 +554,7 @@ class Reversed_InteractionModule(_InteractionBase):
 # ------------------------------------------------------------------------------------------------------
 # encoders
 # ------------------------------------------------------------------------------------------------------
+EARLY_SELF_LAYERS = os.environ.get("D2R_EARLY_SELF", "1") != "0"
 INTERLEAVE_ENCODERS = os.environ.get("D2R_INTERLEAVE", "1") != "0"  # issue the two encoders layer by layer in alternation
 COMPOSITE_LAYERS = os.environ.get("D2R_COMPOSITE", "1") != "0"  # whole encoder layers as one C call (bf16 only)
 COMPOSITE_HEAD = os.environ.get("D2R_COMPOSITE_HEAD", "1") != "0"  # Block fusion + fc + cross entropy + loss as one C call each way (fp32)
@@ -938,6 +939,27 @@ class UnimoModel(D2RModule):
                 v_enc = self.encoder.run_vision(v_enc, gate)
             with on_t():
                 t_enc = self.encoder.run_text(t_enc, key_mask, gate)
+        # The extra self layers and cls poolers read their OWN encoder's output only: issued in front of the barrier, the shorter
+        # branch (text: 128 tokens against 197) runs them while the other encoder is still busy (EARLY_SELF_LAYERS = False: behind it).
+        def self_layers():
+            with on_t():
+                if gate is not None:
+                    gate("all", 0)
+                t_out = t_enc
+                for layer in self.self_text:
+                    t_out = layer(t_out, key_mask)
+                tc = self.text_cls_pool(t_out, fp32=True)
+            with on_v():
+                if gate is not None:
+                    gate("all", 0)
+                v_out = v_enc
+                for layer in self.self_vision:
+                    v_out = layer(v_out)
+                vc = self.vision_cls_pool(v_out, fp32=True)
+            return tc, vc
+
+        if EARLY_SELF_LAYERS:
+            t_cls, v_cls = self_layers()
         if two:
             # barrier through the launching stream, then fork again (a direct sT<->sV cross wait is legal HIP but
             # crashes hipStreamEndCapture on ROCm 7.2 when the step is being captured into a hipGraph)
@@ -949,20 +971,8 @@ class UnimoModel(D2RModule):
         if two:
             sT.wait_stream(main)
             sV.wait_stream(main)
-        with on_t():
-            if gate is not None:
-                gate("all", 0)
-            t_out = t_enc
-            for layer in self.self_text:
-                t_out = layer(t_out, key_mask)
-            t_cls = self.text_cls_pool(t_out, fp32=True)
-        with on_v():
-            if gate is not None:
-                gate("all", 0)
-            v_out = v_enc
-            for layer in self.self_vision:
-                v_out = layer(v_out)
-            v_cls = self.vision_cls_pool(v_out, fp32=True)
+        if not EARLY_SELF_LAYERS:
+            t_cls, v_cls = self_layers()
         with on_t():
             (emb_t,), sim_paths = self.itr_module(t_enc, v_enc)
             js1 = F.js_div(sim_paths, F.matmul_nt(t_cls, t_cls))
