@@ -34,7 +34,22 @@ def mark(tag):
 
 
 _fw, _bw = F._StreamJoin.forward, F._StreamJoin.backward
-F._StreamJoin.forward = staticmethod(lambda ctx, a, b: (mark("encoders forward"), _fw(ctx, a, b))[1])
+branch_marks = []
+
+
+def _join_fw(ctx, a, b):
+    # when does each branch stream finish its encoder (+ extra self layer)?  (the launching stream waits for both)
+    st = model.model._streams
+    if st is not None:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in st]
+        for e, s_ in zip(ev, st):
+            e.record(s_)
+        branch_marks.append(ev)
+    mark("encoders forward")
+    return _fw(ctx, a, b)
+
+
+F._StreamJoin.forward = staticmethod(_join_fw)
 F._StreamJoin.backward = staticmethod(lambda ctx, ga, gb: (mark("modules backward"), _bw(ctx, ga, gb))[1])
 _lin = F.lincomb
 def lincomb(*a, **k):
@@ -46,8 +61,10 @@ _hb = F._Head.backward
 F._Head.backward = staticmethod(lambda ctx, *g: (_hb(ctx, *g), mark("head forward + backward"))[0])
 
 rows = []
+branch_rows = []
 for it in range(10):
     marks.clear()
+    branch_marks.clear()
     mark("start")
     loss, _ = model(*batch)
     opt.scale_loss(loss).backward()
@@ -57,9 +74,15 @@ for it in range(10):
     opt.zero_grad()
     mark("optimiser + zero")
     torch.cuda.synchronize()
+    if it >= 4 and branch_marks:
+        branch_rows.append([marks[0][1].elapsed_time(e) for e in branch_marks[0]])
     if it >= 4:
         rows.append([(marks[i][0], marks[i - 1][1].elapsed_time(marks[i][1])) for i in range(1, len(marks))])
 for i, (tag, _) in enumerate(rows[0]):
     v = sorted(r[i][1] for r in rows)
     print(f"{tag:45s} median {v[len(v) // 2]:6.2f} ms  (min {v[0]:.2f}, max {v[-1]:.2f})")
 print(f"{'step':45s} median {sorted(sum(x[1] for x in r) for r in rows)[len(rows) // 2]:6.2f} ms")
+if branch_rows:
+    med = lambda v: sorted(v)[len(v) // 2]
+    print(f"branch streams reach the barrier behind the encoders after {med([r[0] for r in branch_rows]):.2f} ms (text) / "
+          f"{med([r[1] for r in branch_rows]):.2f} ms (vision) of the step")
