@@ -217,7 +217,7 @@ def main():
     def step():
         dp.begin_step()
         loss, logits = model(*batch)
-        opt.scale_loss(loss).backward()
+        opt.backward(loss)
         dp.reduce_gradients()
         opt.step()
         dp.gather_parameters()
@@ -297,7 +297,7 @@ def main():
     def fwd_bwd_only():
         dp.begin_step()
         loss, _ = model(*batch)
-        opt.scale_loss(loss).backward()
+        opt.backward(loss)
         opt.zero_grad()
 
     n2 = max(3, args.steps // 2)
@@ -335,7 +335,7 @@ def main():
 
             def small_step():
                 loss, _ = model(*small)
-                opt.scale_loss(loss).backward()
+                opt.backward(loss)
                 opt.step()
                 opt.zero_grad()
 
@@ -360,7 +360,7 @@ def main():
         # alone on the GPU — the durations rocprofv3 --kernel-trace reports (it serialises dispatches too).
         def local_step():  # the step without its collective: rank 0 is alone here
             loss, _ = model(*batch)
-            opt.scale_loss(loss).backward()
+            opt.backward(loss)
             opt.step()
             sched.step()
             opt.zero_grad()

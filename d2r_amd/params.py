@@ -242,6 +242,20 @@ class FusedAdamW:
     def scale_loss(self, loss):
         return loss if self._scaler is None else loss * self.loss_scale
 
+    def backward(self, loss):
+        """``scale_loss(loss).backward()`` without the three tiny launches it costs on the serial stretch between forward and backward
+        (the multiply, autograd's ones_like root gradient, the multiply's backward): the loss scale IS the root gradient, kept in a
+        device scalar that is rewritten only when the scale changes.  Same gradients bit for bit (1.0 * scale == scale)."""
+        if self._scaler is None or loss.dim() != 0 or not loss.is_cuda:
+            self.scale_loss(loss).backward()
+            return
+        sc = self._scaler
+        g = sc.get("root_grad")
+        if g is None or sc.get("root_grad_value") != self.loss_scale or g.dtype != loss.dtype or g.device != loss.device:
+            g = sc["root_grad"] = torch.full((), self.loss_scale, dtype=loss.dtype, device=loss.device)
+            sc["root_grad_value"] = self.loss_scale
+        loss.backward(gradient=g)
+
     def _scaler_before_step(self):
         """Consumes the previous step's overflow flag (its copy has long landed), then arms the check for this step."""
         sc = self._scaler

@@ -143,7 +143,7 @@ class MSDTrainer:
                 self.dp.begin_step()
                 (loss, logits), labels = self._step(batch, mode="train")
                 F._lib.call("d2r_axpby", F.F32, 1.0, loss.detach().data_ptr(), 1.0, run_loss.data_ptr(), 1, F._stream())
-                self.optimizer.scale_loss(loss).backward()
+                self.optimizer.backward(loss)
                 self.dp.reduce_gradients()
                 self.optimizer.step()
                 self.dp.gather_parameters()  # (sharded optimiser only: publish this rank's slice of the updated weights)

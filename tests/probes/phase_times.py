@@ -67,7 +67,7 @@ for it in range(10):
     branch_marks.clear()
     mark("start")
     loss, _ = model(*batch)
-    opt.scale_loss(loss).backward()
+    (opt.backward(loss) if os.environ.get("FUSED_ROOT", "1") != "0" else opt.scale_loss(loss).backward())
     F.wgrad_join()
     mark("encoders backward + weight-gradient flush")
     opt.step()

@@ -170,6 +170,21 @@ def test_fp16_loss_scaling_matches_fp32_steps_and_survives_an_overflow(gpu):
     torch.cuda.synchronize()
     assert opt._scaler["skipped"] == 1 and opt.loss_scale == 2048.0 and opt.step_count == count + 1, (opt._scaler, opt.loss_scale)
     assert not torch.equal(before[0], store.flat_w) and bool(torch.isfinite(store.flat_w).all())
+    # (iii) opt.backward(loss) - the loss scale as the root gradient - gives the gradients of scale_loss(loss).backward() bit for bit,
+    #       also after the scale has changed
+    for scale in (2048.0, 512.0):
+        opt.loss_scale = scale
+        grads = []
+        for fused in (False, True):
+            store.zero_grad()
+            loss, _ = model(*batch)
+            if fused:
+                opt.backward(loss)
+            else:
+                opt.scale_loss(loss).backward()
+            torch.cuda.synchronize()
+            grads.append(store.flat_g.clone())
+        assert bool(grads[0].abs().max() > 0) and torch.equal(grads[0], grads[1]), scale
 
 
 def test_cli_smoke(gpu, tmp_path):
