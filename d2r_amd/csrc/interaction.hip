@@ -516,8 +516,7 @@ int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
       TRY(d2r_colsum(D2R_F32, K.dhp, (int64_t)nc * hid, B, nc * hid, K.cs0, K.cws, K.cws_bytes, c.st));
       TRY(acc32(c, K.cs0, lp[D2R_RL_R0].gb, (int64_t)nc * hid));
       // dx[0] already holds the aggregation's gradient (and, in the final layer, every dx[j] the skip-path gradient)
-      for (int j = 0; j < nc; ++j)
-        TRY(d2r_meanpool_bwd(c.dt, K.dpooled + (size_t)j * B * E, B, d.Lq, E, dx[j], (j == 0 || final) ? 1 : 0, c.st));
+      TRY(d2r_meanpool_bwd_multi(c.dt, K.dpooled, nc, B, d.Lq, E, dx, final ? 0xffu : 1u, c.st));  // (one launch for the nc inputs)
     }
   }
   void* ev_routers = nullptr;  // recorded HERE (not behind IMRC, which follows on the same stream); stream 2 waits for it in front of its tails

@@ -116,6 +116,55 @@ extern "C" int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, i
   return d2r_check_launch("d2r_meanpool_bwd");
 }
 
+// The same broadcast for up to 8 pooled gradients [n, B, D] into n different [B, L, D] tensors in ONE launch (blockIdx.y = source;
+// bit j of acc_mask: accumulate into dX[j]): the routers of a middle / final routing layer pool six different inputs.
+template <typename T>
+__global__ __launch_bounds__(256) void meanpool_bwd_multi_kernel(const float* __restrict__ dpooled, int B, int L, int D, MPtrs8 dX,
+                                                                 unsigned acc_mask) {
+  constexpr int VEC = PackOf<T>::N;
+  const int npk = D / VEC, src = blockIdx.y;
+  const int64_t total = (int64_t)B * L * npk;
+  const float invL = 1.f / (float)L;
+  const float* gp = dpooled + (int64_t)src * B * D;
+  T* out = reinterpret_cast<T*>(dX.p[src]);
+  const bool accumulate = (acc_mask >> src) & 1u;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int pk = (int)(idx % npk);
+    const int64_t bl = idx / npk;
+    const int b = (int)(bl / L);
+    const float* g = gp + (int64_t)b * D + pk * VEC;
+    T* dst = out + bl * D + pk * VEC;
+    Pack<T, VEC> o;
+    if (accumulate) {
+      Pack<T, VEC> old = ld_pack<T, VEC>(dst);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(to_f<T>(old.v[j]) + g[j] * invL);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(g[j] * invL);
+    }
+    st_pack<T, VEC>(dst, o);
+  }
+}
+
+extern "C" int d2r_meanpool_bwd_multi(int dtype, const float* dpooled, int n, int B, int L, int D, void* const* dX, unsigned acc_mask,
+                                      void* stream) {
+  D2R_REQUIRE(dpooled && dX && n >= 1 && n <= 8, "d2r_meanpool_bwd_multi: bad argument");
+  D2R_REQUIRE(d2r_is16(dtype) && B >= 1 && L >= 1 && D % 8 == 0, "d2r_meanpool_bwd_multi: 16-bit dtypes, D a multiple of 8");
+  MPtrs8 t = {};
+  for (int j = 0; j < n; ++j) {
+    D2R_REQUIRE(dX[j] && d2r_aligned16(dX[j]), "d2r_meanpool_bwd_multi: null or unaligned pointer %d", j);
+    for (int k = 0; k < j; ++k) D2R_REQUIRE(dX[j] != dX[k], "d2r_meanpool_bwd_multi: outputs %d and %d alias", k, j);
+    t.p[j] = dX[j];
+  }
+  int blocks = d2r_cdiv((int64_t)B * L * (D / 8), 256);
+  if (blocks > 1024) blocks = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == D2R_BF16) hipLaunchKernelGGL((meanpool_bwd_multi_kernel<bf16_t>), dim3(blocks, n), dim3(256), 0, st, dpooled, B, L, D, t, acc_mask);
+  else hipLaunchKernelGGL((meanpool_bwd_multi_kernel<f16_t>), dim3(blocks, n), dim3(256), 0, st, dpooled, B, L, D, t, acc_mask);
+  return d2r_check_launch("d2r_meanpool_bwd_multi");
+}
+
 // =====================================================================================================
 // K8 forward.  gates: fp32 [B, nc, P] (sample-major: the layout the routers' grouped GEMM writes).  Cells 1 (GLAC) and 5 (GESC) are [B,D] broadcasts.
 // nc = number of cells of the layer: the first nc of [RIC, GLAC, IMRC, CMRC, CRCMC, GESC] (6 in the reference, which

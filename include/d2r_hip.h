@@ -200,6 +200,9 @@ int d2r_meanpool_fwd(int dtype, const void* const* h_srcs, int nsrc, int B, int 
                      void* stream);
 /* dX[b,l,:] (+)= dpooled[b,:]/L ; accumulate!=0 adds into dX */
 int d2r_meanpool_bwd(int dtype, const float* dpooled, int B, int L, int D, void* dX, int accumulate, void* stream);
+/* n <= 8 pooled gradients dpooled[n,B,D] broadcast into n distinct [B,L,D] tensors in one launch (16-bit dtypes); bit j of acc_mask:
+ * accumulate into dX[j] instead of overwriting it. */
+int d2r_meanpool_bwd_multi(int dtype, const float* dpooled, int n, int B, int L, int D, void* const* dX, unsigned acc_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8  route_aggregate — path normalisation, threshold gate and aggregation of the cell outputs of one routing layer.

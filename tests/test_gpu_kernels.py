@@ -468,6 +468,27 @@ def test_skinny_fp32_gemm(gpu, cfg):
 
 
 @pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
+def test_meanpool_backward_multi_matches_single_launches(gpu, lowp):
+    """d2r_meanpool_bwd_multi (the pooled gradients of the six routers of a layer broadcast into six tensors in one launch, some
+    accumulated, some overwritten) against one d2r_meanpool_bwd launch per tensor: bit-identical."""
+    from d2r_amd import _lib
+    from d2r_amd.functional import _parr, _stream
+    code = _lib.BF16 if lowp == torch.bfloat16 else _lib.F16
+    n, B, L, D = 6, 5, 37, 768
+    dp = rnd(n, B, D, seed=1).to(gpu)
+    base = [rnd(B, L, D, seed=10 + j).to(lowp).to(gpu) for j in range(n)]
+    for mask in (1, 0x3f, 0b101010):
+        one = [t.clone() for t in base]
+        for j in range(n):
+            _lib.call("d2r_meanpool_bwd", code, dp[j].data_ptr(), B, L, D, one[j].data_ptr(), (mask >> j) & 1, _stream())
+        multi = [t.clone() for t in base]
+        _lib.call("d2r_meanpool_bwd_multi", code, dp.data_ptr(), n, B, L, D, _parr(multi), mask, _stream())
+        torch.cuda.synchronize()
+        for j in range(n):
+            assert torch.equal(one[j], multi[j]), (mask, j)
+
+
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
 def test_matrix_vector_16bit_gemm(gpu, lowp):
     """N = 1 products of 16-bit operands (the SAF scores a = S w over B*(Lq+1) rows) take the wave-per-row kernel: fp32 and 16-bit
     output, bias, tanh, a row stride larger than K, against fp64 on the rounded operands."""
