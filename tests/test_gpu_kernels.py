@@ -436,7 +436,8 @@ def test_adamw_matches_torch(gpu):
 
 @pytest.mark.parametrize("cfg", [("NT", 32, 768, 768, 1), ("NT", 2, 768, 768, 1), ("NT", 17, 100, 128, 6), ("NT", 32, 1600, 768, 1), ("NT", 1, 1, 768, 1),
                                  ("NT", 32, 1200, 80, 20), ("NN", 32, 80, 1200, 20), ("NT", 5, 64, 1200, 2),
-                                 ("NN", 32, 768, 768, 1), ("NN", 3, 768, 128, 6), ("NN", 32, 50, 1600, 1)], ids=lambda c: "-".join(map(str, c)))
+                                 ("NN", 32, 768, 768, 1), ("NN", 3, 768, 128, 6), ("NN", 32, 50, 1600, 1), ("NN", 32, 768, 4608, 1), ("NN", 17, 64, 80, 3),
+                                 ("NN", 32, 1600, 768, 1)], ids=lambda c: "-".join(map(str, c)))
 def test_skinny_fp32_gemm(gpu, cfg):
     """The fp32 kernel for products with at most 32 rows (router MLPs, poolers, Block head and chunk products; K a multiple of 16): plain, batched
     with per-batch bias rows, with activation + saved pre-activation, residual and accumulation, against fp64."""
