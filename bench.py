@@ -428,7 +428,8 @@ def main():
         summ = {k: v for k, v in summ.items() if not k.startswith("gemm_")}
         per_family = {}
         VARIANT = {0: "tiles", 1: "ldsdma128x64", 2: "ldsdma128x128w4", 3: "ldsdma128x128w8", 4: "ldsdma128x192w8", 11: "ldsdma128x64p", 12: "ldsdma128x128w4p",
-                   13: "ldsdma128x128w8p", 20: "ldsdma128x128", 21: "tiles64x64", 22: "batched16", 30: "skinny", 31: "skinny"}
+                   13: "ldsdma128x128w8p", 20: "ldsdma128x128", 21: "tiles64x64", 22: "batched16", 30: "skinny", 31: "skinny",
+                   8: "ldsdma256x256", 28: "ldsdma256x256"}
         ATT = {10001: "xattn_core_fwd", 10002: "xattn_core_bwd"}  # recorded by d2r_xattn_{fwd,bwd}_multi in the step's real launch shape
         att = {}
         for i in range(n_rec):

@@ -91,6 +91,8 @@ SIGNATURES = {
     "d2r_last_error": (C.c_char_p, []),
     "d2r_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "d2r_gemm_tuning": (None, [i32, i32, i32]),
+    "d2r_gemm_tn_grouped_v": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
+                                    C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), f32, vp]),
     "d2r_gemm_tn_grouped": (i32, [i32, i32, i32, i32, i64, i64, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                   C.POINTER(vp), i32, f32, vp]),
     "d2r_softmax_fwd": (i32, [i32, i32, vp, vp, i64, i64, i32, f32, vp, i64, vp]),

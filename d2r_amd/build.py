@@ -28,6 +28,8 @@ if os.environ.get("D2R_GEMM_PROBES", "0") != "0":  # measurement build: cycle st
 if os.environ.get("D2R_X3_PROBES", "0") != "0":  # measurement build of the cross-attention forward kernel (tests/probes/xattn3_probe.py stamps)
     EXTRA_FLAGS["xattn3.hip"] = ["-DD2R_X3_PROBES=1"]
     EXTRA_FLAGS["xattn2.hip"] = ["-DD2R_X3_PROBES=1"]
+if os.environ.get("D2R_G8_STAMPS", "0") != "0":  # measurement build of the 256-wide GEMM (tests/probes/gemm8_probe.py stamps)
+    EXTRA_FLAGS["gemm8.hip"] = ["-DD2R_G8_STAMPS=1"]
 if os.environ.get("D2R_GEMM_ILV", "1") == "0":  # A/B build: DMA instructions of the pipelined K-loop issued in one run
     EXTRA_FLAGS["gemm_glds.hip"] = EXTRA_FLAGS.get("gemm_glds.hip", []) + ["-DD2R_GEMM_ILV=0"]
 

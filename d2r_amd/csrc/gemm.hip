@@ -400,6 +400,14 @@ static int g_vepi = env_int("D2R_GEMM_VEPI", 1);
 static int g_tile = env_int("D2R_GEMM_TILE", -1);
 static int g_xcd = env_int("D2R_GEMM_XCD", 1);
 static int g_wgrad_glds = env_int("D2R_WGRAD_GLDS", 1);
+// 256-wide tiles for forward / dX products (d2r_gemm_tuning tile 110 / 111): OFF by default.  Measured on the workload's shapes
+// (tests/probes/gemm8_probe.py, profiles/gemm8_probe_r04.log): the deep-pipelined loop reaches 1360-1480 TFLOP/s at K >= 4096, but the
+// K = 768 / 3072 products of the path have 48-300 such tiles (one partial round of workgroups) and twelve K-tiles of loop between a
+// 2.5 k-cycle prologue and the store burst of the whole grid: 530-860 TFLOP/s against 580-940 on the 128-wide kernels at 2-3
+// workgroups per CU.  The weight gradients (64-98 K-tiles, a thousand tiles per launch) are where the wide tiles pay.
+static int g_gemm8 = 0;
+static int g_gemm8_wgrad = 1;  // ... for the grouped weight gradients (tile 102 / 103)
+static int g_gemm8_min = 150;  // fewest 256 x 256 tiles of a forward / dX product that takes them (tile 1000 + n sets it)
 
 // ---- optional per-launch timing of the GEMM entry points (bench.py's roofline leg) -----------------------------------------
 // The whole-layer / whole-module C calls (encoder_layer.hip, interaction.hip) launch their GEMMs from inside the library, where
@@ -466,6 +474,9 @@ extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
   g_xcd = (nbuf >> 8) & 1 ? 0 : 1;  // bit 8 of the first argument disables the XCD-aware tile order (A/B runs)
   g_vepi = vepi;
   if (tile == 100 || tile == 101) g_wgrad_glds = tile - 100;  // A/B switch of the grouped weight-gradient kernel (0: 64x64 generic)
+  else if (tile == 102 || tile == 103) g_gemm8_wgrad = tile - 102;  // 256 x 256 deep-pipelined grouped weight gradients off / on
+  else if (tile == 110 || tile == 111) g_gemm8 = tile - 110;        // 256 x 256 forward / dX products off / on
+  else if (tile >= 1000) g_gemm8_min = tile - 1000;
   else g_tile = tile;
 }
 
@@ -478,6 +489,18 @@ static void launch_tile(const GemmArgs& a, int gz, hipStream_t st) {
 }
 
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st);  // gemm_glds.hip
+int d2r_gemm8_fwd_ok(const GemmArgs& a, int layout, int batch);                           // gemm8.hip
+int d2r_gemm8_fwd_launch(const GemmArgs* probs, int n, int layout, hipStream_t st);
+int d2r_gemm8_wgrad_ok(int dtype, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const void* A, const void* B, const void* C);
+int d2r_gemm8_wgrad_launch(int dtype, int count, const int* M, const int* N, const int* K, const int64_t* lda, const int64_t* ldb, const int64_t* ldc,
+                           const void* const* A, const void* const* B, float* const* C, float* const* dbias, float beta, hipStream_t st);
+// One workgroup per CU: a launch of t tiles runs in ceil(t / 256) rounds.  The wide tiles pay when the last round is well filled.
+static bool gemm8_pays(const GemmArgs& a) {
+  const int64_t t = (int64_t)d2r_cdiv(a.M, 256) * d2r_cdiv(a.N, 256);
+  if (t < g_gemm8_min) return false;
+  const int64_t rounds = (t + 255) / 256;
+  return t * 100 >= rounds * 256 * 70;  // at least 70 % of the slots of its rounds
+}
 static int g_glds = env_int("D2R_GEMM_GLDS", 1);
 static int g_wide = env_int("D2R_GEMM_WIDE", 1);
 
@@ -822,6 +845,14 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN)
       bn = ((g_wide && a.N >= 128) || a.N >= 1536 || (LAYOUT == D2R_GEMM_NT && a.K >= 2048 && a.N >= 128)) ? 129 : 64;
     if (a.dbias) bn = 0;
+    if constexpr (LAYOUT != D2R_GEMM_TN) {
+      // 256 x 256 tiles on the deep-pipelined kernel (gemm8.hip) when the product fills the chip with them (tile code 11 forces them
+      // wherever they are eligible; d2r_gemm_tuning 110 / 111 switches the automatic choice off / on: A/B runs)
+      if ((g_tile == 11 || (g_tile < 0 && g_gemm8 && gemm8_pays(a))) && d2r_gemm8_fwd_ok(a, LAYOUT, batch)) {
+        d2r_gemm_variant_tl = 8;
+        return d2r_gemm8_fwd_launch(&a, 1, LAYOUT, st);
+      }
+    }
     if (bn) {
       GemmArgs b = a;
       b.ws = nullptr; b.splits = 1; b.tiles_per_split = 0;
@@ -1008,9 +1039,8 @@ static int launch_grouped_tn(const GemmArgs& base, const void* const* A, const v
   return D2R_OK;
 }
 
-extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                                   const void* const* h_A, const void* const* h_B, float* const* h_C,
-                                   float* const* h_dbias, int count, float beta, void* stream) {
+static int tn_grouped_same(int dtype, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const void* const* h_A, const void* const* h_B,
+                           float* const* h_C, float* const* h_dbias, int count, float beta, void* stream, bool allow8) {
   D2R_REQUIRE(h_A && h_B && h_C && count >= 0, "d2r_gemm_tn_grouped: null pointer array");
   D2R_REQUIRE(dtype == D2R_F32 || d2r_is16(dtype), "d2r_gemm_tn_grouped: bad dtype %d", dtype);
   D2R_REQUIRE(M >= 1 && N >= 1 && K >= 0 && lda >= M && ldb >= N && ldc >= N, "d2r_gemm_tn_grouped: bad shape");
@@ -1035,9 +1065,91 @@ extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, 
   // algorithmic bytes: both operands once, the fp32 sink read and written
   GemmTimerScope timed(st, dtype * 8 + D2R_GEMM_TN * 2 + 1, 2.0 * count * M * N * (double)K,
                        (double)count * (((double)K * M + (double)K * N) * es + 2.0 * M * N * 4.0));
+  if (allow8 && g_gemm8_wgrad && d2r_is16(dtype) && (int64_t)count * d2r_cdiv(M, 256) * d2r_cdiv(N, 256) >= 96) {
+    bool ok = true;
+    for (int i = 0; i < count && ok; ++i) ok = d2r_gemm8_wgrad_ok(dtype, M, N, K, lda, ldb, ldc, h_A[i], h_B[i], h_C[i]) != 0;
+    if (ok) {
+      std::vector<int> Ms(count, M), Ns(count, N), Ks(count, K);
+      std::vector<int64_t> la(count, lda), lb(count, ldb), lc(count, ldc);
+      d2r_gemm_variant_tl = 28;
+      return d2r_gemm8_wgrad_launch(dtype, count, Ms.data(), Ns.data(), Ks.data(), la.data(), lb.data(), lc.data(), h_A, h_B, h_C, h_dbias, beta, st);
+    }
+  }
   if (dtype == D2R_BF16) return launch_grouped_tn<bf16_t>(a, h_A, h_B, h_C, h_dbias, count, st);
   if (dtype == D2R_F16) return launch_grouped_tn<f16_t>(a, h_A, h_B, h_C, h_dbias, count, st);
   return launch_grouped_tn<float>(a, h_A, h_B, h_C, h_dbias, count, st);
+}
+
+extern "C" int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const void* const* h_A,
+                                   const void* const* h_B, float* const* h_C, float* const* h_dbias, int count, float beta, void* stream) {
+  return tn_grouped_same(dtype, M, N, K, lda, ldb, ldc, h_A, h_B, h_C, h_dbias, count, beta, stream, true);
+}
+
+
+// Weight gradients of DIFFERENT shapes in one call: problem i is C_i[M_i,N_i] (fp32, ldc_i) = beta * C_i + A_i^T B_i (+ dbias_i).  The
+// problems that fit the 256-wide deep-pipelined kernel (gemm8.hip) leave together, as launches of up to 40 problems whose tiles fill
+// the chip whatever the single shapes are (a 768 x 768 gradient alone has 9 such tiles); the others go through d2r_gemm_tn_grouped
+// shape class by shape class.  No two problems of a call may share an output.
+extern "C" int d2r_gemm_tn_grouped_v(int dtype, int count, const int* M, const int* N, const int* K, const int64_t* lda, const int64_t* ldb,
+                                     const int64_t* ldc, const void* const* h_A, const void* const* h_B, float* const* h_C,
+                                     float* const* h_dbias, float beta, void* stream) {
+  D2R_REQUIRE(count >= 0 && (count == 0 || (M && N && K && lda && ldb && ldc && h_A && h_B && h_C)), "d2r_gemm_tn_grouped_v: null array");
+  D2R_REQUIRE(dtype == D2R_F32 || d2r_is16(dtype), "d2r_gemm_tn_grouped_v: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  std::vector<int> wide, rest;
+  for (int i = 0; i < count; ++i) {
+    D2R_REQUIRE(h_A[i] && h_B[i] && h_C[i] && (!h_dbias || h_dbias[i]), "d2r_gemm_tn_grouped_v: null operand in problem %d", i);
+    D2R_REQUIRE(M[i] >= 1 && N[i] >= 1 && K[i] >= 0 && lda[i] >= M[i] && ldb[i] >= N[i] && ldc[i] >= N[i], "d2r_gemm_tn_grouped_v: bad shape in problem %d", i);
+    for (int j = 0; j < i; ++j) {
+      D2R_REQUIRE(h_C[i] != h_C[j], "d2r_gemm_tn_grouped_v: problems %d and %d write the same C", j, i);
+      D2R_REQUIRE(!h_dbias || h_dbias[i] != h_dbias[j], "d2r_gemm_tn_grouped_v: problems %d and %d write the same dbias", j, i);
+    }
+    const bool w = g_gemm8_wgrad && d2r_gemm8_wgrad_ok(dtype, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], h_A[i], h_B[i], h_C[i]);
+    (w ? wide : rest).push_back(i);
+  }
+  int64_t wtiles = 0;
+  for (int i : wide) wtiles += (int64_t)d2r_cdiv(M[i], 256) * d2r_cdiv(N[i], 256);
+  if (wtiles < 96) {  // too few wide tiles to occupy the chip: the 128-wide grouped kernel, class by class
+    rest.insert(rest.end(), wide.begin(), wide.end());
+    wide.clear();
+  }
+  if (!wide.empty()) {
+    const int n = (int)wide.size();
+    std::vector<int> Ms(n), Ns(n), Ks(n);
+    std::vector<int64_t> la(n), lb(n), lc(n);
+    std::vector<const void*> As(n), Bs(n);
+    std::vector<float*> Cs(n), Ds(n);
+    double flops = 0, bytes = 0;
+    for (int k = 0; k < n; ++k) {
+      const int i = wide[k];
+      Ms[k] = M[i], Ns[k] = N[i], Ks[k] = K[i], la[k] = lda[i], lb[k] = ldb[i], lc[k] = ldc[i], As[k] = h_A[i], Bs[k] = h_B[i], Cs[k] = h_C[i];
+      Ds[k] = h_dbias ? h_dbias[i] : nullptr;
+      flops += 2.0 * M[i] * N[i] * (double)K[i];
+      bytes += ((double)K[i] * M[i] + (double)K[i] * N[i]) * 2.0 + (beta != 0.f ? 2.0 : 1.0) * M[i] * N[i] * 4.0;
+    }
+    GemmTimerScope timed(st, dtype * 8 + D2R_GEMM_TN * 2 + 1, flops, bytes);
+    d2r_gemm_variant_tl = 28;
+    if (int rc = d2r_gemm8_wgrad_launch(dtype, n, Ms.data(), Ns.data(), Ks.data(), la.data(), lb.data(), lc.data(), As.data(), Bs.data(), Cs.data(),
+                                        h_dbias ? Ds.data() : nullptr, beta, st))
+      return rc;
+  }
+  std::vector<char> done(count, 0);
+  for (size_t a = 0; a < rest.size(); ++a) {
+    const int i = rest[a];
+    if (done[i]) continue;
+    std::vector<const void*> As, Bs;
+    std::vector<float*> Cs, Ds;
+    for (size_t b = a; b < rest.size(); ++b) {
+      const int j = rest[b];
+      if (done[j] || M[j] != M[i] || N[j] != N[i] || K[j] != K[i] || lda[j] != lda[i] || ldb[j] != ldb[i] || ldc[j] != ldc[i]) continue;
+      done[j] = 1;
+      As.push_back(h_A[j]), Bs.push_back(h_B[j]), Cs.push_back(h_C[j]), Ds.push_back(h_dbias ? h_dbias[j] : nullptr);
+    }
+    if (int rc = tn_grouped_same(dtype, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], As.data(), Bs.data(), Cs.data(), h_dbias ? Ds.data() : nullptr,
+                                 (int)As.size(), beta, stream, false))  // (decided above: these did not qualify for the wide tiles)
+      return rc;
+  }
+  return D2R_OK;
 }
 
 

@@ -182,36 +182,29 @@ void defer(Jobs& jobs, int M, int Nf, int Kf, const void* dy, int64_t ldy, const
   jobs.push_back(WJob{M, Nf, Kf, ldy, ldx, dy, x, p.gw, p.gb});
 }
 
+// All queued products of the call in ONE d2r_gemm_tn_grouped_v (different shapes share launches on the 256-wide kernel); a sink that
+// was queued twice (one parameter used at two sites) waits for the next round: the problems of a call run in parallel.
 int flush_jobs(const Ctx& c, Jobs& jobs) {
-  std::vector<char> done(jobs.size(), 0);
-  std::vector<const void*> A, Bp;
-  std::vector<float*> Cp, Dp;
-  for (size_t i = 0; i < jobs.size(); ++i) {
-    if (done[i]) continue;
-    const WJob& a = jobs[i];
-    A.clear(), Bp.clear(), Cp.clear(), Dp.clear();
-    for (size_t j = i; j < jobs.size(); ++j) {
-      const WJob& b = jobs[j];
-      if (done[j] || b.M != a.M || b.Nf != a.Nf || b.Kf != a.Kf || b.ldy != a.ldy || b.ldx != a.ldx) continue;
-      bool dup = false;  // one sink twice in a launch would race: the second product waits for the next round
-      for (size_t k = 0; k < Cp.size(); ++k) dup |= (Cp[k] == b.gw);
-      if (dup) continue;
-      done[j] = 1;
+  while (!jobs.empty()) {
+    std::vector<int> M, N, K;
+    std::vector<int64_t> lda, ldb, ldc;
+    std::vector<const void*> A, Bp;
+    std::vector<float*> Cp, Dp;
+    Jobs rest;
+    for (const WJob& b : jobs) {
+      bool dup = false;
+      for (size_t k = 0; k < Cp.size(); ++k) dup |= (Cp[k] == b.gw) || (b.gb && Dp[k] == b.gb);
+      if (dup) {
+        rest.push_back(b);
+        continue;
+      }
+      M.push_back(b.Nf), N.push_back(b.Kf), K.push_back(b.M), lda.push_back(b.ldy), ldb.push_back(b.ldx), ldc.push_back(b.Kf);
       A.push_back(b.dy), Bp.push_back(b.x), Cp.push_back(b.gw), Dp.push_back(b.gb);
     }
-    TRY(d2r_gemm_tn_grouped(c.dt, a.Nf, a.Kf, a.M, a.ldy, a.ldx, a.Kf, A.data(), Bp.data(), Cp.data(), Dp.data(), (int)A.size(), 1.f, c.st));
-  }
-  // leftovers (duplicates of a sink within one shape class): one more pass each
-  bool left = false;
-  for (size_t i = 0; i < jobs.size(); ++i) left |= !done[i];
-  if (left) {
-    Jobs rest;
-    for (size_t i = 0; i < jobs.size(); ++i)
-      if (!done[i]) rest.push_back(jobs[i]);
+    TRY(d2r_gemm_tn_grouped_v(c.dt, (int)A.size(), M.data(), N.data(), K.data(), lda.data(), ldb.data(), ldc.data(), A.data(), Bp.data(), Cp.data(),
+                              Dp.data(), 1.f, c.st));
     jobs.swap(rest);
-    return flush_jobs(c, jobs);
   }
-  jobs.clear();
   return D2R_OK;
 }
 

@@ -170,30 +170,72 @@ def _defer_ln_sum(rows, D, ws_ptr, g_sink, b_sink, params, keepalive, flush_at=N
 
 
 def _flush_wgrad_group(key, jobs):
-    if key[0] == "ln":
-        _, rows, D = key
-        _lib.call("d2r_layernorm_bwd_sum_grouped", _iparr([j[0] for j in jobs]), _iparr([j[1] for j in jobs]), _iparr([j[2] for j in jobs]),
-                  len(jobs), rows, D, 1, _stream(), meta=dict(group="d2r_layernorm_bwd_sum"))
-        for j in jobs:  # data-parallel bucket readiness (d2r_amd.dp)
+    _flush_wgrad_groups([(key, jobs)])
+
+
+def _flush_wgrad_groups(groups):
+    """Launches queued weight-gradient groups [(shape key, jobs)] of ONE stream: the LayerNorm sums per key, every GEMM job of
+    every shape in ONE d2r_gemm_tn_grouped_v call (the 256-wide deep-pipelined kernel takes different shapes in one launch: the
+    four weight gradients of seven encoder layers are 756 tiles instead of four launches of 63-252)."""
+    gemm_jobs = []
+    for key, jobs in groups:
+        if key[0] == "ln":
+            _, rows, D = key
+            _lib.call("d2r_layernorm_bwd_sum_grouped", _iparr([j[0] for j in jobs]), _iparr([j[1] for j in jobs]), _iparr([j[2] for j in jobs]),
+                      len(jobs), rows, D, 1, _stream(), meta=dict(group="d2r_layernorm_bwd_sum"))
+        else:
+            gemm_jobs.extend((key, j) for j in jobs)
+    # one dtype and one "has bias sink" flavour per call
+    flavours = {}
+    for key, j in gemm_jobs:
+        flavours.setdefault((key[0], key[5]), []).append((key, j))
+    for (dt, has_b), kj in flavours.items():
+        n = len(kj)
+        Ms, Ns, Ks = [k[1] for k, _ in kj], [k[2] for k, _ in kj], [k[3] for k, _ in kj]  # dW [N_out, K_in] over M tokens
+        lda, ldb, ldc = Ms, [k[4] for k, _ in kj], Ns
+        meta = None
+        if _lib._timer is not None:
+            es = 4 if dt == F32 else 2
+            meta = dict(group=f"gemm_{_DT_NAME[dt]}_TN_grouped", flops=sum(2.0 * a * b * c for a, b, c in zip(Ms, Ns, Ks)),
+                        bytes=float(sum((c * a + c * b) * es + 2 * a * b * 4 for a, b, c in zip(Ms, Ns, Ks))))
+        _lib.call("d2r_gemm_tn_grouped_v", dt, n, _iarr32(Ms), _iarr32(Ns), _iarr32(Ks), _iarr64(lda), _iarr64(ldb), _iarr64(ldc),
+                  _iparr([j[0] for _, j in kj]), _iparr([j[1] for _, j in kj]), _iparr([j[2] for _, j in kj]),
+                  _iparr([j[3] for _, j in kj]) if has_b else None, 1.0, _stream(), meta=meta)
+    for key, jobs in groups:  # data-parallel bucket readiness (d2r_amd.dp)
+        for j in jobs:
             for p in j[4]:
                 cb = getattr(p, "_d2r_ready_cb", None) if p is not None else None
                 if cb is not None:
                     cb(p)
-        return
-    dt, N, K, M, lda_x, has_b = key
-    n = len(jobs)
-    A, B, Cc = _iparr([j[0] for j in jobs]), _iparr([j[1] for j in jobs]), _iparr([j[2] for j in jobs])
-    D = _iparr([j[3] for j in jobs]) if has_b else None
-    meta = None
-    if _lib._timer is not None:
-        meta = dict(group=f"gemm_{_DT_NAME[dt]}_TN_grouped", flops=2.0 * n * M * N * K,
-                    bytes=float(n) * ((M * N + M * K) * (4 if dt == F32 else 2) + 2 * N * K * 4))
-    _lib.call("d2r_gemm_tn_grouped", dt, N, K, M, N, lda_x, K, A, B, Cc, D, n, 1.0, _stream(), meta=meta)
-    for j in jobs:  # data-parallel bucket readiness (d2r_amd.dp)
-        for p in j[4]:
-            cb = getattr(p, "_d2r_ready_cb", None) if p is not None else None
-            if cb is not None:
-                cb(p)
+
+
+def _iarr32(vals):
+    arr = (C.c_int * len(vals))()
+    for i, v in enumerate(vals):
+        arr[i] = v
+    return arr
+
+
+def _iarr64(vals):
+    arr = (C.c_int64 * len(vals))()
+    for i, v in enumerate(vals):
+        arr[i] = v
+    return arr
+
+
+def _flush_stream_queue(q):
+    """Every queued group of one stream's queue, together."""
+    groups = [(key, q["jobs"].pop(key)) for key in list(q["jobs"])]
+    if groups:
+        _flush_wgrad_groups(groups)
+
+
+def flush_wgrads_if(total: int):
+    """Launches the current stream's queued weight gradients once at least `total` GEMM jobs wait (the encoder layers call this
+    after queueing their four products: groups of D2R_LAYER_GROUP whole layers leave as one launch)."""
+    q = _WGRAD_Q.get(torch.cuda.current_stream().cuda_stream)
+    if q is not None and sum(len(v) for k, v in q["jobs"].items() if k[0] != "ln") >= total:
+        _flush_stream_queue(q)
 
 
 EARLY_FLUSH = False  # set by d2r_amd.dp when the gradient all-reduce overlaps with backward
@@ -210,8 +252,7 @@ def _flush_before_encoders():
     _early_flushed.add(h)
     q = _WGRAD_Q.get(h)
     if q is not None:
-        for key in list(q["jobs"]):
-            _flush_wgrad_group(key, q["jobs"].pop(key))
+        _flush_stream_queue(q)
 
 
 def flush_wgrads():
@@ -220,8 +261,7 @@ def flush_wgrads():
     for q in _WGRAD_Q.values():
         if q["jobs"]:
             with torch.cuda.stream(q["stream"]):
-                for key in list(q["jobs"]):
-                    _flush_wgrad_group(key, q["jobs"].pop(key))
+                _flush_stream_queue(q)
 
 
 _COMPUTE_STREAMS = []  # extra streams the forward forks onto (d2r_amd.modules registers its text / vision streams)
@@ -920,13 +960,14 @@ class _EncoderLayer(torch.autograd.Function):
             for which, (N, K, xin, gw, gb) in enumerate(((3 * E, E, attn_in, d.gw_qkv, d.gb_qkv), (E, E, d.ctx, d.gw_o, d.gb_o),
                                                           (Fi, E, ffn_in, d.gw_1, d.gb_1), (E, Fi, d.f, d.gw_2, d.gb_2))):
                 _defer_wgrad_raw(d.dtype, N, K, T, K, d.o_dy[which], xin, gw, gb, (P[2 * which], P[2 * which + 1]), keep,
-                                 flush_at=D2R_LAYER_GROUP)
+                                 flush_at=1 << 30)
             if d.defer_ln:  # ... and the two LayerNorms' gamma / beta gradients: their partial sums sit in `scratch`
                 for i, (gs, bs) in enumerate(((d.gln1_g, d.gln1_b), (d.gln2_g, d.gln2_b))):
-                    _defer_ln_sum(T, E, d.o_lnws[i], gs, bs, (P[8 + 2 * i], P[9 + 2 * i]), keep, flush_at=2 * D2R_LAYER_GROUP)
+                    _defer_ln_sum(T, E, d.o_lnws[i], gs, bs, (P[8 + 2 * i], P[9 + 2 * i]), keep, flush_at=1 << 30)
                 ready = ()
             else:
                 ready = bundle.params[8:]  # LayerNorm gradients were accumulated inside the call
+            flush_wgrads_if(4 * D2R_LAYER_GROUP)  # whole layers: the four shapes of D2R_LAYER_GROUP layers leave as one launch
         else:
             ready = bundle.params
         ctx.keep = None

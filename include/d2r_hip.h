@@ -109,6 +109,15 @@ int d2r_gemm(const d2r_gemm_desc* d, void* stream);
 int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const void* const* h_A,
                         const void* const* h_B, float* const* h_C, float* const* h_dbias, int count, float beta,
                         void* stream);
+/* Weight gradients of DIFFERENT shapes in one call: problem i is C_i[M_i,N_i] (fp32, ldc_i) = beta * C_i + A_i^T B_i with A_i [K_i,M_i]
+ * (lda_i), B_i [K_i,N_i] (ldb_i) of dtype, dbias_i[m] += sum_k A_i[k,m] (h_dbias may be NULL).  All arrays are HOST arrays of `count`
+ * entries.  The 16-bit problems with at least 128 rows, columns and reduction rows leave together on 256 x 256 tiles (launches of up
+ * to 40 problems: the deferred weight gradients of a whole branch - models/modeling_unimo.py:334-470 and the cells' linears - fill
+ * the chip whatever the single shapes are); the rest go through d2r_gemm_tn_grouped shape class by shape class.  No two problems may
+ * share an output.  Deterministic. */
+int d2r_gemm_tn_grouped_v(int dtype, int count, const int* M, const int* N, const int* K, const int64_t* lda, const int64_t* ldb,
+                          const int64_t* ldc, const void* const* h_A, const void* const* h_B, float* const* h_C, float* const* h_dbias,
+                          float beta, void* stream);
 /* tuning switches for A/B measurements (tests/bench_gemm.py): LDS buffers (1|2), vectorised bf16 epilogue (0|1),
  * forced tile (-1 auto, 1: 64x64, 2: 128x64, 3: 128x128, 4..9 / 100..101: LDS-DMA variants).  Defaults are the measured
  * winners.  Debug aid: the setting (like the D2R_GEMM_* environment switches read at load time) is PROCESS-GLOBAL and not

@@ -57,6 +57,10 @@ ROUTING_CASES = [
     RoutingCase("rt_img_init", True, 3, 5, 8, 3, "init"),
     RoutingCase("rt_img_normal", True, 3, 10, 16, 3, "normal", seed=2),
     RoutingCase("rt_text_ragged", False, 4, 19, 7, 3, "normal", seed=3, in_scale=0.5),
+    # DR_step 8 (BASELINE.json configs[4]): the reference builds DR_step - 2 = six middle layers (models/InteractionModule.py:16,27-29);
+    # about half of the paths pruned, so that closed routers and skip paths occur in the middle of the chain
+    RoutingCase("rt_text_dr8", False, 2, 6, 5, 8, "normal", seed=4),
+    RoutingCase("rt_img_dr8", True, 2, 5, 6, 8, "normal", seed=5),
 ]
 
 MODEL_CASES = [
@@ -65,6 +69,7 @@ MODEL_CASES = [
     ModelCase("m_l2_eval", 2, 64, 32, 3, 8, 3, "normal", train=False),
     ModelCase("m_l2_dr4", 2, 96, 32, 2, 12, 4, "normal", seed=1),
     ModelCase("m_l12", 12, 96, 32, 2, 16, 3, "normal", seed=2),
+    ModelCase("m_l2_dr8", 2, 64, 32, 2, 8, 8, "normal", seed=6),
     # BASELINE.json configs[0] ("C1") at FULL size: MVSA-Single as the reference's own run.py builds it - batch 4, max_seq 64,
     # 224x224 images at patch 32 (49 patches + CLS = 50 image tokens), 12+12 encoder layers, DR_step 3 (run.py:70), default
     # router initialisation (every path open), ragged text lengths

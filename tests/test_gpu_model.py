@@ -103,7 +103,10 @@ def _grad_norm_check(tag, names, norms, noise, params, dtype):
         # statistics are printed, and only sanity is asserted; the stable bf16 gradient check is
         # test_default_init_gradients_vs_oracle.
         if tag.startswith("rt_"):
-            assert np.median(rels) <= 2e-2, f"{tag}: median bf16 gradient-norm error {np.median(rels):.3f}"
+            # DR_step 8 (round 4 fixtures): eight routing layers instead of three or four round every stored activation twice as
+            # often before the loss; measured median 4.5e-2 / 4.5e-3 (text / image branch; fp16: 5.3e-3 / 1.4e-3, fp32: 8e-7 / 3e-6)
+            deep = 4.0 if tag.endswith("dr8") else 1.0
+            assert np.median(rels) <= 2e-2 * deep, f"{tag}: median bf16 gradient-norm error {np.median(rels):.3f}"
             assert np.quantile(rels, 0.9) <= 0.2, f"{tag}: p90 bf16 gradient-norm error {np.quantile(rels, 0.9):.3f}"
         else:
             assert np.isfinite(rels).all() and np.median(rels) <= 1.0, f"{tag}: median bf16 gradient-norm error {np.median(rels):.3f}"
@@ -139,7 +142,8 @@ def _full_grad_check(tag, g, names, noise, params, dtype):
             lim = 0.999 if tag.startswith("rt_") else (0.99 if tag in ("m_l2_normal", "m_l2_eval", "m_l2_dr4") else 0.8)
             assert cos >= lim, f"{tag}: fp16 gradient direction cos {cos:.4f} < {lim}"
         elif tag.startswith("rt_"):  # full-model fixtures: chaotic in bf16, see _grad_norm_check
-            assert cos >= 0.99, f"{tag}: bf16 gradient direction cos {cos:.3f}"
+            lim = 0.96 if tag.endswith("dr8") else 0.99  # (eight layers deep: measured 0.976 on rt_img_dr8; fp16 0.9996 - 0.9998, asserted above)
+            assert cos >= lim, f"{tag}: bf16 gradient direction cos {cos:.3f}"
 
 
 def _layer_names(dr):
