@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--dr-step", type=int, default=3)
+    ap.add_argument("--num-cells", type=int, default=6, help="cells per routing layer (6 = the reference; BASELINE configs[4] names 4)")
+    ap.add_argument("--classes", type=int, default=3, help="classes of the head (3 = MVSA; BASELINE configs[3], TumEmo: 7)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "f32"],
                     help="compute dtype; fp16 (default) is the 16-bit mode that meets the 1e-3 logits/loss tolerance")
     ap.add_argument("--no-alt-leg", "--no-fp16-leg", dest="no_alt_leg", action="store_true",
@@ -84,13 +86,15 @@ def parse():
                     help="overlap the AdamW pass with the next forward pass (FusedAdamW.overlap_with_forward; measured: no gain, DESIGN.md)")
     ap.add_argument("--bert-dropout", type=float, default=0.0,
                     help="hidden / attention-probability dropout of the BERT config (BASELINE.md section 3 benchmarks 0)")
+    ap.add_argument("--tuning", type=int, action="append", default=[],
+                    help="A/B runs: d2r_gemm_tuning tile code(s) applied before the first step (e.g. 120: grouped launches off, 102: 128-wide weight gradients)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("D2R_BENCH_GRAPH", "0")),
                     help="1: replay the step from a captured hipGraph (fwd+bwd[+AdamW at N=1]); 0 (default): eager launches — measured faster on ROCm 7.2, see DESIGN.md")
     return ap.parse_args()
 
 
-def synthetic_batch(B, L, image_size, device, seed):
-    """ids ~ U{1000..29999} with [:,0]=101, all-ones mask, images ~ N(0,1), labels ~ U{0..2}."""
+def synthetic_batch(B, L, image_size, device, seed, classes=3):
+    """ids ~ U{1000..29999} with [:,0]=101, all-ones mask, images ~ N(0,1), labels ~ U{0..classes-1}."""
     import torch
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(1000, 30000, (B, L), generator=g)
@@ -98,8 +102,20 @@ def synthetic_batch(B, L, image_size, device, seed):
     mask = torch.ones(B, L, dtype=torch.long)
     tt = torch.zeros(B, L, dtype=torch.long)
     images = torch.randn(B, 3, image_size, image_size, generator=g)
-    labels = torch.randint(0, 3, (B,), generator=g)
+    labels = torch.randint(0, classes, (B,), generator=g)
     return tuple(t.to(device) for t in (ids, mask, tt, labels, images))
+
+
+def workload_name(args):
+    """Which BASELINE.json configuration the flags describe (per-GPU shard of the 8-GPU configurations)."""
+    key = (args.seq, args.image_size, args.patch, args.dr_step, args.num_cells, args.classes)
+    if key == (128, 224, 16, 3, 6, 3):
+        return "BASELINE configs[1]" if args.batch == 32 else "BASELINE configs[1] shape at another batch"
+    if key == (256, 384, 16, 3, 6, 7):
+        return "BASELINE configs[3] (TumEmo-scale: global batch 64 on 8 GPUs = 8 per GPU)" if args.batch == 8 else "BASELINE configs[3] shape at another batch"
+    if key == (512, 224, 16, 8, 4, 3):
+        return "BASELINE configs[4] (stress: global batch 128 on 8 GPUs = 16 per GPU)" if args.batch == 16 else "BASELINE configs[4] shape at another batch"
+    return "custom shape"
 
 
 def cpu_baseline(args, sd_cpu):
@@ -117,9 +133,9 @@ def cpu_baseline(args, sd_cpu):
     cores = max(1, min(cores, 16))  # a 1-GPU box owns a 16-core CPU share; os.cpu_count() reports the whole host
     torch.set_num_threads(cores)
     cfg = O.OracleConfig(text_layers=args.layers, vision_layers=args.layers, image_size=args.image_size,
-                         patch_size=args.patch, DR_step=args.dr_step)
+                         patch_size=args.patch, DR_step=args.dr_step, num_cells=args.num_cells, num_classes=args.classes)
     nb = args.cpu_samples
-    ids, mask, tt, labels, images = synthetic_batch(nb, args.seq, args.image_size, "cpu", seed=0)
+    ids, mask, tt, labels, images = synthetic_batch(nb, args.seq, args.image_size, "cpu", seed=0, classes=args.classes)
 
     def run():
         sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
@@ -180,6 +196,9 @@ def main():
     import d2r_amd
     d2r_amd.configure_runtime()
     log("imports done")
+    for code in args.tuning:
+        from d2r_amd import _lib as _l
+        _l.load().d2r_gemm_tuning(1, 1, code)
     rank, world = init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -192,7 +211,7 @@ def main():
     tc = TextConfig(num_hidden_layers=args.layers, hidden_dropout_prob=args.bert_dropout,
                     attention_probs_dropout_prob=args.bert_dropout)
     vc = VisionConfig(num_hidden_layers=args.layers, image_size=args.image_size, patch_size=args.patch)
-    model = M.UnimoModelF(default_args(DR_step=args.dr_step), vc, tc)
+    model = M.UnimoModelF(default_args(DR_step=args.dr_step, num_cells=args.num_cells), vc, tc, num_classes=args.classes)
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     log("model built on host")
     model.to(dev).set_compute_dtype(dtype).train()
@@ -212,7 +231,7 @@ def main():
         # (FusedAdamW.overlap_with_forward): same launches, same results; all of it inside the timed region (the closing
         # synchronisation waits for the last update).
         opt.overlap_with_forward(model)
-    batch = synthetic_batch(args.batch, args.seq, args.image_size, dev, seed=rank)
+    batch = synthetic_batch(args.batch, args.seq, args.image_size, dev, seed=rank, classes=args.classes)
 
     def step():
         dp.begin_step()
@@ -314,10 +333,11 @@ def main():
         "metric": "samples/sec fwd+bwd", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "precision": PRECISION_NOTE[args.dtype], "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: synthetic MVSA-Single shape, per-GPU batch %d, seq_len %d, %d image tokens, "
-                               "DR_step %d, %d+%d encoder layers, random-init weights, dropout %g; step = fwd+bwd+grad-allreduce+AdamW"
-                               % (args.batch, args.seq, (args.image_size // args.patch) ** 2 + 1, args.dr_step, args.layers, args.layers,
-                                  args.bert_dropout),
+        "config": {"workload": "%s: synthetic MVSA-Single-style batch, per-GPU batch %d, seq_len %d, %d image tokens, "
+                               "DR_step %d, %d cells per routing layer, %d classes, %d+%d encoder layers, random-init weights, dropout %g; "
+                               "step = fwd+bwd+grad-allreduce+AdamW"
+                               % (workload_name(args), args.batch, args.seq, (args.image_size // args.patch) ** 2 + 1, args.dr_step,
+                                  args.num_cells, args.classes, args.layers, args.layers, args.bert_dropout),
                    "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}"},
         "final_loss": round(loss_val, 5), "launch": "hipGraph replay" if args.graph else "eager",
         "optimizer_overlap": bool(opt._defer is not None),
@@ -331,7 +351,7 @@ def main():
         # queue long before the host refills it, so the loop time is host time (launch calls, autograd, Python).  The
         # host_enqueue figure above is taken at the benchmark batch, where the host mostly waits for room in the launch queue.
         try:
-            small = synthetic_batch(2, args.seq, args.image_size, dev, seed=7)
+            small = synthetic_batch(2, args.seq, args.image_size, dev, seed=7, classes=args.classes)
 
             def small_step():
                 loss, _ = model(*small)
@@ -535,7 +555,9 @@ def main():
         try:
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--dtype", alt, "--steps", str(min(args.steps, 10)), "--warmup", "3",
-                   "--batch", str(args.batch), "--seq", str(args.seq), "--layers", str(args.layers), "--no-cpu-baseline",
+                   "--batch", str(args.batch), "--seq", str(args.seq), "--layers", str(args.layers), "--image-size", str(args.image_size),
+                   "--patch", str(args.patch), "--dr-step", str(args.dr_step), "--num-cells", str(args.num_cells), "--classes", str(args.classes),
+                   "--no-cpu-baseline",
                    "--no-fp32-leg", "--no-roofline", "--no-alt-leg", "--no-host-leg"]
             torch.cuda.synchronize()
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)

@@ -68,8 +68,7 @@ class InteractionDesc(C.Structure):
                 ("heads_imrc", i32), ("hid_imrc", i32), ("train", i32), ("layers", C.POINTER(RoutingLayerParams)),
                 ("own", vp), ("other", vp), ("out", vp), ("paths", vp), ("arena", vp), ("arena_bytes", sz),
                 ("splitk_ws", vp), ("splitk_bytes", sz), ("d_out", vp), ("d_paths", vp), ("d_own", vp), ("d_other", vp),
-                ("scratch", vp), ("scratch_bytes", sz), ("kv_all", LinearParams),
-                ("n_aux", i32), ("aux_stream", vp * 3), ("aux_ws", vp * 3), ("aux_ws_bytes", sz)]
+                ("scratch", vp), ("scratch_bytes", sz), ("kv_all", LinearParams)]
 
 
 class HeadDesc(C.Structure):
@@ -91,6 +90,7 @@ SIGNATURES = {
     "d2r_last_error": (C.c_char_p, []),
     "d2r_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "d2r_gemm_tuning": (None, [i32, i32, i32]),
+    "d2r_gemm_group": (i32, [C.POINTER(GemmDesc), i32, vp]),
     "d2r_gemm_tn_grouped_v": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), f32, vp]),
     "d2r_gemm_tn_grouped": (i32, [i32, i32, i32, i32, i64, i64, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),

@@ -18,6 +18,7 @@
 // include/d2r_hip.h, section K11.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -406,6 +407,7 @@ static int g_wgrad_glds = env_int("D2R_WGRAD_GLDS", 1);
 // 2.5 k-cycle prologue and the store burst of the whole grid: 530-860 TFLOP/s against 580-940 on the 128-wide kernels at 2-3
 // workgroups per CU.  The weight gradients (64-98 K-tiles, a thousand tiles per launch) are where the wide tiles pay.
 static int g_gemm8 = 0;
+static int g_group = 1;  // d2r_gemm_group: grouped launches of independent forward / dX products (d2r_gemm_tuning tile 120 / 121: off / on)
 static int g_gemm8_wgrad = 1;  // ... for the grouped weight gradients (tile 102 / 103)
 static int g_gemm8_min = 150;  // fewest 256 x 256 tiles of a forward / dX product that takes them (tile 1000 + n sets it)
 
@@ -476,6 +478,7 @@ extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
   if (tile == 100 || tile == 101) g_wgrad_glds = tile - 100;  // A/B switch of the grouped weight-gradient kernel (0: 64x64 generic)
   else if (tile == 102 || tile == 103) g_gemm8_wgrad = tile - 102;  // 256 x 256 deep-pipelined grouped weight gradients off / on
   else if (tile == 110 || tile == 111) g_gemm8 = tile - 110;        // 256 x 256 forward / dX products off / on
+  else if (tile == 120 || tile == 121) g_group = tile - 120;        // grouped launches of d2r_gemm_group off / on
   else if (tile >= 1000) g_gemm8_min = tile - 1000;
   else g_tile = tile;
 }
@@ -931,7 +934,8 @@ static int launch_dtype(const GemmArgs& a, int layout, int batch, hipStream_t st
   return d2r_fail(D2R_ERR_INVALID, "d2r_gemm: bad layout %d", layout);
 }
 
-extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
+// descriptor -> kernel argument block (validation included); `batch` = nb * nh
+static int gemm_desc_to_args(const d2r_gemm_desc* d, GemmArgs& a, int& batch) {
   D2R_REQUIRE(d != nullptr, "d2r_gemm: null descriptor");
   D2R_REQUIRE(d->A && d->B && d->C, "d2r_gemm: null operand");
   D2R_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "d2r_gemm: negative size");
@@ -942,13 +946,13 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
   D2R_REQUIRE(d->nb >= 1 && d->nh >= 1, "d2r_gemm: batch must be >= 1");
   D2R_REQUIRE((int64_t)d->nb * d->nh <= 65535, "d2r_gemm: batch %lld exceeds grid.z", (long long)d->nb * d->nh);
   const bool a_kcont = d->layout != D2R_GEMM_TN, b_kcont = d->layout == D2R_GEMM_NT;
+  D2R_REQUIRE(d->layout == D2R_GEMM_NT || d->layout == D2R_GEMM_NN || d->layout == D2R_GEMM_TN, "d2r_gemm: bad layout %d", d->layout);
   D2R_REQUIRE(d->lda >= (a_kcont ? d->K : d->M), "d2r_gemm: lda %lld too small", (long long)d->lda);
   D2R_REQUIRE(d->ldb >= (b_kcont ? d->K : d->N), "d2r_gemm: ldb %lld too small", (long long)d->ldb);
   D2R_REQUIRE(d->ldc >= d->N, "d2r_gemm: ldc %lld < N", (long long)d->ldc);
   D2R_REQUIRE(!d->residual || d->ldr >= d->N, "d2r_gemm: ldr too small");
   D2R_REQUIRE(!d->workspace || d2r_aligned16(d->workspace), "d2r_gemm: workspace must be 16-byte aligned");
-  if (d->M == 0 || d->N == 0) return D2R_OK;
-  GemmArgs a;
+  a = GemmArgs{};
   a.A = d->A; a.B = d->B; a.C = d->C; a.bias = d->bias; a.R = d->residual; a.P = d->preact;
   a.M = d->M; a.N = d->N; a.K = d->K; a.nh = d->nh;
   a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldr = d->ldr;
@@ -979,15 +983,68 @@ extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
               cvec(d->grad_ref, d->ldc, d->sCb, d->sCh) &&
               cvec(d->residual, d->ldr, d->sRb, d->sRh)) ? 1 : 0;
   }
-  const int batch = d->nb * d->nh;
+  batch = d->nb * d->nh;
+  return D2R_OK;
+}
+static double gemm_desc_flops(const d2r_gemm_desc* d) { return 2.0 * d->nb * d->nh * d->M * d->N * (double)d->K; }
+static double gemm_desc_bytes(const d2r_gemm_desc* d) {
+  const double es = (double)d2r_esize(d->dtype), cs = (double)d2r_esize(d->c_dtype);
+  return (double)d->nb * d->nh * (((double)d->M * d->K + (double)d->N * d->K) * es +
+                                  (double)d->M * d->N * cs * (1 + (d->beta != 0.f) + (d->residual != nullptr) + (d->grad_ref != nullptr) + (d->preact != nullptr)));
+}
+
+extern "C" int d2r_gemm(const d2r_gemm_desc* d, void* stream) {
+  GemmArgs a;
+  int batch = 1;
+  if (int rc = gemm_desc_to_args(d, a, batch)) return rc;
+  if (d->M == 0 || d->N == 0) return D2R_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const double cs_ = (double)d2r_esize(d->c_dtype);
-  GemmTimerScope timed(st, d->dtype * 8 + d->layout * 2, 2.0 * batch * d->M * d->N * (double)d->K,
-                       (double)batch * (((double)d->M * d->K + (double)d->N * d->K) * es +
-                                        (double)d->M * d->N * cs_ * (1 + (d->beta != 0.f) + (d->residual != nullptr) + (d->grad_ref != nullptr) + (d->preact != nullptr))));
+  GemmTimerScope timed(st, d->dtype * 8 + d->layout * 2, gemm_desc_flops(d), gemm_desc_bytes(d));
   if (d->dtype == D2R_BF16) return launch_dtype<bf16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
   if (d->dtype == D2R_F16) return launch_dtype<f16_t>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
   return launch_dtype<float>(a, d->layout, batch, st, d->workspace, d->workspace_bytes);
+}
+
+// `n` INDEPENDENT products (no output of one is an operand or an output of another) enqueued together: the 16-bit forward / dX
+// products of one layout that fit the 128 x 128 LDS-DMA tiles leave as grouped launches of up to 16 problems (gemm_glds.hip:
+// every tile is computed exactly as in a launch of its own - bit-identical to n d2r_gemm calls); everything else is launched one
+// by one, in the order given.
+int d2r_gemm_glds_group_ok(const GemmArgs& a, int layout, int batch);                           // gemm_glds.hip
+int d2r_gemm_glds_group_launch(const GemmArgs* probs, int n, int layout, hipStream_t st);
+extern "C" int d2r_gemm_group(const d2r_gemm_desc* descs, int n, void* stream) {
+  D2R_REQUIRE(n >= 0 && (n == 0 || descs), "d2r_gemm_group: null descriptor array");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  std::vector<GemmArgs> args(n);
+  std::vector<char> grouped(n, 0);
+  for (int layout : {D2R_GEMM_NT, D2R_GEMM_NN}) {
+    for (int dtype : {D2R_BF16, D2R_F16}) {
+      std::vector<int> idx;
+      for (int i = 0; i < n; ++i) {
+        const d2r_gemm_desc& d = descs[i];
+        if (!g_group || g_tile >= 0 || d.layout != layout || d.dtype != dtype || d.M == 0 || d.N == 0) continue;
+        int batch = 1;
+        if (int rc = gemm_desc_to_args(&d, args[i], batch)) return rc;
+        if (d2r_gemm_glds_group_ok(args[i], layout, batch) && !(d.M <= 32)) idx.push_back(i);
+      }
+      if (idx.size() < 2) continue;  // (a single problem: its own launch, with its column-band tile order)
+      for (size_t first = 0; first < idx.size(); first += 16) {
+        const int m = (int)std::min<size_t>(16, idx.size() - first);
+        std::vector<GemmArgs> probs(m);
+        double fl = 0, by = 0;
+        for (int k = 0; k < m; ++k) {
+          const int i = idx[first + k];
+          probs[k] = args[i], grouped[i] = 1;
+          fl += gemm_desc_flops(&descs[i]), by += gemm_desc_bytes(&descs[i]);
+        }
+        GemmTimerScope timed(st, dtype * 8 + layout * 2, fl, by);
+        if (int rc = d2r_gemm_glds_group_launch(probs.data(), m, layout, st)) return rc;
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    if (!grouped[i])
+      if (int rc = d2r_gemm(&descs[i], stream)) return rc;
+  return D2R_OK;
 }
 
 // ---- grouped weight gradients -------------------------------------------------------------------------------

@@ -59,8 +59,8 @@ __device__ __forceinline__ int kpos(int c, int k) {
 // + batch index, operands at grp.A/B/C[group] + batch * g.sAb / sBb / sCb; the reduction length need not be a multiple of 64
 // (as in mode 1); rows are LOADED up to g.M (a multiple of 8) and STORED up to g.m_store.  Serves the key-side products of the
 // cross-attention backward (dV = P^T dO, dK = dS^T Q for every sample of up to four attention problems: one launch).
-template <typename E, int LAYOUT, int BN, int NWN = 2, int PIPE = 0, int MODE = 0, int NWM = 2>
-__global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, GemmGroup grp) {
+template <typename E, int LAYOUT, int BN, int NWN, int PIPE, int MODE, int NWM>
+__device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp, int tile_m, int tile_n, int z) {
   constexpr bool WGRAD = MODE == 1;        // fp32 accumulate epilogue + bias gradient
   constexpr bool RAGGED = MODE != 0;       // grouped launch (3-D tile order), ragged reduction length
   typedef typename H16<E>::v8 h8;  // E: E or f16_t (same tiles and LDS images; the MFMA opcode differs)
@@ -90,9 +90,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
   const bool stamping = PROBES && g.ts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
 #define GEMM_STAMP(i) do { if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g.ts[wave * 8 + (i)] = t_; } } while (0)
   GEMM_STAMP(0);
-  int tile_m, tile_n, z = 0;
-  if constexpr (RAGGED) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
-  else xcd_tile(g.xcd, tile_m, tile_n, g.band);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const E* A = reinterpret_cast<const E*>(g.A);
   const E* B = reinterpret_cast<const E*>(g.B);
@@ -531,6 +528,103 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
       }
     }
   }
+}
+
+template <typename E, int LAYOUT, int BN, int NWN = 2, int PIPE = 0, int MODE = 0, int NWM = 2>
+__global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, GemmGroup grp) {
+  int tile_m, tile_n, z = 0;
+  if constexpr (MODE != 0) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
+  else xcd_tile(g.xcd, tile_m, tile_n, g.band);
+  gemm_glds_body<E, LAYOUT, BN, NWN, PIPE, MODE, NWM>(g, grp, tile_m, tile_n, z);
+}
+
+// ---- grouped forward / dX launch: up to 16 INDEPENDENT problems of one layout and type on the 128 x 128 eight-wave tiles ------------
+// The cells of a routing layer (models/Cells.py:30-255) run chains of 768 x 768 products over 4-6 thousand rows: 192-300 tiles per
+// launch, one partial round of workgroups, 13-15 us for work worth 5.  Products that do not depend on each other (the query projections
+// of the three alignment cells and IMRC's q|k|v; the cells' second linears; ...) leave as ONE launch of a thousand tiles.  Every tile is
+// computed exactly as in a launch of its own (same tile shape, same accumulation order): bit-identical results.
+struct GemmFwdProb {
+  const void *A, *B;
+  void* C;
+  const float* bias;
+  const void* R;
+  void* P;
+  const void* G;
+  int M, N, K, lda, ldb, ldc, ldr;
+  float alpha, beta;
+  int act, gact, tn, pad;
+};
+constexpr int D2R_GEMM_FWD_GROUP_MAX = 16;
+struct GemmFwdGroup {
+  int nprob, ntiles, xcd, pad;
+  int tile_end[D2R_GEMM_FWD_GROUP_MAX];
+  GemmFwdProb p[D2R_GEMM_FWD_GROUP_MAX];
+};
+
+template <typename E, int LAYOUT>
+__global__ __launch_bounds__(512) void gemm_glds_group_kernel(GemmArgs g, GemmFwdGroup fg) {
+  // linear workgroup id -> linear tile id: every XCD (ids congruent mod 8) walks a CONTIGUOUS run of tiles, i.e. whole problems or
+  // whole row panels of one
+  int L = blockIdx.x;
+  const int nwg = fg.ntiles;
+  if (fg.xcd && nwg >= 16) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, k = L >> 3;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  int lo = 0, hi = fg.nprob - 1;  // first problem whose tile_end exceeds L
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (L < fg.tile_end[mid]) hi = mid;
+    else lo = mid + 1;
+  }
+  const int zp = __builtin_amdgcn_readfirstlane(lo);
+  const GemmFwdProb& P = fg.p[zp];
+  const int rem = L - (zp ? fg.tile_end[zp - 1] : 0);
+  const int tile_m = rem / P.tn, tile_n = rem - tile_m * P.tn;
+  g.A = P.A, g.B = P.B, g.C = P.C, g.bias = P.bias, g.R = P.R, g.P = P.P, g.G = P.G;
+  g.M = P.M, g.N = P.N, g.K = P.K, g.lda = P.lda, g.ldb = P.ldb, g.ldc = P.ldc, g.ldr = P.ldr;
+  g.alpha = P.alpha, g.beta = P.beta, g.act = P.act, g.gact = P.gact;
+  gemm_glds_body<E, LAYOUT, 128, 4, 0, 0, 2>(g, GemmGroup{}, tile_m, tile_n, 0);
+}
+
+// eligibility of one problem for the grouped launch (the conditions of d2r_gemm_glds_try for the 128 x 128 eight-wave tile, plus a
+// 16-bit vectorised output: the shared pack epilogue)
+int d2r_gemm_glds_group_ok(const GemmArgs& a, int layout, int batch) {
+  if (!d2r_is16(a.dtype) || a.c_dtype != a.dtype || batch != 1 || layout == D2R_GEMM_TN) return 0;
+  if (a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 128 || !a.vecA || !a.vecB || !a.vecC || a.dbias) return 0;
+  if (layout == D2R_GEMM_NN && a.N % 8 != 0) return 0;
+  if (a.lda >= ((int64_t)1 << 31) || a.ldb >= ((int64_t)1 << 31) || a.ldc >= ((int64_t)1 << 31) || a.ldr >= ((int64_t)1 << 31)) return 0;
+  return 1;
+}
+
+int d2r_gemm_glds_group_launch(const GemmArgs* probs, int n, int layout, hipStream_t st) {
+  if (n < 1 || n > D2R_GEMM_FWD_GROUP_MAX) return d2r_fail(D2R_ERR_INVALID, "d2r_gemm_glds_group_launch: %d problems (1..%d)", n, D2R_GEMM_FWD_GROUP_MAX);
+  GemmFwdGroup fg = {};
+  fg.nprob = n, fg.xcd = 1;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const GemmArgs& a = probs[i];
+    GemmFwdProb& p = fg.p[i];
+    p.A = a.A, p.B = a.B, p.C = a.C, p.bias = a.bias, p.R = a.R, p.P = a.P, p.G = a.G;
+    p.M = a.M, p.N = a.N, p.K = a.K, p.lda = (int)a.lda, p.ldb = (int)a.ldb, p.ldc = (int)a.ldc, p.ldr = (int)a.ldr;
+    p.alpha = a.alpha, p.beta = a.beta, p.act = a.act, p.gact = a.gact, p.tn = d2r_cdiv(a.N, 128), p.pad = 0;
+    tiles += d2r_cdiv(a.M, 128) * p.tn;
+    fg.tile_end[i] = tiles;
+  }
+  for (int i = n; i < D2R_GEMM_FWD_GROUP_MAX; ++i) fg.tile_end[i] = tiles;
+  fg.ntiles = tiles;
+  GemmArgs base = probs[0];
+  base.ts = nullptr, base.dbg = 0, base.band = 0, base.vecC = 1;
+  const bool f16 = base.dtype == D2R_F16;
+  d2r_gemm_variant_tl = 3;
+  if (layout == D2R_GEMM_NT) {
+    if (f16) hipLaunchKernelGGL((gemm_glds_group_kernel<f16_t, D2R_GEMM_NT>), dim3(tiles), dim3(512), 0, st, base, fg);
+    else hipLaunchKernelGGL((gemm_glds_group_kernel<bf16_t, D2R_GEMM_NT>), dim3(tiles), dim3(512), 0, st, base, fg);
+  } else {
+    if (f16) hipLaunchKernelGGL((gemm_glds_group_kernel<f16_t, D2R_GEMM_NN>), dim3(tiles), dim3(512), 0, st, base, fg);
+    else hipLaunchKernelGGL((gemm_glds_group_kernel<bf16_t, D2R_GEMM_NN>), dim3(tiles), dim3(512), 0, st, base, fg);
+  }
+  return d2r_check_launch("d2r_gemm_group(glds)");
 }
 
 template <typename E, int LAYOUT>

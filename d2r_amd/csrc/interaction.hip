@@ -169,6 +169,33 @@ int dwg(const Ctx& c, int M, int Nf, int Kf, const void* dy, int64_t ldy, const 
   return d2r_gemm(&g.d, c.st);
 }
 
+// ---- grouped launches of independent products (d2r_gemm_group) -----------------------------------------------------------------------
+// The cells of a routing layer are independent between the layer's inputs and its aggregation, and their token-row linears are
+// 768-wide products over 4-6 thousand rows: 192-300 tiles each, one partial round of workgroups (13-15 us for work worth 5).  The
+// products of DIFFERENT cells that are ready at the same point of the layer leave as one grouped launch (a thousand tiles: the
+// same kernel at its saturated rate); every tile is computed exactly as in a launch of its own, so the results are bit-identical to
+// the op-by-op schedule.  A Group must only hold products that neither read nor write each other's outputs.
+struct Group {
+  std::vector<d2r_gemm_desc> v;
+  void lin(const Ctx& c, int M, int N, int K, const void* x, int64_t ldx, const d2r_linear_params& p, void* y, int act = D2R_ACT_NONE,
+           const void* res = nullptr) {
+    G g(c.dt, c.dt, D2R_GEMM_NT, M, N, K, x, ldx, p.w, K, y, N);
+    g.d.bias = p.b, g.d.act = act, g.d.residual = res, g.d.ldr = N;
+    v.push_back(g.d);
+  }
+  void dxg(const Ctx& c, int M, int Kf, int Nf, const void* dy, int64_t ldy, const void* w, void* dx, int64_t ldc, float beta = 0.f,
+           const void* res = nullptr, const void* gref = nullptr, int gact = D2R_ACT_NONE) {
+    G g(c.dt, c.dt, D2R_GEMM_NN, M, Kf, Nf, dy, ldy, w, Kf, dx, ldc);
+    g.d.beta = beta, g.d.residual = res, g.d.ldr = Kf, g.d.grad_ref = gref, g.d.grad_act = gact;
+    v.push_back(g.d);
+  }
+  int flush(const Ctx& c) {
+    const int rc = v.empty() ? D2R_OK : d2r_gemm_group(v.data(), (int)v.size(), c.st);
+    v.clear();
+    return rc;
+  }
+};
+
 // queued weight gradients (768x768 / 1536x768 class): nothing in the backward pass reads them
 struct WJob {
   int M, Nf, Kf;
@@ -230,41 +257,25 @@ int xat_bwd(const Ctx& c, const Dims& d, const void* q, const void* k, int64_t l
                              d.B, d.Lq, Lk, E, scale, c.st);
 }
 
-// ---- cell-level concurrency ---------------------------------------------------------------------------------------------
-// The cells of a routing layer are independent between the layer's inputs and its aggregation, and most of them are chains of
-// launches that each fill a fraction of the chip (768-wide products over 4-6 thousand rows: one and a half workgroups per CU;
-// per-sample vector ops: a handful of workgroups).  With d2r_interaction_desc.n_aux = 3 the chains go to the call's stream and
-// three auxiliary streams, forked from and joined into the call's stream by events.  Every buffer has ONE writer stream at a
-// time and every accumulation into a shared buffer keeps the order of the single-stream schedule (the results are
-// bit-identical); all auxiliary work is joined before the call returns, in stream order.  cs[0] is the call's stream; without
-// auxiliary streams the four contexts are the same and the forks are no-ops.
-int fork(const Ctx& from, const Ctx& to) { return d2r_stream_fork(from.st, to.st); }
-
 // ---- forward of one routing layer --------------------------------------------------------------------------
-int layer_fwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
+// Schedule (one stream): routers and the per-sample vector chains (GLAC's global branch, GESC) as before; the token-row products in
+// four grouped launches A - D between the attention cores and the element-wise steps that separate them.
+int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
               const void* const* refs, const void* other, LayerF& L, void* out_final, float* probs, int64_t ldp) {
-  const Ctx &c0 = cs[0], &c1 = cs[1], &c2 = cs[2], &c3 = cs[3];
   const int B = d.B, T = d.T, nc = d.nc, hid = d.hid, n = d.n;
   const int64_t TEe = (int64_t)d.Lq * E, SEe = (int64_t)d.Lk * E;
   const d2r_linear_params* lp = p.lin;
-  TRY(fork(c0, c1));  // the layer's inputs are complete on the call's stream
-  TRY(fork(c0, c2));
-  TRY(fork(c0, c3));
-  // --- IMRC (cell 2): four large launches of its own --------------------------------------------------------------- stream 1
-  if (nc > 2) {
-    const Ctx& c = c1;
-    const void* x = refs[2];
-    const int dh = E / d.heads;
-    const char* qkv = (const char*)L.qkv;
-    TRY(lin(c, T, 3 * E, E, x, E, lp[D2R_RL_IMRC_QKV], L.qkv));
-    TRY(d2r_mha_fwd(c.dt, qkv, 3 * E, (int64_t)d.Lq * 3 * E, qkv + E * d.es, 3 * E, (int64_t)d.Lq * 3 * E, qkv + 2 * E * d.es, 3 * E,
-                    (int64_t)d.Lq * 3 * E, L.y, E, TEe, x, E, TEe, nullptr, L.lse_i, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
-    TRY(lin(c, T, d.hidi, E, L.y, E, lp[D2R_RL_IMRC_FC1], L.f1, D2R_ACT_RELU));
-    TRY(lin(c, T, E, d.hidi, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2], L.e2, D2R_ACT_NONE, L.y));
-  }
-  // --- routers (fp32 end to end: routing decisions are exact) -------------------------------------------------- stream 2
+  Group grp;
+  // --- group A: everything that reads only the layer's inputs: IMRC's q|k|v, the query projections of the three alignment cells,
+  //     CRCMC's second input branch Ks = tanh(W x) ---------------------------------------------------------------------------------
+  if (nc > 2) grp.lin(c, T, 3 * E, E, refs[2], E, lp[D2R_RL_IMRC_QKV], L.qkv);
+  if (nc > 1) grp.lin(c, T, E, E, refs[1], E, lp[D2R_RL_GLAC_Q], L.g_q);
+  if (nc > 3) grp.lin(c, T, E, E, refs[3], E, lp[D2R_RL_CMRC_Q], L.c_q);
+  if (nc > 4) grp.lin(c, T, E, E, refs[4], E, lp[D2R_RL_CRCMC_Q], L.r_q);
+  if (nc > 4) grp.lin(c, T, E, E, refs[4], E, lp[D2R_RL_CRCMC_MLP2], L.r_Ks, D2R_ACT_TANH);
+  TRY(grp.flush(c));
+  // --- routers (fp32 end to end: routing decisions are exact) ---------------------------------------------------------------------
   {
-    const Ctx& c = c2;
     if (first) {  // the cells of layer 0 read the same tensor: pool once, ONE plain GEMM with N = ncell*hid
       TRY(d2r_meanpool_fwd(c.dt, refs, 1, B, d.Lq, E, L.pooled, c.st));
       TRY(lin(c, B, nc * hid, E, L.pooled, E, lp[D2R_RL_R0], L.h, D2R_ACT_RELU, nullptr, D2R_F32));
@@ -280,9 +291,33 @@ int layer_fwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
     g.d.bias = lp[D2R_RL_R2].b, g.d.s_bias_b = P, g.d.act = D2R_ACT_TANH_RELU;
     TRY(d2r_gemm(&g.d, c.st));
   }
-  // --- GLAC (cell 1), global branch: per-sample vectors ------------------------------------------------------------ stream 2
+  // --- IMRC (cell 2): 16-head attention over its own q|k|v -------------------------------------------------------------------------
+  if (nc > 2) {
+    const int dh = E / d.heads;
+    const char* qkv = (const char*)L.qkv;
+    TRY(d2r_mha_fwd(c.dt, qkv, 3 * E, (int64_t)d.Lq * 3 * E, qkv + E * d.es, 3 * E, (int64_t)d.Lq * 3 * E, qkv + 2 * E * d.es, 3 * E,
+                    (int64_t)d.Lq * 3 * E, L.y, E, TEe, refs[2], E, TEe, nullptr, L.lse_i, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
+  }
+  // --- the alignment cores of GLAC / CMRC / CRCMC: ONE attention launch for all of them (same shapes, same
+  //     softmax(100 q k^T / sqrt(768)) v).  Keys and values are column blocks of the module-wide k|v projection of `other` ---------
+  {
+    const void *qa[3], *ka[3], *va[3];
+    void* oa[3];
+    float* la[3];
+    int ncore = 0;
+    auto core = [&](void* qbuf, const void* kv, void* o, float* lse) {
+      qa[ncore] = qbuf, ka[ncore] = kv, va[ncore] = (const char*)kv + E * d.es, oa[ncore] = o, la[ncore] = lse;
+      ++ncore;
+    };
+    if (nc > 1) core(L.g_q, L.g_kv, L.g_c, L.g_lse);
+    if (nc > 3) core(L.c_q, L.c_kv, L.c_c, L.c_lse);
+    if (nc > 4) core(L.r_q, L.r_kv, L.r_c, L.r_lse);
+    if (ncore)
+      TRY(d2r_xattn_fwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, (int64_t)d.Lk * d.ldkv, va, d.ldkv, (int64_t)d.Lk * d.ldkv, oa, E, TEe, nullptr, E,
+                              TEe, nullptr, la, B, d.Lq, d.Lk, E, XSCALE, c.st));
+  }
+  // --- GLAC (cell 1), global branch: per-sample vectors -------------------------------------------------------------------------------
   if (nc > 1) {
-    const Ctx& c = c2;
     const void* x = refs[1];
     TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GLAC_TPOOL], L.g_pt, D2R_ACT_TANH));
     TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GLAC_IPOOL], L.g_pi, D2R_ACT_TANH));
@@ -290,49 +325,30 @@ int layer_fwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
     TRY(lin(c, B, E, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO], L.g_glo));
     TRY(d2r_l2norm_fwd(c.dt, L.g_glo, L.g_l2g, L.g_nglo, B, E, c.st));
     TRY(lin(c, B, E, E, L.g_l2g, E, lp[D2R_RL_GLAC_FC2], L.g_sg));
+    TRY(d2r_sqdiff_fwd(c.dt, x, L.g_c, L.g_sq, (int64_t)T * E, c.st));  // local branch: (t - c)^2 behind the core
   }
-  // --- the alignment cores of GLAC / CMRC / CRCMC: their query projections, then ONE attention launch for all of them (same
-  //     shapes, same softmax(100 q k^T / sqrt(768)) v: three times the workgroups of a single core).  Keys and values are column
-  //     blocks of the module-wide k|v projection of `other` computed before the first layer. ------------------------ stream 0
-  {
-    const Ctx& c = c0;
-    const void *qa[3], *ka[3], *va[3];
-    void* oa[3];
-    float* la[3];
-    int ncore = 0;
-    auto core = [&](const void* x, const d2r_linear_params& pq, void* qbuf, const void* kv, void* o, float* lse) -> int {
-      TRY(lin(c, T, E, E, x, E, pq, qbuf));
-      qa[ncore] = qbuf, ka[ncore] = kv, va[ncore] = (const char*)kv + E * d.es, oa[ncore] = o, la[ncore] = lse;
-      ++ncore;
-      return D2R_OK;
-    };
-    if (nc > 1) TRY(core(refs[1], lp[D2R_RL_GLAC_Q], L.g_q, L.g_kv, L.g_c, L.g_lse));
-    if (nc > 3) TRY(core(refs[3], lp[D2R_RL_CMRC_Q], L.c_q, L.c_kv, L.c_c, L.c_lse));
-    if (nc > 4) TRY(core(refs[4], lp[D2R_RL_CRCMC_Q], L.r_q, L.r_kv, L.r_c, L.r_lse));
-    if (ncore)
-      TRY(d2r_xattn_fwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, (int64_t)d.Lk * d.ldkv, va, d.ldkv, (int64_t)d.Lk * d.ldkv, oa, E, TEe, nullptr, E,
-                              TEe, nullptr, la, B, d.Lq, d.Lk, E, XSCALE, c.st));
-  }
-  TRY(fork(c0, c2));  // the cores' outputs
-  TRY(fork(c0, c3));
-  // --- CRCMC (cell 4) behind its core ----------------------------------------------------------------------------- stream 3
-  if (nc > 4) {
-    const Ctx& c = c3;
-    const void* x = refs[4];
-    TRY(lin(c, T, E, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1], L.r_Qs, D2R_ACT_TANH));
-    TRY(lin(c, T, E, E, x, E, lp[D2R_RL_CRCMC_MLP2], L.r_Ks, D2R_ACT_TANH));
-    TRY(lin(c, T, E, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1], L.r_a));
-    TRY(lin(c, T, E, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2], L.r_b));
-    TRY(xat_fwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, L.e4, L.r_Qs, L.r_lse2, 1.0f));  // unscaled softmax(Q K^T), + Qs
-  }
-  // --- GLAC, local branch behind its core, then the SAF gate over [global | local] ------------------------------- stream 2
+  // --- group B: the first linears behind the cores and behind IMRC's attention ---------------------------------------------------------
+  if (nc > 2) grp.lin(c, T, d.hidi, E, L.y, E, lp[D2R_RL_IMRC_FC1], L.f1, D2R_ACT_RELU);
+  if (nc > 1) grp.lin(c, T, E, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC], L.g_loc);
+  if (nc > 3) grp.lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE], L.c_s, D2R_ACT_TANH);
+  if (nc > 3) grp.lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT], L.c_h);
+  if (nc > 4) grp.lin(c, T, E, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1], L.r_Qs, D2R_ACT_TANH);
+  if (nc > 4) grp.lin(c, T, E, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2], L.r_b);
+  TRY(grp.flush(c));
+  if (nc > 1) TRY(d2r_l2norm_fwd(c.dt, L.g_loc, L.g_l2, L.g_nloc, T, E, c.st));
+  if (nc > 3) TRY(d2r_muladd_fwd(c.dt, refs[3], L.c_s, L.c_h, L.c_mod, (int64_t)T * E, c.st));
+  // --- group C: the second linears -------------------------------------------------------------------------------------------------------
+  if (nc > 2) grp.lin(c, T, E, d.hidi, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2], L.e2, D2R_ACT_NONE, L.y);
+  if (nc > 1) grp.lin(c, T, E, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1], L.g_sl);
+  if (nc > 3) grp.lin(c, T, E, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1], L.c_f, D2R_ACT_RELU);
+  if (nc > 4) grp.lin(c, T, E, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1], L.r_a);
+  TRY(grp.flush(c));
+  // --- CRCMC (cell 4): its second core, unscaled softmax(Q K^T) over its own tokens, + Qs ------------------------------------------------
+  if (nc > 4) TRY(xat_fwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, L.e4, L.r_Qs, L.r_lse2, 1.0f));
+  // --- CMRC (cell 3): last linear + skip ---------------------------------------------------------------------------------------------------
+  if (nc > 3) TRY(lin(c, T, E, E, L.c_f, E, lp[D2R_RL_CMRC_FC2], L.e3, D2R_ACT_NONE, refs[3]));
+  // --- GLAC: the SAF gate over [global | local] ----------------------------------------------------------------------------------------------
   if (nc > 1) {
-    const Ctx& c = c2;
-    const void* x = refs[1];
-    TRY(d2r_sqdiff_fwd(c.dt, x, L.g_c, L.g_sq, (int64_t)T * E, c.st));
-    TRY(lin(c, T, E, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC], L.g_loc));
-    TRY(d2r_l2norm_fwd(c.dt, L.g_loc, L.g_l2, L.g_nloc, T, E, c.st));
-    TRY(lin(c, T, E, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1], L.g_sl));
     // S = cat([sg[:,None], sl], 1)  [B, n, E]
     const size_t row = (size_t)E * d.es;
     TRY(copy2d(L.g_S, (size_t)n * row, L.g_sg, row, row, B, c.st));
@@ -345,19 +361,8 @@ int layer_fwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
     TRY(d2r_gemm(&g.d, c.st));
     TRY(d2r_l2norm_fwd(c.dt, L.g_wsum, L.e1, L.g_ne1, B, E, c.st));
   }
-  // --- CMRC (cell 3) behind its core ------------------------------------------------------------------------------ stream 0
-  if (nc > 3) {
-    const Ctx& c = c0;
-    const void* x = refs[3];
-    TRY(lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE], L.c_s, D2R_ACT_TANH));
-    TRY(lin(c, T, E, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT], L.c_h));
-    TRY(d2r_muladd_fwd(c.dt, x, L.c_s, L.c_h, L.c_mod, (int64_t)T * E, c.st));
-    TRY(lin(c, T, E, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1], L.c_f, D2R_ACT_RELU));
-    TRY(lin(c, T, E, E, L.c_f, E, lp[D2R_RL_CMRC_FC2], L.e3, D2R_ACT_NONE, x));
-  }
-  // --- GESC (cell 5): per-sample vectors ------------------------------------------------------------------------------ stream 1
+  // --- GESC (cell 5): per-sample vectors ------------------------------------------------------------------------------------------------------
   if (nc > 5) {
-    const Ctx& c = c1;
     const void* x = refs[5];
     TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GESC_TPOOL], L.s_a, D2R_ACT_TANH));
     TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GESC_IPOOL], L.s_b, D2R_ACT_TANH));
@@ -367,14 +372,11 @@ int layer_fwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
     TRY(d2r_softmax_fwd(c.dt, c.dt, L.s_z, L.s_g, E, B, E, 1.0f, nullptr, 1, c.st));
     TRY(d2r_lerp_fwd(c.dt, L.s_g, L.s_a, L.s_b, L.e5, (int64_t)B * E, c.st));
   }
-  TRY(fork(c1, c0));  // join
-  TRY(fork(c2, c0));
-  TRY(fork(c3, c0));
   // --- K8: path normalisation, gates, aggregation ------------------------------------------------------------------
   const void* embs[6] = {refs[0], L.e1, L.e2, L.e3, L.e4, L.e5};
   void* outs[6];
   for (int i = 0; i < 6; ++i) outs[i] = final ? (i == 0 ? out_final : nullptr) : L.outs[i];
-  return d2r_route_aggregate_fwd(c0.dt, embs, final ? refs : nullptr, L.gates, B, d.Lq, E, nc, P, outs, probs, ldp, c0.st);
+  return d2r_route_aggregate_fwd(c.dt, embs, final ? refs : nullptr, L.gates, B, d.Lq, E, nc, P, outs, probs, ldp, c.st);
 }
 
 // ---- backward scratch of one layer -----------------------------------------------------------------------------
@@ -447,23 +449,19 @@ int acc32(const Ctx& c, const float* tmp, float* sink, int64_t nel) { return d2r
 // ---- backward of one routing layer --------------------------------------------------------------------------------
 // douts[i]: gradient of output i (NULL = zero; only legal for the final layer's single output);  dx[j]: gradient w.r.t.
 // input j, OVERWRITTEN (layer 0: all six alias d_own);  d_other: ACCUMULATED (zeroed by the caller).
-// Streams (see "cell-level concurrency" above): 0 aggregation, CMRC, CRCMC, the cores' backward, the query-side products;
-// 1 routers, IMRC; 2 GLAC's gate and global branch, GESC (the per-sample vector chains; both accumulate into the cls rows of
-// d_other, in this order); 3 GLAC's local branch.  The launches that ACCUMULATE into an input gradient dx[j] ("tails") come
-// last in every chain: behind the routers' pooled gradient (which initialises dx[j]) in layers whose dx[j] are six buffers,
-// and - layer 0, where all six alias d_own - on the call's stream after the join, in the order of the single-stream schedule.
-int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
+// Schedule (one stream): aggregation, routers (their pooled gradient initialises every dx[j]), the per-sample vector chains, then
+// the token-row products in grouped launches B1 - B5 between the attention backward kernels and the element-wise steps.  The
+// products that ACCUMULATE into an input gradient dx[j] ("tails", beta = 1) are grouped only when the dx[j] are six different
+// buffers; in layer 0, where all six alias d_own, they are launched one after the other in a fixed order.
+int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, int P, bool first, bool final, int train,
               const void* const* refs, const void* other, const LayerF& L, LayerB& K, const void* const* douts, const void* out_final,
               const float* dprobs, int64_t ldp, void* const* dx, void* d_other, Jobs& jobs) {
-  const Ctx &c0 = cs[0], &c1 = cs[1], &c2 = cs[2], &c3 = cs[3];
   const int B = d.B, T = d.T, nc = d.nc, hid = d.hid, n = d.n;
   const int64_t TEe = (int64_t)d.Lq * E, SEe = (int64_t)d.Lk * E, TEn = (int64_t)T * E, BEn = (int64_t)B * E;
   const d2r_linear_params* lp = p.lin;
-  const bool serial_tails = first;  // layer 0: the tails run on stream 0 after the join, in the order of the single-stream schedule
-  const bool multi = c1.st != c0.st;
-  // --- K8 backward -------------------------------------------------------------------------------------------- stream 0
+  Group grp;
+  // --- K8 backward ------------------------------------------------------------------------------------------------------------------
   {
-    const Ctx& c = c0;
     const void* embs[6] = {refs[0], L.e1, L.e2, L.e3, L.e4, L.e5};
     void* dembs[6];
     void* drefs[6];
@@ -478,11 +476,8 @@ int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
                                 dembs, final ? drefs : nullptr, K.dgates, K.agg_ws, K.agg_bytes, c.st));
     if (final) TRY(d2r_axpby(c.dt, 1.f, K.de[0], 1.f, dx[0], TEn, c.st));  // x0 is ref_0: relu path + skip path
   }
-  TRY(fork(c0, c1));
-  TRY(fork(c0, c2));
-  // --- routers ---------------------------------------------------------------------------------------------------- stream 1
+  // --- routers ------------------------------------------------------------------------------------------------------------------------
   {
-    const Ctx& c = c1;
     TRY(d2r_act_bwd(D2R_F32, D2R_ACT_TANH_RELU, K.dgates, L.gates, K.dG, (int64_t)B * nc * P, c.st));
     G gx(D2R_F32, D2R_F32, D2R_GEMM_NN, B, hid, P, K.dG, (int64_t)nc * P, lp[D2R_RL_R2].w, hid, K.dh, (int64_t)nc * hid);
     gx.batch(nc, P, (int64_t)P * hid, hid);
@@ -512,42 +507,12 @@ int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
       TRY(d2r_meanpool_bwd_multi(c.dt, K.dpooled, nc, B, d.Lq, E, dx, final ? 0xffu : 1u, c.st));  // (one launch for the nc inputs)
     }
   }
-  void* ev_routers = nullptr;  // recorded HERE (not behind IMRC, which follows on the same stream); stream 2 waits for it in front of its tails
-  if (multi) TRY(d2r_event_record(c1.st, &ev_routers));
-  // from here on (in stream 1's order) every dx[j] is initialised: the cells ACCUMULATE into it (GEMM epilogues, beta = 1)
-  // --- IMRC ------------------------------------------------------------------------------------------------------- stream 1
-  auto imrc_tail = [&](const Ctx& c) -> int {
-    TRY(dxg(c, T, E, 3 * E, K.i_dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
-    return D2R_OK;
-  };
-  if (nc > 2) {
-    const Ctx& c = c1;
-    const void* x = refs[2];
-    const int dh = E / d.heads;
-    const char* qkv = (const char*)L.qkv;
-    char* dqkv = (char*)K.i_dqkv;
-    const int64_t E3 = 3 * E, sb3 = (int64_t)d.Lq * 3 * E;
-    TRY(dxg(c, T, d.hidi, E, K.de[2], E, lp[D2R_RL_IMRC_FC2].w, K.i_df1, d.hidi, 0.f, nullptr, L.f1, D2R_ACT_RELU));  // d f1_pre
-    defer(jobs, T, E, d.hidi, K.de[2], E, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2]);
-    TRY(dxg(c, T, E, d.hidi, K.i_df1, d.hidi, lp[D2R_RL_IMRC_FC1].w, K.i_dy, E, 0.f, K.de[2]));  // + skip y -> e2
-    defer(jobs, T, d.hidi, E, K.i_df1, d.hidi, L.y, E, lp[D2R_RL_IMRC_FC1]);
-    TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, K.i_dsum, dqkv, E3, sb3,
-                    dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
-    if (!serial_tails) TRY(imrc_tail(c));
-    defer(jobs, T, 3 * E, E, dqkv, 3 * E, x, E, lp[D2R_RL_IMRC_QKV]);  // (with the other layers' q|k|v gradients: one grouped launch per module)
-  }
-  // ===== part 1: every cell down to the gradient of its alignment core's output (d c) =================================================
-  // --- GLAC: gate, then (stream 3) the local branch, then the global branch --------------------------------------- stream 2
-  auto glac_tail = [&](const Ctx& c) -> int {
-    TRY(dxg(c, B, E, E, K.g_dptp, E, lp[D2R_RL_GLAC_TPOOL].w, dx[1], TEe, 1.f));  // token 0 of every sample
-    return D2R_OK;
-  };
+  // from here on every dx[j] is initialised: the cells ACCUMULATE into it (GEMM epilogues, beta = 1)
+  // --- GLAC: the SAF gate's backward (per-sample chain), which yields the gradients of the global and the local score -------------------
+  const int64_t ldsg = (int64_t)n * E;
   if (nc > 1) {
-    const Ctx& c = c2;
-    const void* x = refs[1];
     TRY(d2r_l2norm_bwd(c.dt, K.de[1], L.g_wsum, L.g_ne1, K.g_dwsum, B, E, c.st));
-    // d w[b] = d wsum[b] S[b]^T (fp32), the gate's backward, then d S[b] = w[b]^T d wsum[b] + d a w_saf in ONE pass (rank-one products:
-    // as GEMMs on the tiled kernel they took 19 + 32-47 + 9 us per layer, and two casts)
+    // d w[b] = d wsum[b] S[b]^T (fp32), the gate's backward, then d S[b] = w[b]^T d wsum[b] + d a w_saf in ONE pass (rank-one products)
     TRY(d2r_saf_dweights(c.dt, K.g_dwsum, L.g_S, B, n, E, K.g_dwf, c.st));
     TRY(d2r_saf_gate_bwd(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, K.bn2, K.bn2 + 1, c.st));
     TRY(acc32(c, K.bn2, p.g_bn_weight, 1));
@@ -558,18 +523,107 @@ int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
     // split dS: row 0 of every sample = d sg (used in place, row stride n*E), rows 1.. = d sl (made contiguous)
     const size_t row = (size_t)E * d.es;
     TRY(copy2d(K.g_dsl, (size_t)d.Lq * row, (char*)K.g_dS + row, (size_t)n * row, (size_t)d.Lq * row, B, c.st));
-    const int64_t ldsg = (int64_t)n * E;
-    TRY(fork(c2, c3));
-    {  // local path --------------------------------------------------------------------------------------------------- stream 3
-      const Ctx& c = c3;
-      TRY(dxg(c, T, E, E, K.g_dsl, E, lp[D2R_RL_GLAC_FC1].w, K.g_dl2, E));
-      defer(jobs, T, E, E, K.g_dsl, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1]);
-      TRY(d2r_l2norm_bwd(c.dt, K.g_dl2, L.g_loc, L.g_nloc, K.g_dloc, T, E, c.st));
-      TRY(dxg(c, T, E, E, K.g_dloc, E, lp[D2R_RL_GLAC_LOC].w, K.g_dsq, E));
-      defer(jobs, T, E, E, K.g_dloc, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC]);
-      TRY(d2r_sqdiff_bwd(c.dt, x, L.g_c, K.g_dsq, K.g_da, K.g_dc, TEn, c.st));
-    }
-    // global path
+  }
+  // --- CRCMC: backward of its second core (d e4 -> d a, d b, d Ks as its value) ---------------------------------------------------------
+  if (nc > 4)
+    TRY(xat_bwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, K.de[4], L.e4, L.r_Qs, L.r_lse2, K.r_da, K.r_db, E, K.r_dKv, E, K.r_P2, K.r_dS2, 1.0f));
+  // --- group B1: the last linear of every cell, backwards ---------------------------------------------------------------------------------
+  if (nc > 2) {
+    grp.dxg(c, T, d.hidi, E, K.de[2], E, lp[D2R_RL_IMRC_FC2].w, K.i_df1, d.hidi, 0.f, nullptr, L.f1, D2R_ACT_RELU);  // d f1_pre
+    defer(jobs, T, E, d.hidi, K.de[2], E, L.f1, d.hidi, lp[D2R_RL_IMRC_FC2]);
+  }
+  if (nc > 1) {
+    grp.dxg(c, T, E, E, K.g_dsl, E, lp[D2R_RL_GLAC_FC1].w, K.g_dl2, E);
+    defer(jobs, T, E, E, K.g_dsl, E, L.g_l2, E, lp[D2R_RL_GLAC_FC1]);
+  }
+  if (nc > 3) {
+    grp.dxg(c, T, E, E, K.de[3], E, lp[D2R_RL_CMRC_FC2].w, K.c_dfp, E, 0.f, nullptr, L.c_f, D2R_ACT_RELU);
+    defer(jobs, T, E, E, K.de[3], E, L.c_f, E, lp[D2R_RL_CMRC_FC2]);
+  }
+  if (nc > 4) {
+    grp.dxg(c, T, E, E, K.r_da, E, lp[D2R_RL_CRCMC_FC1].w, K.r_dQs, E, 0.f, K.de[4]);  // + residual Qs -> e4
+    defer(jobs, T, E, E, K.r_da, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1]);
+    grp.dxg(c, T, E, E, K.r_db, E, lp[D2R_RL_CRCMC_FC2].w, K.r_dKs, E, 0.f, K.r_dKv);  // + Ks as the attention's value
+    defer(jobs, T, E, E, K.r_db, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2]);
+  }
+  TRY(grp.flush(c));
+  if (nc > 1) TRY(d2r_l2norm_bwd(c.dt, K.g_dl2, L.g_loc, L.g_nloc, K.g_dloc, T, E, c.st));
+  if (nc > 4) {
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dQs, L.r_Qs, K.r_dQsp, TEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dKs, L.r_Ks, K.r_dKsp, TEn, c.st));
+  }
+  // --- group B2: the first linears, backwards ------------------------------------------------------------------------------------------------
+  if (nc > 2) {
+    grp.dxg(c, T, E, d.hidi, K.i_df1, d.hidi, lp[D2R_RL_IMRC_FC1].w, K.i_dy, E, 0.f, K.de[2]);  // + skip y -> e2
+    defer(jobs, T, d.hidi, E, K.i_df1, d.hidi, L.y, E, lp[D2R_RL_IMRC_FC1]);
+  }
+  if (nc > 1) {
+    grp.dxg(c, T, E, E, K.g_dloc, E, lp[D2R_RL_GLAC_LOC].w, K.g_dsq, E);
+    defer(jobs, T, E, E, K.g_dloc, E, L.g_sq, E, lp[D2R_RL_GLAC_LOC]);
+  }
+  if (nc > 3) {
+    grp.dxg(c, T, E, E, K.c_dfp, E, lp[D2R_RL_CMRC_FC1].w, K.c_dmod, E);
+    defer(jobs, T, E, E, K.c_dfp, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1]);
+  }
+  if (nc > 4) {
+    grp.dxg(c, T, E, E, K.r_dQsp, E, lp[D2R_RL_CRCMC_MLP1].w, K.r_dc, E);
+    defer(jobs, T, E, E, K.r_dQsp, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1]);
+  }
+  TRY(grp.flush(c));
+  // --- IMRC's attention backward; the element-wise steps of GLAC and CMRC --------------------------------------------------------------------
+  if (nc > 2) {
+    const int dh = E / d.heads;
+    const char* qkv = (const char*)L.qkv;
+    char* dqkv = (char*)K.i_dqkv;
+    const int64_t E3 = 3 * E, sb3 = (int64_t)d.Lq * 3 * E;
+    TRY(d2r_mha_bwd(c.dt, qkv, E3, sb3, qkv + E * d.es, E3, sb3, qkv + 2 * E * d.es, E3, sb3, K.i_dy, E, TEe, nullptr, L.lse_i, K.i_dsum, dqkv, E3, sb3,
+                    dqkv + E * d.es, E3, sb3, dqkv + 2 * E * d.es, E3, sb3, B, d.heads, d.Lq, d.Lq, dh, 1.0f / sqrtf((float)dh), 0.f, 0, c.st));
+    defer(jobs, T, 3 * E, E, dqkv, 3 * E, refs[2], E, lp[D2R_RL_IMRC_QKV]);  // (with the other layers' q|k|v gradients: one grouped launch per module)
+  }
+  if (nc > 1) TRY(d2r_sqdiff_bwd(c.dt, refs[1], L.g_c, K.g_dsq, K.g_da, K.g_dc, TEn, c.st));
+  if (nc > 3) {
+    TRY(d2r_muladd_bwd(c.dt, refs[3], L.c_s, K.c_dmod, K.c_da, K.c_ds, TEn, c.st));
+    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.c_ds, L.c_s, K.c_dsp, TEn, c.st));
+  }
+  // --- group B3: CMRC's d c through fc_scale (fc_shift accumulates into it next), and - where the dx[j] are separate buffers - the tails
+  //     that need nothing further: IMRC's q|k|v (+ skip x -> y) and CRCMC's second input branch ---------------------------------------------
+  if (nc > 3) {
+    grp.dxg(c, T, E, E, K.c_dsp, E, lp[D2R_RL_CMRC_SCALE].w, K.c_dc, E);
+    defer(jobs, T, E, E, K.c_dsp, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE]);
+  }
+  if (!first) {
+    if (nc > 2) grp.dxg(c, T, E, 3 * E, K.i_dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy);
+    if (nc > 4) grp.dxg(c, T, E, E, K.r_dKsp, E, lp[D2R_RL_CRCMC_MLP2].w, dx[4], E, 1.f);
+  }
+  TRY(grp.flush(c));
+  if (nc > 4) defer(jobs, T, E, E, K.r_dKsp, E, refs[4], E, lp[D2R_RL_CRCMC_MLP2]);
+  if (nc > 3) {
+    TRY(dxg(c, T, E, E, K.c_dmod, E, lp[D2R_RL_CMRC_SHIFT].w, K.c_dc, E, 1.f));
+    defer(jobs, T, E, E, K.c_dmod, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT]);
+  }
+  // --- ONE backward launch for the alignment cores: dS, P, dQ; then dV / dK of every sample and core (one grouped launch) straight
+  //     into the column blocks of the module-wide k|v gradient -------------------------------------------------------------------------------
+  {
+    const void *qa[3], *ka[3], *va[3], *ga[3], *oa[3];
+    const float* la[3];
+    void *dqa[3], *dka[3], *dva[3], *pa[3], *dsa[3];
+    int ncore = 0;
+    auto core = [&](const void* q, const void* kv, const void* o, const void* dO, const float* lse, void* dq, void* dkv, void* Pm, void* dS) {
+      qa[ncore] = q, ka[ncore] = kv, va[ncore] = (const char*)kv + E * d.es, ga[ncore] = dO, la[ncore] = lse, oa[ncore] = o;
+      dqa[ncore] = dq, dka[ncore] = dkv, dva[ncore] = (char*)dkv + E * d.es, pa[ncore] = Pm, dsa[ncore] = dS;
+      ++ncore;
+    };
+    if (nc > 1) core(L.g_q, L.g_kv, L.g_c, K.g_dc, L.g_lse, K.g_dq, K.g_dkv, K.g_P, K.g_dSa);
+    if (nc > 3) core(L.c_q, L.c_kv, L.c_c, K.c_dc, L.c_lse, K.c_dq, K.c_dkv, K.c_P, K.c_dSa);
+    if (nc > 4) core(L.r_q, L.r_kv, L.r_c, K.r_dc, L.r_lse, K.r_dq, K.r_dkv, K.r_P, K.r_dSa);
+    const int64_t skv = (int64_t)d.Lk * d.ldkv;
+    if (ncore)
+      TRY(d2r_xattn_bwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, skv, va, d.ldkv, skv, ga, E, TEe, oa, E, TEe, nullptr, E, TEe, nullptr, la, dqa, E, TEe, dka, d.ldkv, skv, dva,
+                              d.ldkv, skv, pa, dsa, d.lkp, B, d.Lq, d.Lk, E, XSCALE, c.st));
+  }
+  // --- the per-sample vector chains: GLAC's global branch, GESC (both accumulate into the cls rows of dx[1] / dx[5] and d_other) ----------
+  if (nc > 1) {
+    const void* x = refs[1];
     TRY(dxg(c, B, E, E, K.g_dS, ldsg, lp[D2R_RL_GLAC_FC2].w, K.g_dl2g, E));
     defer(jobs, B, E, E, K.g_dS, ldsg, L.g_l2g, E, lp[D2R_RL_GLAC_FC2]);
     TRY(d2r_l2norm_bwd(c.dt, K.g_dl2g, L.g_glo, L.g_nglo, K.g_dglo, B, E, c.st));
@@ -578,21 +632,12 @@ int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
     TRY(d2r_sqdiff_bwd(c.dt, L.g_pt, L.g_pi, K.g_ddg, K.g_dpt, K.g_dpi, BEn, c.st));
     TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.g_dpt, L.g_pt, K.g_dptp, BEn, c.st));
     TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.g_dpi, L.g_pi, K.g_dpip, BEn, c.st));
-    if (multi) TRY(d2r_stream_wait(c2.st, ev_routers));  // the routers' pooled gradient has initialised dx[1] (and dx[5], below)
-    if (!serial_tails) TRY(glac_tail(c));
+    TRY(dxg(c, B, E, E, K.g_dptp, E, lp[D2R_RL_GLAC_TPOOL].w, dx[1], TEe, 1.f));  // token 0 of every sample
     defer(jobs, B, E, E, K.g_dptp, E, x, TEe, lp[D2R_RL_GLAC_TPOOL]);
     TRY(dxg(c, B, E, E, K.g_dpip, E, lp[D2R_RL_GLAC_IPOOL].w, d_other, SEe, 1.f));
     defer(jobs, B, E, E, K.g_dpip, E, other, SEe, lp[D2R_RL_GLAC_IPOOL]);
-  } else if (multi) {
-    TRY(d2r_stream_wait(c2.st, ev_routers));
   }
-  // --- GESC ------------------------------------------------------------------------------------------------------- stream 2
-  auto gesc_tail = [&](const Ctx& c) -> int {
-    TRY(dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f));
-    return D2R_OK;
-  };
   if (nc > 5) {
-    const Ctx& c = c2;
     const void* x = refs[5];
     TRY(d2r_lerp_bwd(c.dt, L.s_g, L.s_a, L.s_b, K.de[5], K.s_dg, K.s_da1, K.s_db1, BEn, c.st));
     TRY(d2r_softmax_bwd(c.dt, c.dt, L.s_g, K.s_dg, K.s_dz, E, B, E, 1.0f, c.st));
@@ -604,90 +649,38 @@ int layer_bwd(const Ctx* cs, const Dims& d, const d2r_routing_layer_params& p, i
     TRY(d2r_add(c.dt, K.s_db1, K.s_dab, K.s_dbt, BEn, c.st));
     TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dat, L.s_a, K.s_dap, BEn, c.st));
     TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dbt, L.s_b, K.s_dbp, BEn, c.st));
-    if (!serial_tails) TRY(gesc_tail(c));
+    TRY(dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f));
     defer(jobs, B, E, E, K.s_dap, E, x, TEe, lp[D2R_RL_GESC_TPOOL]);
     TRY(dxg(c, B, E, E, K.s_dbp, E, lp[D2R_RL_GESC_IPOOL].w, d_other, SEe, 1.f));
     defer(jobs, B, E, E, K.s_dbp, E, other, SEe, lp[D2R_RL_GESC_IPOOL]);
   }
-  // --- CMRC ------------------------------------------------------------------------------------------------------- stream 0
-  if (nc > 3) {
-    const Ctx& c = c0;
-    TRY(dxg(c, T, E, E, K.de[3], E, lp[D2R_RL_CMRC_FC2].w, K.c_dfp, E, 0.f, nullptr, L.c_f, D2R_ACT_RELU));
-    defer(jobs, T, E, E, K.de[3], E, L.c_f, E, lp[D2R_RL_CMRC_FC2]);
-    TRY(dxg(c, T, E, E, K.c_dfp, E, lp[D2R_RL_CMRC_FC1].w, K.c_dmod, E));
-    defer(jobs, T, E, E, K.c_dfp, E, L.c_mod, E, lp[D2R_RL_CMRC_FC1]);
-    TRY(d2r_muladd_bwd(c.dt, refs[3], L.c_s, K.c_dmod, K.c_da, K.c_ds, TEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.c_ds, L.c_s, K.c_dsp, TEn, c.st));
-    TRY(dxg(c, T, E, E, K.c_dsp, E, lp[D2R_RL_CMRC_SCALE].w, K.c_dc, E));
-    defer(jobs, T, E, E, K.c_dsp, E, L.c_c, E, lp[D2R_RL_CMRC_SCALE]);
-    TRY(dxg(c, T, E, E, K.c_dmod, E, lp[D2R_RL_CMRC_SHIFT].w, K.c_dc, E, 1.f));
-    defer(jobs, T, E, E, K.c_dmod, E, L.c_c, E, lp[D2R_RL_CMRC_SHIFT]);
-  }
-  // --- CRCMC ------------------------------------------------------------------------------------------------------ stream 0
-  if (nc > 4) {
-    const Ctx& c = c0;
-    TRY(xat_bwd(c, d, L.r_a, L.r_b, E, L.r_Ks, E, d.Lq, K.de[4], L.e4, L.r_Qs, L.r_lse2, K.r_da, K.r_db, E, K.r_dKv, E, K.r_P2, K.r_dS2, 1.0f));
-    TRY(dxg(c, T, E, E, K.r_da, E, lp[D2R_RL_CRCMC_FC1].w, K.r_dQs, E, 0.f, K.de[4]));  // + residual Qs -> e4
-    defer(jobs, T, E, E, K.r_da, E, L.r_Qs, E, lp[D2R_RL_CRCMC_FC1]);
-    TRY(dxg(c, T, E, E, K.r_db, E, lp[D2R_RL_CRCMC_FC2].w, K.r_dKs, E, 0.f, K.r_dKv));  // + Ks as the attention's value
-    defer(jobs, T, E, E, K.r_db, E, L.r_Ks, E, lp[D2R_RL_CRCMC_FC2]);
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dQs, L.r_Qs, K.r_dQsp, TEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dKs, L.r_Ks, K.r_dKsp, TEn, c.st));
-    TRY(dxg(c, T, E, E, K.r_dQsp, E, lp[D2R_RL_CRCMC_MLP1].w, K.r_dc, E));
-    defer(jobs, T, E, E, K.r_dQsp, E, L.r_c, E, lp[D2R_RL_CRCMC_MLP1]);
-  }
-  TRY(fork(c3, c0));  // GLAC's d c (and d(sqdiff)/dx for part 2)
-  // ===== ONE backward launch for the alignment cores: dS, P, dQ; then dV / dK of every sample and core (one grouped launch)
-  //       straight into the column blocks of the module-wide k|v gradient ====================================== stream 0
-  {
-    const Ctx& c = c0;
-    const void *qa[3], *ka[3], *va[3], *ga[3], *oa[3];
-    const float* la[3];
-    void *dqa[3], *dka[3], *dva[3], *pa[3], *dsa[3];
-    int ncore = 0;
-    auto core = [&](const void* q, const void* kv, const void* o, const void* dO, const float* lse, void* dq, void* dkv, void* P, void* dS) {
-      qa[ncore] = q, ka[ncore] = kv, va[ncore] = (const char*)kv + E * d.es, ga[ncore] = dO, la[ncore] = lse, oa[ncore] = o;
-      dqa[ncore] = dq, dka[ncore] = dkv, dva[ncore] = (char*)dkv + E * d.es, pa[ncore] = P, dsa[ncore] = dS;
-      ++ncore;
-    };
-    if (nc > 1) core(L.g_q, L.g_kv, L.g_c, K.g_dc, L.g_lse, K.g_dq, K.g_dkv, K.g_P, K.g_dSa);
-    if (nc > 3) core(L.c_q, L.c_kv, L.c_c, K.c_dc, L.c_lse, K.c_dq, K.c_dkv, K.c_P, K.c_dSa);
-    if (nc > 4) core(L.r_q, L.r_kv, L.r_c, K.r_dc, L.r_lse, K.r_dq, K.r_dkv, K.r_P, K.r_dSa);
-    const int64_t skv = (int64_t)d.Lk * d.ldkv;
-    if (ncore)
-      TRY(d2r_xattn_bwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, skv, va, d.ldkv, skv, ga, E, TEe, oa, E, TEe, nullptr, E, TEe, nullptr, la, dqa, E, TEe, dka, d.ldkv, skv, dva,
-                              d.ldkv, skv, pa, dsa, d.lkp, B, d.Lq, d.Lk, E, XSCALE, c.st));
-  }
-  TRY(fork(c1, c0));  // join: routers (dx[j] initialised), IMRC
-  TRY(fork(c2, c0));  //       GLAC's cls-row gradient is in dx[1] before the query-side product accumulates into it; GESC
-  if (serial_tails && nc > 1) TRY(glac_tail(c0));
-  // ===== part 2: the query-side projections (the key / value side of every cell and layer is one product at the end of the module) ===
+  // --- the query-side projections (the key / value side of every cell and layer is one product at the end of the module): group B4 where
+  //     the dx[j] are separate buffers, one after the other in layer 0 -------------------------------------------------------------------------
+  if (nc > 3) TRY(d2r_add(c.dt, K.c_da, K.de[3], K.c_tmp, TEn, c.st));  // FiLM path + skip x -> e3
+  Group tails;
+  Group& tg = first ? tails : grp;
+  auto step = [&]() -> int { return first ? tails.flush(c) : D2R_OK; };  // layer 0: every product alone, in this order
   if (nc > 1) {
-    TRY(dxg(c0, T, E, E, K.g_dq, E, lp[D2R_RL_GLAC_Q].w, dx[1], E, 1.f, K.g_da));  // += dq Wq + d(sqdiff)/dx
+    tg.dxg(c, T, E, E, K.g_dq, E, lp[D2R_RL_GLAC_Q].w, dx[1], E, 1.f, K.g_da);  // += dq Wq + d(sqdiff)/dx
     defer(jobs, T, E, E, K.g_dq, E, refs[1], E, lp[D2R_RL_GLAC_Q]);
+    TRY(step());
   }
   if (nc > 3) {
-    TRY(d2r_add(c0.dt, K.c_da, K.de[3], K.c_tmp, TEn, c0.st));  // FiLM path + skip x -> e3
-    TRY(dxg(c0, T, E, E, K.c_dq, E, lp[D2R_RL_CMRC_Q].w, dx[3], E, 1.f, K.c_tmp));
+    tg.dxg(c, T, E, E, K.c_dq, E, lp[D2R_RL_CMRC_Q].w, dx[3], E, 1.f, K.c_tmp);
     defer(jobs, T, E, E, K.c_dq, E, refs[3], E, lp[D2R_RL_CMRC_Q]);
+    TRY(step());
   }
   if (nc > 4) {
-    const void* x = refs[4];
-    TRY(dxg(c0, T, E, E, K.r_dq, E, lp[D2R_RL_CRCMC_Q].w, dx[4], E, 1.f));
-    defer(jobs, T, E, E, K.r_dq, E, x, E, lp[D2R_RL_CRCMC_Q]);
-    TRY(dxg(c0, T, E, E, K.r_dKsp, E, lp[D2R_RL_CRCMC_MLP2].w, dx[4], E, 1.f));
-    defer(jobs, T, E, E, K.r_dKsp, E, x, E, lp[D2R_RL_CRCMC_MLP2]);
+    tg.dxg(c, T, E, E, K.r_dq, E, lp[D2R_RL_CRCMC_Q].w, dx[4], E, 1.f);
+    defer(jobs, T, E, E, K.r_dq, E, refs[4], E, lp[D2R_RL_CRCMC_Q]);
+    TRY(step());
   }
-  if (serial_tails && nc > 2) TRY(imrc_tail(c0));
-  if (serial_tails && nc > 5) TRY(gesc_tail(c0));
+  TRY(grp.flush(c));
+  if (first) {
+    if (nc > 4) TRY(dxg(c, T, E, E, K.r_dKsp, E, lp[D2R_RL_CRCMC_MLP2].w, dx[4], E, 1.f));
+    if (nc > 2) TRY(dxg(c, T, E, 3 * E, K.i_dqkv, 3 * E, lp[D2R_RL_IMRC_QKV].w, dx[2], E, 1.f, K.i_dy));  // += dqkv Wqkv + skip x -> y
+  }
   return D2R_OK;
-}
-
-// cs[0]: the call's stream; cs[1..3]: the auxiliary streams with their own split-K scratch, or copies of cs[0]
-void make_ctx(const d2r_interaction_desc* D, void* stream, Ctx* cs) {
-  cs[0] = Ctx{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
-  for (int i = 1; i < 4; ++i)
-    cs[i] = D->n_aux == 3 ? Ctx{D->dtype, D->aux_stream[i - 1], D->aux_ws[i - 1], D->aux_ws_bytes} : cs[0];
 }
 
 int check(const d2r_interaction_desc* D, const char* fn, bool bwd, void* stream) {
@@ -697,12 +690,6 @@ int check(const d2r_interaction_desc* D, const char* fn, bool bwd, void* stream)
   D2R_REQUIRE(d2r_interaction_supported(D->dtype, D->Lq, D->Lk, D->ncell, D->heads_imrc),
               "%s: unsupported (bf16, 2..6 cells, token counts within the fused attention cores' limits)", fn);
   D2R_REQUIRE(D->layers && D->own && D->other && D->out && D->paths && D->arena && d2r_aligned16(D->arena), "%s: null / unaligned pointer", fn);
-  D2R_REQUIRE(D->n_aux == 0 || D->n_aux == 3, "%s: n_aux must be 0 or 3", fn);
-  if (D->n_aux == 3)
-    for (int i = 0; i < 3; ++i)
-      D2R_REQUIRE(D->aux_stream[i] && D->aux_stream[i] != stream && D->aux_stream[i] != D->aux_stream[(i + 1) % 3] && D->aux_ws[i] && D->aux_ws[i] != D->splitk_ws &&
-                      D->aux_ws[i] != D->aux_ws[(i + 1) % 3] && D->aux_ws_bytes >= ((size_t)1 << 20),
-                  "%s: three distinct auxiliary streams, each with its own split-K scratch (>= 1 MiB), are required with n_aux = 3", fn);
   D2R_REQUIRE(D->kv_all.w && D->kv_all.b && (!bwd || (D->kv_all.gw && D->kv_all.gb)), "%s: kv_all (the fused k|v projections of `other`) missing", fn);
   D2R_REQUIRE(D->arena_bytes >= d2r_interaction_arena_bytes(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc),
               "%s: arena too small", fn);
@@ -746,9 +733,7 @@ extern "C" size_t d2r_interaction_bwd_scratch(int B, int Lq, int Lk, int ncell, 
 extern "C" int d2r_interaction_fwd(const d2r_interaction_desc* D, void* stream) {
   TRY(check(D, "d2r_interaction_fwd", false, stream));
   const Dims d = make_dims(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc, D->heads_imrc);
-  Ctx cs[4];
-  make_ctx(D, stream, cs);
-  const Ctx& c = cs[0];
+  const Ctx c{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
   Arena A(D->arena);
   const int nc = d.nc, total = nc * nc * (d.nl - 1) + nc;
   // keys | values of every alignment cell of every layer: `other` is the same tensor in all of them
@@ -762,7 +747,7 @@ extern "C" int d2r_interaction_fwd(const d2r_interaction_desc* D, void* stream) 
     const bool first = l == 0, final = l == d.nl - 1;
     const int P = final ? 1 : nc;
     plan_fwd(A, d, P, first, final, L, kvall, l);
-    TRY(layer_fwd(cs, d, D->layers[l], P, first, final, D->train, refs, D->other, L, D->out, D->paths + (size_t)l * nc * nc, total));
+    TRY(layer_fwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, L, D->out, D->paths + (size_t)l * nc * nc, total));
     for (int j = 0; j < nc && !final; ++j) refs[j] = L.outs[j];
   }
   return D2R_OK;
@@ -771,9 +756,7 @@ extern "C" int d2r_interaction_fwd(const d2r_interaction_desc* D, void* stream) 
 extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) {
   TRY(check(D, "d2r_interaction_bwd", true, stream));
   const Dims d = make_dims(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc, D->heads_imrc);
-  Ctx cs[4];
-  make_ctx(D, stream, cs);
-  const Ctx& c = cs[0];
+  const Ctx c{D->dtype, stream, D->splitk_ws, D->splitk_bytes};
   const int nc = d.nc, nl = d.nl, total = nc * nc * (nl - 1) + nc;
   const size_t TE = (size_t)d.T * E * d.es;
   std::vector<LayerF> F(nl);
@@ -800,7 +783,7 @@ extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) 
       douts[j] = final ? (j == 0 ? (D->d_out ? D->d_out : zero_out) : nullptr) : K[l + 1].dx[j];
     }
     const float* dprobs = D->d_paths ? D->d_paths + (size_t)l * nc * nc : nullptr;
-    TRY(layer_bwd(cs, d, D->layers[l], P, first, final, D->train, refs, D->other, F[l], K[l], douts, D->out, dprobs, total, dx, D->d_other, jobs));
+    TRY(layer_bwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, F[l], K[l], douts, D->out, dprobs, total, dx, D->d_other, jobs));
   }
   if (d.nkv) {
     // every cell and layer wrote its dK | dV block: the gradient w.r.t. `other` through ALL key / value projections is one product

@@ -22,6 +22,7 @@ by bucket.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List, Optional
 
@@ -112,6 +113,10 @@ class FlatGradReducer:
                         if comm_dtype != torch.float32 else None)
         self._unstage = []
         self._native_rs = None
+        # Rehearsal aid (tests/test_dp_gloo.py): gloo has no reduce-scatter and all-reduces the bucket instead, which leaves the full
+        # sum in every stripe - a reader of a stripe this rank does NOT own (stale under RCCL's reduce-scatter) would go unnoticed.
+        # With poison_stale the non-owned stripes of mode "reduce_scatter" are overwritten with NaN after the reduction.
+        self.poison_stale = False
 
     def _has_reduce_scatter(self) -> bool:
         if self._native_rs is None:
@@ -178,6 +183,12 @@ class FlatGradReducer:
                 view.copy_(buf)
         self.handles.clear()
         self._unstage.clear()
+        if self.poison_stale and self.mode == "reduce_scatter" and not self._has_reduce_scatter():
+            ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else contextlib.nullcontext()
+            with ctx:
+                for (oa, ob), (ba, bb), _ in self.stripes:
+                    self.flat_g[ba:oa] = float("nan")
+                    self.flat_g[ob:bb] = float("nan")
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
@@ -192,28 +203,32 @@ class FlatGradReducer:
 class DataParallel:
     def __init__(self, store: ParamStore, optimizer, model: torch.nn.Module, bucket_mb: int = 128, group=None,
                  overlap: bool = False, bucket_elems: Optional[int] = None, grad_comm_dtype: torch.dtype = torch.float32,
-                 shard_optimizer: bool = False, algorithm: str = "all_reduce"):
+                 shard_optimizer: bool = False, algorithm: str = "all_reduce", single_rank_collectives: bool = False):
         """grad_comm_dtype: torch.bfloat16 sends the gradient buckets as bf16 (see FlatGradReducer).
         algorithm: "all_reduce" or "reduce_scatter_all_gather" (module docstring).
         shard_optimizer: reduce-scatter of every bucket + AdamW on this rank's stripes + all-gather of the updated weights
-        (same bytes on the links as the all-reduce); works with overlap: a bucket's scatter goes out when the bucket is complete."""
+        (same bytes on the links as the all-reduce); works with overlap: a bucket's scatter goes out when the bucket is complete.
+        single_rank_collectives: with an initialised process group of ONE rank, issue every collective anyway (a one-GPU box
+        executes the RCCL code path - in-place reduce_scatter_tensor, all_gather_into_tensor, the communication stream's ordering -
+        with results that must equal the plain step bit for bit: tests/test_gpu_trainer.py).  Off: world size 1 is a no-op."""
         self.store, self.opt, self.model, self.group = store, optimizer, model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.active = self.world > 1 or (bool(single_rank_collectives) and dist.is_initialized())
         if algorithm not in ALGORITHMS:
             raise ValueError(f"algorithm must be one of {ALGORITHMS}, got {algorithm!r}")
-        self.shard_optimizer = bool(shard_optimizer) and self.world > 1
+        self.shard_optimizer = bool(shard_optimizer) and self.active
         self.algorithm = "reduce_scatter_all_gather" if self.shard_optimizer else algorithm
         mode = "reduce_scatter" if self.shard_optimizer else algorithm
         self.reducer = (FlatGradReducer(store.flat_g, bucket_elems or bucket_mb * (1 << 20) // 4, group, grad_comm_dtype, mode=mode)
-                        if self.world > 1 else None)
+                        if self.active else None)
         optimizer.grad_scale = 1.0 / self.world
         optimizer.dp_group = group
         if self.shard_optimizer:
             # this rank updates its stripe of every bucket, and every rank updates the (tiny) bucket tails
             optimizer.element_ranges = [r for own, _, tail in self.reducer.stripes for r in (own, tail) if r[1] > r[0]]
             optimizer.shard_gather = self.reducer.gather_stripes
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and self.active
         self._pending: List[int] = []
         self._bucket_of = {}
         if self.overlap:
@@ -221,7 +236,7 @@ class DataParallel:
 
     # -- start-up: identical replicas ---------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
-        if self.world == 1:
+        if not self.active:
             return
         dist.broadcast(self.store.flat_w, src=src, group=self.group)
         for _, p in self.store.dead:
@@ -234,7 +249,7 @@ class DataParallel:
         """BatchNorm running statistics are updated from each rank's LOCAL batch and drift apart after the initial
         broadcast (DDP would re-broadcast rank 0's every step); before evaluation / checkpointing they are replaced by
         their mean over ranks (integer buffers such as num_batches_tracked: rank 0's value)."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.model.buffers():
             if b.is_floating_point():
@@ -244,7 +259,7 @@ class DataParallel:
                 dist.broadcast(b, src=0, group=self.group)
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             dist.barrier(group=self.group)
 
     # -- readiness counting for overlap ---------------------------------------------------------------
@@ -366,7 +381,7 @@ class DataParallel:
 
     # -- per step -------------------------------------------------------------------------------------
     def reduce_gradients(self):
-        if self.world == 1:
+        if not self.active:
             return
         if self.overlap:
             if self._expect is None:

@@ -1047,34 +1047,6 @@ class InteractionBundle:
                 and bool(_lib.load().d2r_interaction_supported(_dt_of(self.tdtype), own.shape[1], other.shape[1], self.ncell, self.heads_imrc)))
 
 
-# Opt-in (measured): bit-identical, +10 % with ONE branch stream (D2R_STREAMS=0), -2 % beside the two
-# branch streams at the runtime's four hardware queues and -25 ... -43 % at five to seven (GPU_MAX_HW_QUEUES): a fork / join
-# between streams that sit on different hardware queues costs more than the chains it overlaps.
-CELL_STREAMS = os.environ.get("D2R_CELL_STREAMS", "0") != "0"
-_AUX = {}
-
-
-def _cell_streams(d, device):
-    """Fills the auxiliary-stream fields of a d2r_interaction_desc: three streams (and a split-K scratch each) per launching
-    stream, created once.  Inside the call the independent cells of a routing layer run on them, forked from and joined back
-    into the launching stream - nothing of it is visible to the caller (every buffer the call touches is allocated on the
-    launching stream, which has waited for all auxiliary work when the call returns)."""
-    if not CELL_STREAMS:
-        d.n_aux = 0
-        return None
-    key = (device.index, _stream())
-    aux = _AUX.get(key)
-    if aux is None:
-        streams = [torch.cuda.Stream(device=device) for _ in range(3)]
-        aux = _AUX[key] = (streams, [torch.empty(64 << 20, dtype=torch.uint8, device=device) for _ in range(3)])
-    d.n_aux = 3
-    for i in range(3):
-        d.aux_stream[i] = aux[0][i].cuda_stream
-        d.aux_ws[i] = aux[1][i].data_ptr()
-    d.aux_ws_bytes = aux[1][0].numel()
-    return aux
-
-
 class _Interaction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, own, other, anchor, bundle, train):
@@ -1095,7 +1067,6 @@ class _Interaction(torch.autograd.Function):
         ws = _workspace(64 << 20, own.device)
         d.own, d.other, d.out, d.paths = own.data_ptr(), other.data_ptr(), out.data_ptr(), paths.data_ptr()
         d.arena, d.arena_bytes, d.splitk_ws, d.splitk_bytes = arena.data_ptr(), arena.numel(), ws.data_ptr(), ws.numel()
-        _cell_streams(d, own.device)
         _lib.call("d2r_interaction_fwd", C.byref(d), _stream(), meta=dict(group="interaction_fwd"))
         ctx.save_for_backward(own, other, out)
         ctx.d, ctx.keep, ctx.bundle = d, arena, bundle
@@ -1126,7 +1097,6 @@ class _Interaction(torch.autograd.Function):
         d.splitk_ws, d.splitk_bytes = ws.data_ptr(), ws.numel()
         d.d_out, d.d_paths, d.d_own, d.d_other = _ptr(d_out), _ptr(d_paths), d_own.data_ptr(), d_other.data_ptr()
         d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
-        _cell_streams(d, own.device)  # (the backward may run on another launching stream than the forward did)
         _lib.call("d2r_interaction_bwd", C.byref(d), _stream(), meta=dict(group="interaction_bwd"))
         ctx.keep = None
         for p in bundle.params:  # data-parallel bucket readiness (d2r_amd.dp): every sink of the module is written now

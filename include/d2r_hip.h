@@ -100,6 +100,12 @@ typedef struct {
 } d2r_gemm_desc;
 
 int d2r_gemm(const d2r_gemm_desc* d, void* stream);
+/* `n` INDEPENDENT products enqueued together (no output of one is an operand or an output of another; the caller guarantees it).
+ * The 16-bit NT / NN products with at least 128 rows and columns leave as grouped launches of up to 16 problems on the 128 x 128
+ * LDS-DMA tiles - the chains of 768 x 768 linears of the routing cells (models/Cells.py:30-255, models/Refinement.py:133-154) are
+ * 192-300 tiles each, one partial round of workgroups; four to six of them together fill the chip - and every tile is computed
+ * exactly as by d2r_gemm: bit-identical results.  Everything else is launched by d2r_gemm, one by one, in the order given. */
+int d2r_gemm_group(const d2r_gemm_desc* descs, int n, void* stream);
 /* `count` weight-gradient GEMMs of ONE shape in launches of up to 16 problems:
  *   C_i[M,N] (fp32, ldc) = beta * C_i + A_i^T B_i,   A_i [K,M] (lda), B_i [K,N] (ldb) of dtype;   dbias_i[m] += sum_k A_i[k,m]
  * h_A / h_B / h_C / h_dbias are HOST arrays of device pointers (h_dbias may be NULL).  Replaces `count` d2r_gemm TN
@@ -477,14 +483,6 @@ typedef struct {
    * (`other` is the same tensor in every layer, models/DynamicInteraction.py:95-102): one GEMM with N = 13,824 at DR_step 3 in
    * the forward pass, one dX and one dW product in the backward pass.  The D2R_RL_*_KV entries of `layers` are then unused. */
   d2r_linear_params kv_all;
-  /* Optional cell-level concurrency (round 3).  The cells of a routing layer are independent between the layer's inputs and its
-   * aggregation (models/DynamicInteraction.py:41-48,95-102) and most of them are chains of launches that fill a fraction of the
-   * chip: with n_aux = 3 the calls issue them on `stream` and on these three auxiliary streams, forked from and joined back into
-   * `stream` by events (all auxiliary work is joined before the call returns, in stream order; results are bit-identical to
-   * n_aux = 0).  Each auxiliary stream needs its own split-K scratch of aux_ws_bytes. */
-  int n_aux;                 /* 0 or 3 */
-  void* aux_stream[3];
-  void* aux_ws[3]; size_t aux_ws_bytes;
 } d2r_interaction_desc;
 int d2r_interaction_supported(int dtype, int Lq, int Lk, int ncell, int heads_imrc);
 size_t d2r_interaction_arena_bytes(int B, int Lq, int Lk, int ncell, int nlayer, int hid_router, int hid_imrc);

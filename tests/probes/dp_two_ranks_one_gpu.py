@@ -1,4 +1,6 @@
-"""Two data-parallel ranks sharing cuda:0 over gloo (launched by tests/test_gpu_trainer.py through torch.distributed.run):
+"""Two data-parallel ranks sharing cuda:0 over gloo - or, with D2R_PROBE_BACKEND=nccl, ONE rank over RCCL with every collective
+issued anyway (DataParallel(single_rank_collectives=True): the only way a one-GPU box executes the RCCL code path) - launched by
+tests/test_gpu_trainer.py through torch.distributed.run:
 the whole DataParallel machinery on real kernels — broadcast, sharded batch, bucketed all-reduce with and without
 overlap (readiness callbacks from the kernels' gradient sinks, deferred grouped weight gradients, whole-layer C calls),
 fused AdamW with grad_scale = 1/world.  Writes the final weights of both modes; they must be bit-identical."""
@@ -10,8 +12,11 @@ import torch.distributed as dist
 
 out_dir = sys.argv[1]
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo")
+backend = os.environ.get("D2R_PROBE_BACKEND", "gloo")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 torch.cuda.set_device(0)
+dist.init_process_group(backend)
+assert world == (1 if backend == "nccl" else 2), (backend, world)
 from d2r_amd import modules as M
 from d2r_amd.config import TextConfig, VisionConfig, default_args
 from d2r_amd.dp import DataParallel, shard_batch
@@ -39,8 +44,12 @@ for overlap, kw in MODES.items():
     store = ParamStore(model, torch.bfloat16)
     opt = FusedAdamW(store, lr=1e-3)
     sched = LinearWarmupSchedule(opt, 0, 12)
-    dp = DataParallel(store, opt, model, bucket_mb=32, **kw)
-    assert dp.world == 2 and opt.grad_scale == 0.5
+    dp = DataParallel(store, opt, model, bucket_mb=32, single_rank_collectives=(world == 1), **kw)
+    assert dp.world == world and opt.grad_scale == 1.0 / world and dp.active
+    if backend == "gloo":
+        dp.reducer.poison_stale = True  # stripes this rank does not own: NaN after the (all-reduce standing in for the) reduce-scatter
+    else:
+        assert dp.reducer._has_reduce_scatter(), "the RCCL run must take reduce_scatter_tensor / all_gather_into_tensor"
     dp.broadcast_parameters()
     w_start = store.flat_w.detach().cpu().clone()  # (identical in every mode: same seeds, same broadcast)
     losses = []

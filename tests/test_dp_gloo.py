@@ -114,10 +114,18 @@ def _bf16_buckets_and_sharded_optimizer(rank, world):
     own = [(64 * rank, 64 * rank + 64), (128 + 64 * rank, 192 + 64 * rank), (256 + 20 * rank, 276 + 20 * rank)]
     assert opt.element_ranges == own + [(296, 303)], opt.element_ranges
     assert opt.grad_scale == 0.5 and opt.shard_gather is not None
+    # gloo all-reduces the bucket (no reduce-scatter): the stripes this rank does NOT own would hold the full sum, where RCCL's
+    # reduce-scatter leaves them stale.  The rehearsal poisons them with NaN, so that anything downstream that reads a non-owned
+    # stripe (a wrong stripe offset, an optimiser range that is too wide) shows up here instead of on the 8-GPU node.
+    dp.reducer.poison_stale = True
     store.flat_g += (rank + 1)
     dp.reduce_gradients()
-    for a, b in opt.element_ranges:  # summed where this rank will update (gloo leaves the other stripes summed too; RCCL leaves them stale)
+    for a, b in opt.element_ranges:  # summed where this rank will update
         assert torch.equal(store.flat_g[a:b], torch.full((b - a,), 3.0))
+    owned_mask = torch.zeros(303, dtype=torch.bool)
+    for a, b in opt.element_ranges:
+        owned_mask[a:b] = True
+    assert bool(torch.isnan(store.flat_g[~owned_mask]).all()) and int((~owned_mask).sum()) == 148, "non-owned stripes must be poisoned"
     owned = FusedAdamW._owned(opt, (100, 300))  # a parameter group's range against this rank's stripes and the tail
     assert owned == ([(128, 192), (256, 276), (296, 300)] if rank == 0 else [(100, 128), (192, 256), (276, 296), (296, 300)]), owned
     assert FusedAdamW._owned(opt, (0, 0)) == []
@@ -137,6 +145,7 @@ def _bf16_buckets_and_sharded_optimizer(rank, world):
 
     store, opt = Store96(), _FakeOpt()
     dp = DataParallel(store, opt, None, shard_optimizer=True, overlap=True, bucket_elems=96)
+    dp.reducer.poison_stale = True
     assert len(dp.reducer.bounds) == 3
     order = []
     launch = dp.reducer.launch_bucket

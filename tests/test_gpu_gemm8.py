@@ -181,3 +181,55 @@ def test_same_shape_groups_take_the_wide_kernel_and_match_the_128_wide_one(gpu):
         for code in (102, 103):
             assert float((out[code][0][i].double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
             assert float((out[code][1][i].double() - dys[i].double().sum(0)).abs().max()) <= 3e-5 * float(dys[i].double().sum(0).abs().max())
+
+
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("layout", [0, 1], ids=["NT", "NN"])
+def test_grouped_launch_of_independent_products_is_bit_identical_to_separate_launches(layout, lowp, gpu):
+    """d2r_gemm_group (gemm_glds.hip: independent forward / dX products of the routing cells in one launch of the 128 x 128 LDS-DMA
+    kernel) against one d2r_gemm per problem: every tile is computed exactly as in a launch of its own."""
+    from d2r_amd import _lib
+    from d2r_amd import functional as F
+    from d2r_amd._lib import GemmDesc
+    dt = _lib.BF16 if lowp == torch.bfloat16 else _lib.F16
+    g = torch.Generator(device=gpu).manual_seed(5 + layout)
+    # (M, N, K, bias, act, residual, beta, grad_ref act): the shapes of one routing layer (q|k|v, 768-wide linears), ragged rows,
+    # a small one that stays out of the group (M < 128), a deep reduction
+    specs = [(4096, 2304, 768, True, 0, False, 0.0, 0), (4096, 768, 768, True, 2, False, 0.0, 0), (4096, 768, 768, True, 1, True, 0.0, 0),
+             (6304, 768, 768, False, 0, False, 1.0, 0), (6304, 768, 768, True, 0, True, 1.0, 0), (300, 136, 128, True, 3, False, 0.0, 0),
+             (64, 768, 768, True, 0, False, 0.0, 0), (4096, 768, 3072, False, 0, False, 0.0, 1)]
+    ops = []
+    for M, N, K, hb, act, hr, beta, gact in specs:
+        a = (torch.randn(M, K, device=gpu, generator=g) * 0.5).to(lowp)
+        b = (torch.randn((N, K) if layout == 0 else (K, N), device=gpu, generator=g) * 0.5).to(lowp)
+        c0 = torch.randn(M, N, device=gpu, generator=g).to(lowp)
+        bias = torch.randn(N, device=gpu, generator=g) if hb else None
+        res = torch.randn(M, N, device=gpu, generator=g).to(lowp) if hr else None
+        gref = torch.randn(M, N, device=gpu, generator=g).to(lowp) if gact else None
+        ops.append((a, b, c0, bias, res, gref, act, beta, gact))
+
+    def descs(outs):
+        arr = (GemmDesc * len(ops))()
+        for d, (a, b, c0, bias, res, gref, act, beta, gact), c in zip(arr, ops, outs):
+            M, K = a.shape
+            N = c.shape[1]
+            d.dtype, d.c_dtype, d.layout, d.act, d.M, d.N, d.K, d.nb, d.nh, d.alpha, d.beta = dt, dt, layout, act, M, N, K, 1, 1, 1.0, beta
+            d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), K, b.data_ptr(), b.shape[1], c.data_ptr(), N
+            d.bias = None if bias is None else bias.data_ptr()
+            d.residual, d.ldr = (None, 0) if res is None else (res.data_ptr(), N)
+            d.grad_ref, d.grad_act = (None, 0) if gref is None else (gref.data_ptr(), gact)
+        return arr
+
+    one = [o[2].clone() for o in ops]
+    arr = descs(one)
+    for i in range(len(ops)):
+        _lib.call("d2r_gemm", C.byref(arr[i]), F._stream())
+    grp = [o[2].clone() for o in ops]
+    _lib.call("d2r_gemm_group", descs(grp), len(ops), F._stream())
+    torch.cuda.synchronize()
+    for i, (x, y) in enumerate(zip(one, grp)):
+        assert torch.equal(x, y), f"problem {i} {specs[i]}: grouped launch differs, max {float((x.float() - y.float()).abs().max()):.3e}"
+    # and both are right
+    a, b, c0, bias, res, gref, act, beta, gact = ops[1]
+    ref = torch.tanh(a.double() @ (b.double().t() if layout == 0 else b.double()) + bias.double())
+    assert float((grp[1].double() - ref).abs().max()) <= 2.5 * ULP[lowp] * float(ref.abs().max()) + 1e-6

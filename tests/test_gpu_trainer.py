@@ -323,3 +323,35 @@ def test_data_parallel_two_ranks_on_one_gpu(gpu, tmp_path):
         assert res["same_rs_ag"], "algorithm='reduce_scatter_all_gather' changed the result"
         # gradient buckets sent as bf16: a rounded sum, same direction of the three-step update
         assert res["cos_bf16"] >= 0.9 and all(l == l for l in res["losses_bf16"]), (res["cos_bf16"], res["losses_bf16"])
+
+
+def test_rccl_collectives_execute_on_one_rank(gpu, tmp_path):
+    """The RCCL code path on the one GPU of the box: a process group of ONE rank over backend "nccl" (= RCCL) with every collective
+    issued anyway (DataParallel(single_rank_collectives=True)) - bucketed all_reduce without and with overlap, the in-place
+    reduce_scatter_tensor (output stripe aliasing its position in the input) + all_gather_into_tensor of the two-phase algorithm, the
+    sharded optimiser (reduce-scatter, AdamW on the rank's stripes, all-gather of the weights) plain and overlapped on the
+    communication stream, bf16 buckets.  A sum over one rank is the identity: every mode must reproduce the plain step bit for bit
+    (bf16 buckets: the gradient rounded to bf16, same direction of the update).  The rank is a fresh process started before any GPU
+    call (RCCL initialisation, HSA_ENABLE_IPC_MODE_LEGACY=0)."""
+    import signal
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "probes", "dp_two_ranks_one_gpu.py"), str(tmp_path)]
+    proc = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                            env=dict(os.environ, D2R_PROBE_DUMP_S="150", D2R_PROBE_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    try:
+        out, err = proc.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        pytest.fail("the RCCL rank did not finish in 300 s: hang.\n--- stdout\n" + out[-3000:] + "\n--- stderr\n" + err[-6000:])
+    assert proc.returncode == 0, "single-rank RCCL probe failed\n--- stdout\n" + out[-3000:] + "\n--- stderr\n" + err[-6000:]
+    res = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    assert res["finite"] and all(l == l for l in res["losses"]), res
+    assert res["same_modes"], "overlapped RCCL all-reduce buckets changed the result: %s" % (res["bad"][:6],)
+    assert res["same_rs_ag"], "in-place reduce_scatter_tensor + all_gather_into_tensor (one rank) changed the result"
+    assert res["same_shard"] and res["same_shard_overlap"], "the sharded optimiser over RCCL (one rank) changed the result"
+    assert res["cos_bf16"] >= 0.9 and all(l == l for l in res["losses_bf16"]), (res["cos_bf16"], res["losses_bf16"])
