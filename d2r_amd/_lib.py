@@ -77,7 +77,7 @@ class HeadDesc(C.Structure):
                 ("lin_out", LinearParams), ("fc", LinearParams), ("x0", vp), ("x1", vp), ("labels", vp), ("js", vp),
                 ("loss", vp), ("logits", vp), ("pooled", vp), ("arena", vp), ("arena_bytes", sz), ("splitk_ws", vp),
                 ("splitk_bytes", sz), ("d_loss", vp), ("d_x0", vp), ("d_x1", vp), ("d_js", vp), ("scratch", vp),
-                ("scratch_bytes", sz)]
+                ("scratch_bytes", sz), ("d_logits", vp), ("d_pooled", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/d2r_hip.h declares

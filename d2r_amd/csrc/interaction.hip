@@ -918,8 +918,10 @@ extern "C" int d2r_head_bwd(const d2r_head_desc* D, void* stream) {
   head_plan_bwd(Z, h, g);
   TRY(d2r_axpby(D2R_F32, 1.f, D->d_loss, 0.f, D->d_js, 1, stream));  // loss = ce + js
   TRY(d2r_ce_bwd(D->logits, D->labels, h.B, h.classes, D->d_loss, g.dlogits, stream));
+  if (D->d_logits) TRY(d2r_axpby(D2R_F32, 1.f, D->d_logits, 1.f, g.dlogits, (int64_t)h.B * h.classes, stream));  // a second consumer of the logits
   TRY(dxg(c, h.B, h.E, h.classes, g.dlogits, h.classes, D->fc.w, g.dpooled, h.E));
   TRY(dwg(c, h.B, h.classes, h.E, g.dlogits, h.classes, D->pooled, h.E, D->fc));
+  if (D->d_pooled) TRY(d2r_axpby(D2R_F32, 1.f, D->d_pooled, 1.f, g.dpooled, (int64_t)h.B * h.E, stream));  // ... of Block's output
   TRY(dxg(c, h.B, h.mm, h.E, g.dpooled, h.E, D->lin_out.w, g.dz, h.mm));
   TRY(dwg(c, h.B, h.E, h.mm, g.dpooled, h.E, a.z, h.mm, D->lin_out));
   TRY(d2r_block_merge_bwd(D2R_F32, a.m0, a.m1, a.zraw, g.dz, h.B, h.chunks, h.rank, h.size, g.dm0, g.dm1, stream));

@@ -1159,16 +1159,17 @@ class _Head(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_logits, g_pooled):
         _ensure_backward_join()
-        if g_logits is not None or g_pooled is not None:
-            raise NotImplementedError("the one-call head differentiates the loss only; set D2R_COMPOSITE_HEAD=0 to backpropagate "
-                                      "through logits or the pooled output")
         x0, x1, labels, logits, pooled = ctx.saved_tensors
         d, bundle = ctx.d, ctx.bundle
         d_x0, d_x1 = torch.empty_like(x0), torch.empty_like(x1)
         d_js = torch.empty((), dtype=torch.float32, device=x0.device)
-        if g_loss is None:
+        if g_loss is None and g_logits is None and g_pooled is None:
             return d_x0.zero_(), d_x1.zero_(), d_js.zero_(), None, None, None
-        g_loss = g_loss.contiguous()
+        # gradients arriving at the logits / Block's output (a second loss on them) are added to the cross-entropy path inside the call
+        g_loss = torch.zeros((), dtype=torch.float32, device=x0.device) if g_loss is None else g_loss.contiguous().float()
+        g_logits = None if g_logits is None else g_logits.contiguous().float()
+        g_pooled = None if g_pooled is None else g_pooled.contiguous().float()
+        d.d_logits, d.d_pooled = _ptr(g_logits), _ptr(g_pooled)
         lib = _lib.load()
         scratch = torch.empty(lib.d2r_head_bwd_scratch(d.B, d.E, d.mm, d.chunks, d.rank, d.classes), dtype=torch.uint8, device=x0.device)
         ws = _workspace(64 << 20, x0.device)

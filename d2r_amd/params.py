@@ -220,6 +220,9 @@ class FusedAdamW:
     def zero_grad(self, set_to_none: bool = False):
         D = getattr(self, "_defer", None)
         if D is not None and D["pending"]:  # behind the update on its stream; "everything" is done when the buffer is clear
+            # (also behind whatever the launching stream and, through its join, the branch streams wrote since: a zero_grad() that
+            #  follows a backward pass without a step in between must not clear the buffer under those writes)
+            D["stream"].wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(D["stream"]):
                 self.store.zero_grad()
                 D["all"].record()

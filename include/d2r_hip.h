@@ -511,6 +511,9 @@ typedef struct {
   const float* d_loss;                  /* fp32 [1] */
   float* d_x0; float* d_x1; float* d_js;       /* [B, E], [B, E], [1]  OVERWRITTEN */
   void* scratch; size_t scratch_bytes;  /* >= d2r_head_bwd_scratch() */
+  /* backward, optional: gradients arriving at the OTHER outputs of the head (a second loss on the logits - distillation, label
+   * smoothing outside the model - or on Block's output), added to the cross-entropy path: fp32 [B, classes] / [B, E] or NULL */
+  const float* d_logits; const float* d_pooled;
 } d2r_head_desc;
 size_t d2r_head_arena_bytes(int B, int E, int mm, int chunks, int rank, int classes);
 size_t d2r_head_bwd_scratch(int B, int E, int mm, int chunks, int rank, int classes);

@@ -859,6 +859,42 @@ def test_head_one_call_matches_op_by_op(gpu, dtype):
     assert float(f1.abs().max()) > 0.0
 
 
+def test_head_one_call_backpropagates_a_second_loss_on_the_logits(gpu):
+    """A caller that adds its own loss on the returned logits (distillation, label smoothing outside the model) - the reference model
+    allows it: the one-call head adds the incoming logit gradient to the cross-entropy path (d2r_head_desc.d_logits) and gives the same
+    parameter gradients as the op-by-op head."""
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    from oracle import d2r_oracle as O
+    cfg = O.OracleConfig(text_layers=1, vision_layers=1, image_size=64, patch_size=32)
+    sd = O.seeded_state_dict(cfg, seed=3, router_bias="normal")
+    batch = tuple(t.to(gpu) for t in O.synthetic_batch(cfg, 5, 12, seed=4))
+    w = torch.randn(5, 3, device=gpu)
+    res = {}
+    for composite in (False, True):
+        M.COMPOSITE_HEAD = composite
+        try:
+            model = M.UnimoModelF(default_args(), VisionConfig(num_hidden_layers=1, image_size=64, patch_size=32),
+                                  TextConfig(num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+            model.load_state_dict(sd, strict=True)
+            model.to(gpu).set_compute_dtype(torch.float32).train()
+            model.model.use_streams = False
+            store = ParamStore(model, torch.float32)
+            loss, logits = model(*batch)
+            (loss + 3.0 * (logits * w).sum()).backward()
+            torch.cuda.synchronize()
+            res[composite] = (store.flat_g.clone(), [(n, o, k) for n, _, o, k, _ in store.entries])
+        finally:
+            M.COMPOSITE_HEAD = True
+    (f0, ent), (f1, _) = res[False], res[True]
+    for n, o, k in ent:
+        a, b = f1[o:o + k], f0[o:o + k]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9, n
+    only_ce = float(f0.norm())
+    assert only_ce > 0
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_dropout_kernel(gpu, dtype):
     """nn.Dropout semantics: keep fraction 1-p, survivors scaled by 1/(1-p), residual add fused, mask = pure function
