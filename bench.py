@@ -82,8 +82,6 @@ def parse():
                     help="N > 1: per bucket reduce-scatter of the gradients, AdamW on 1/N of the buffer, all-gather of the weights")
     ap.add_argument("--algorithm", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
                     help="N > 1: gradient reduction per bucket (RCCL all-reduce, or reduce-scatter + all-gather issued explicitly)")
-    ap.add_argument("--opt-overlap", action="store_true",
-                    help="overlap the AdamW pass with the next forward pass (FusedAdamW.overlap_with_forward; measured: no gain, DESIGN.md)")
     ap.add_argument("--bert-dropout", type=float, default=0.0,
                     help="hidden / attention-probability dropout of the BERT config (BASELINE.md section 3 benchmarks 0)")
     ap.add_argument("--tuning", type=int, action="append", default=[],
@@ -226,11 +224,6 @@ def main():
                       grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32, shard_optimizer=args.shard_optimizer,
                       algorithm=args.algorithm)
     dp.broadcast_parameters()
-    if args.opt_overlap and not (args.shard_optimizer or args.graph):
-        # The update of step N runs on its own stream while step N+1's forward pass proceeds behind it, layer by layer
-        # (FusedAdamW.overlap_with_forward): same launches, same results; all of it inside the timed region (the closing
-        # synchronisation waits for the last update).
-        opt.overlap_with_forward(model)
     batch = synthetic_batch(args.batch, args.seq, args.image_size, dev, seed=rank, classes=args.classes)
 
     def step():
@@ -340,7 +333,6 @@ def main():
                                   args.num_cells, args.classes, args.layers, args.layers, args.bert_dropout),
                    "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}"},
         "final_loss": round(loss_val, 5), "launch": "hipGraph replay" if args.graph else "eager",
-        "optimizer_overlap": bool(opt._defer is not None),
         "host_enqueue_ms_per_step": round(host_ms, 3),
         "fwd_bwd_only": {"ms_per_step_per_rank": round(fb_ms, 3), "samples_per_s": round(world * args.batch / fb_ms * 1e3, 2),
                          "note": "no optimiser step, no gradient all-reduce; measured on rank 0's clock"},

@@ -68,7 +68,8 @@ class InteractionDesc(C.Structure):
                 ("heads_imrc", i32), ("hid_imrc", i32), ("train", i32), ("layers", C.POINTER(RoutingLayerParams)),
                 ("own", vp), ("other", vp), ("out", vp), ("paths", vp), ("arena", vp), ("arena_bytes", sz),
                 ("splitk_ws", vp), ("splitk_bytes", sz), ("d_out", vp), ("d_paths", vp), ("d_own", vp), ("d_other", vp),
-                ("scratch", vp), ("scratch_bytes", sz), ("kv_all", LinearParams)]
+                ("scratch", vp), ("scratch_bytes", sz), ("kv_all", LinearParams),
+                ("bn_sync", vp), ("bn_sync_user", vp), ("bn_sync_buf", vp), ("bn_world", i32)]
 
 
 class HeadDesc(C.Structure):
@@ -89,7 +90,6 @@ SIGNATURES = {
     "d2r_version": (C.c_char_p, []),
     "d2r_last_error": (C.c_char_p, []),
     "d2r_gemm": (i32, [C.POINTER(GemmDesc), vp]),
-    "d2r_gemm_tuning": (None, [i32, i32, i32]),
     "d2r_gemm_group": (i32, [C.POINTER(GemmDesc), i32, vp]),
     "d2r_gemm_tn_grouped_v": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), f32, vp]),
@@ -153,6 +153,9 @@ SIGNATURES = {
     "d2r_saf_dweights": (i32, [i32, vp, vp, i32, i32, i32, vp, vp]),
     "d2r_saf_dscores": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "d2r_saf_gate_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "d2r_saf_gate_stats": (i32, [vp, i32, i32, vp, vp]),
+    "d2r_saf_gate_fwd_ex": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double, vp]),
+    "d2r_saf_gate_bwd_ex": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, C.c_double, vp]),
     "d2r_jsdiv_fwd": (i32, [vp, vp, i32, vp, vp]),
     "d2r_jsdiv_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp]),
     "d2r_ce_fwd": (i32, [vp, vp, i32, i32, vp, vp]),
@@ -168,8 +171,6 @@ SIGNATURES = {
     "d2r_adamw_step_dev": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, f32, f32, f32, f32, vp, vp]),
     "d2r_grad_nonfinite": (i32, [vp, i64, vp, vp]),
     "d2r_copy_rows": (i32, [vp, i64, vp, i64, i64, i64, vp]),
-    "d2r_gemm_timer": (i32, [i32]),
-    "d2r_gemm_timer_read": (i32, [vp, vp, vp, vp, i32]),
 }
 
 
@@ -179,6 +180,18 @@ class D2RError(RuntimeError):
 
 _lib = None
 _FN = {}  # name -> bound foreign function (filled by load(); one dict lookup per launch instead of two getattr)
+
+
+# measurement aids declared in include/d2r_hip_probes.h (not part of the drop-in surface)
+PROBE_SIGNATURES = {
+    "d2r_gemm_tuning": (None, [i32, i32, i32]),
+    "d2r_gemm_timer": (i32, [i32]),
+    "d2r_gemm_timer_read": (i32, [vp, vp, vp, vp, i32]),
+    "d2r_gemm_debug_stamps": (None, [vp]),
+    "d2r_gemm8_debug_stamps": (None, [vp]),
+    "d2r_xattn3_debug_stamps": (None, [vp]),
+    "d2r_xattn3_debug_mode": (None, [i32]),
+}
 
 
 def load():
@@ -191,7 +204,7 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m d2r_amd.build` "
             "(or __graft_entry__.build()). d2r_amd has no CPU or PyTorch fallback.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(PROBE_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch; let it propagate
         fn.restype = res
         fn.argtypes = args

@@ -30,9 +30,6 @@ if os.environ.get("D2R_X3_PROBES", "0") != "0":  # measurement build of the cros
     EXTRA_FLAGS["xattn2.hip"] = ["-DD2R_X3_PROBES=1"]
 if os.environ.get("D2R_G8_STAMPS", "0") != "0":  # measurement build of the 256-wide GEMM (tests/probes/gemm8_probe.py stamps)
     EXTRA_FLAGS["gemm8.hip"] = ["-DD2R_G8_STAMPS=1"]
-if os.environ.get("D2R_GEMM_ILV", "1") == "0":  # A/B build: DMA instructions of the pipelined K-loop issued in one run
-    EXTRA_FLAGS["gemm_glds.hip"] = EXTRA_FLAGS.get("gemm_glds.hip", []) + ["-DD2R_GEMM_ILV=0"]
-
 
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -88,10 +88,6 @@ extern "C" int d2r_mha_bwd(int dtype, const void* q, int64_t ldq, int64_t sqb, c
   return D2R_BY_DTYPE(dtype, mha_bwd_run(dtype, q, ldq, sqb, k, ldk, skb, v, ldv, svb, dO, ldg, sgb, mask, lse, dsum, dq, lddq, sdqb, dk, lddk,
                                          sdkb, dv, lddv, sdvb, B, H, Lq, Lk, head_dim, scale, p_drop, seed, stream));
 }
-static int x3_enabled() {
-  static const int on = getenv("D2R_XATTN3") ? atoi(getenv("D2R_XATTN3")) : 1;
-  return on;
-}
 static bool x3_offsets_fit(int64_t ld, int L) { return ld * (int64_t)L < (int64_t)1 << 31; }  // per-sample element offsets are 32-bit in xattn3
 
 extern "C" int d2r_xattn_fwd_multi(int dtype, int ncore, const void* const* h_q, int64_t ldq, int64_t sqb, const void* const* h_k, int64_t ldk,
@@ -102,7 +98,7 @@ extern "C" int d2r_xattn_fwd_multi(int dtype, int ncore, const void* const* h_q,
   // once per problem)
   D2RTimerScope timed((hipStream_t)stream, 10001, 4.0 * ncore * B * (double)Lq * Lk * D,
                       (double)ncore * B * (2.0 * Lq + 2.0 * Lk) * D * (dtype == D2R_F32 ? 4 : 2));
-  if (x3_enabled() && Lk <= 256 && d2r_xattn_supported(dtype, Lq, Lk, D) && B >= 1 && ncore >= 1 && ncore <= 4 && h_q && h_k && h_v && h_o && h_lse &&
+  if (Lk <= 256 && d2r_xattn_supported(dtype, Lq, Lk, D) && B >= 1 && ncore >= 1 && ncore <= 4 && h_q && h_k && h_v && h_o && h_lse &&
       x3_offsets_fit(ldk, Lk) && x3_offsets_fit(ldv, Lk)) {
     bool ok = true;
     for (int c = 0; c < ncore; ++c)
@@ -141,7 +137,7 @@ extern "C" int d2r_xattn_bwd_multi(int dtype, int ncore, const void* const* h_q,
   // (measurement aid: the whole backward op = query-side launch + product launch; algorithmic bytes = 2 x the forward's)
   D2RTimerScope timed((hipStream_t)stream, 10002, 10.0 * ncore * B * (double)Lq * Lk * D,
                       2.0 * ncore * B * (2.0 * Lq + 2.0 * Lk) * D * (dtype == D2R_F32 ? 4 : 2));
-  bool x3 = x3_enabled() && Lk <= 256 && h_o && d2r_xattn_supported(dtype, Lq, Lk, D) && B >= 1 && h_q && h_k && h_v && h_dO && h_lse && h_dq &&
+  bool x3 = Lk <= 256 && h_o && d2r_xattn_supported(dtype, Lq, Lk, D) && B >= 1 && h_q && h_k && h_v && h_dO && h_lse && h_dq &&
             h_P && h_dS && lkp >= Lk && lkp % 8 == 0 && x3_offsets_fit(ldk, Lk) && x3_offsets_fit(ldv, Lk);
   if (x3) {
     for (int c = 0; c < ncore; ++c)

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/d2r_hip.h"
+#include "../../include/d2r_hip_probes.h"
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;

@@ -350,12 +350,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
   }
 }
 
-// Workgroups of an update launch at most (0 = no cap).  The update is a grid-stride stream over the flat buffers: a small grid
-// runs it at a fraction of the HBM bandwidth, which is what FusedAdamW.overlap_with_forward wants while the next forward pass
-// is running beside it (an uncapped launch takes every CU and the whole memory system, and the forward kernels crawl).
-static int g_adamw_max_blocks = getenv("D2R_ADAMW_BLOCKS") ? atoi(getenv("D2R_ADAMW_BLOCKS")) : 0;
-extern "C" void d2r_adamw_max_blocks(int n) { g_adamw_max_blocks = n; }
-
 static int adamw_launch(const char* name, float* w, const float* g, float* m, float* v, void* w16, int w16_dtype, int64_t n, float lr,
                         float b1, float b2, float eps, float wd, float bc1, float bc2s, float gscale, const float* d_hyper,
                         const int* d_skip, void* stream) {
@@ -365,7 +359,6 @@ static int adamw_launch(const char* name, float* w, const float* g, float* m, fl
   if (n == 0) return D2R_OK;
   int blocks = (int)((n / 4 + 256) / 256);
   if (blocks > 2048) blocks = 2048;
-  if (g_adamw_max_blocks > 0 && blocks > g_adamw_max_blocks) blocks = g_adamw_max_blocks;
   if (w16 && w16_dtype == D2R_F16)
     hipLaunchKernelGGL(adamw_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (f16_t*)w16, n, lr, b1, b2, eps, wd,
                        bc1, bc2s, gscale, d_hyper, d_skip);

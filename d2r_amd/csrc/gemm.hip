@@ -391,22 +391,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-// tuning switches (A/B in one process: tests/bench_gemm.py); defaults are the measured winners
-static int g_nbuf = env_int("D2R_GEMM_NBUF", 1);
-static int g_vepi = env_int("D2R_GEMM_VEPI", 1);
-static int g_tile = env_int("D2R_GEMM_TILE", -1);
-static int g_xcd = env_int("D2R_GEMM_XCD", 1);
-static int g_wgrad_glds = env_int("D2R_WGRAD_GLDS", 1);
-// 256-wide tiles for forward / dX products (d2r_gemm_tuning tile 110 / 111): OFF by default.  Measured on the workload's shapes
-// (tests/probes/gemm8_probe.py, profiles/gemm8_probe_r04.log): the deep-pipelined loop reaches 1360-1480 TFLOP/s at K >= 4096, but the
-// K = 768 / 3072 products of the path have 48-300 such tiles (one partial round of workgroups) and twelve K-tiles of loop between a
-// 2.5 k-cycle prologue and the store burst of the whole grid: 530-860 TFLOP/s against 580-940 on the 128-wide kernels at 2-3
-// workgroups per CU.  The weight gradients (64-98 K-tiles, a thousand tiles per launch) are where the wide tiles pay.
-static int g_gemm8 = 0;
+// tuning state (A/B measurements through d2r_gemm_tuning, include/d2r_hip_probes.h); the defaults are the measured winners and the
+// library reads no environment variable
+static int g_nbuf = 1;
+static int g_vepi = 1;
+static int g_tile = -1;
+static int g_xcd = 1;
+static int g_wgrad_glds = 1;
+static int g_dbg = 0;  // ablation switches of the measurement build (-DD2R_GEMM_PROBES=1): tile code 2000 + mode
+// 256-wide tiles for forward / dX products (tile 110 / 111: off / on), taken when the product fills at least 70 % of the slots of its
+// rounds of workgroups with at least g_gemm8_min tiles (gemm8_pays).  Measured (tests/probes/gemm8_probe.py, profiles/gemm8_probe_r04.log):
+// the deep-pipelined loop reaches 1360-1480 TFLOP/s at K >= 4096, but the K = 768 / 3072 products of the path have 48-300 such tiles
+// (one partial round of workgroups) and twelve K-tiles of loop between a 2.5 k-cycle prologue and the store burst of the whole grid:
+// alone on the GPU 530-860 TFLOP/s against 580-940 on the 128-wide kernels; in the training step, where the other branch stream
+// fills the CUs a partial round leaves free, the rule is worth 0.5-0.9 % (21.06 against 21.21 ms on one box).
+static int g_gemm8 = 1;
 static int g_group = 1;  // d2r_gemm_group: grouped launches of independent forward / dX products (d2r_gemm_tuning tile 120 / 121: off / on)
 static int g_gemm8_wgrad = 1;  // ... for the grouped weight gradients (tile 102 / 103)
 static int g_gemm8_min = 150;  // fewest 256 x 256 tiles of a forward / dX product that takes them (tile 1000 + n sets it)
@@ -479,6 +478,7 @@ extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
   else if (tile == 102 || tile == 103) g_gemm8_wgrad = tile - 102;  // 256 x 256 deep-pipelined grouped weight gradients off / on
   else if (tile == 110 || tile == 111) g_gemm8 = tile - 110;        // 256 x 256 forward / dX products off / on
   else if (tile == 120 || tile == 121) g_group = tile - 120;        // grouped launches of d2r_gemm_group off / on
+  else if (tile >= 2000) g_dbg = tile - 2000;
   else if (tile >= 1000) g_gemm8_min = tile - 1000;
   else g_tile = tile;
 }
@@ -504,8 +504,7 @@ static bool gemm8_pays(const GemmArgs& a) {
   const int64_t rounds = (t + 255) / 256;
   return t * 100 >= rounds * 256 * 70;  // at least 70 % of the slots of its rounds
 }
-static int g_glds = env_int("D2R_GEMM_GLDS", 1);
-static int g_wide = env_int("D2R_GEMM_WIDE", 1);
+static int g_glds = 1;
 
 // ---- skinny fp32 GEMM: M <= 32 rows (router MLPs, poolers, Block head: per-sample vectors, batch-size rows) ------------------
 // C[M,N] = act(alpha * A[M,K] op(B) + bias) (+ R) (+ beta * C), fp32 in and out, NT (B [N,K]) or NN (B [K,N]), batched.
@@ -587,7 +586,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   }
 }
 
-static int g_skinny = env_int("D2R_GEMM_SKINNY", 1);
+static int g_skinny = 1;
 template <int LAYOUT>
 static bool skinny_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
   if (!g_skinny || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 16 != 0 || a.c_dtype != D2R_F32 || a.G || a.dbias || !a.vecA) return false;
@@ -667,8 +666,7 @@ __global__ __launch_bounds__(256) void gemm_rank_tn_kernel(GemmArgs g, GemmGroup
 }
 
 static bool rank_tn_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
-  static const int on = env_int("D2R_GEMM_RANK_TN", 1);
-  if (!on || a.K < 1 || a.K > 64 || a.c_dtype != D2R_F32 || a.dtype != D2R_F32 || a.G || a.R || a.P || a.bias || a.act != D2R_ACT_NONE) return false;
+  if (a.K < 1 || a.K > 64 || a.c_dtype != D2R_F32 || a.dtype != D2R_F32 || a.G || a.R || a.P || a.bias || a.act != D2R_ACT_NONE) return false;
   if (a.dbias && batch != 1) return false;
   if ((int64_t)a.M * a.N < 4096) return false;  // (tiny outputs: the tiled kernel's 32 x 64 tiles do as well)
   static const GemmGroup no_group = {};
@@ -770,8 +768,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_h16_kernel(GemmArgs g) {
 
 template <typename E, int LAYOUT>
 static bool skinny_h16_try(const GemmArgs& a, int batch, hipStream_t st) {
-  static const int on = env_int("D2R_GEMM_SKINNY16", 1);
-  if (!on || !g_skinny || batch != 1 || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 32 != 0 || a.dbias || !a.vecA || !a.vecB) return false;
+  if (!g_skinny || batch != 1 || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 32 != 0 || a.dbias || !a.vecA || !a.vecB) return false;
   if (LAYOUT == D2R_GEMM_NN && a.N % 16 != 0) return false;  // (a 16-column slab per workgroup is loaded unguarded)
   hipLaunchKernelGGL((gemm_skinny_h16_kernel<E, LAYOUT>), dim3(d2r_cdiv(a.N, 16)), dim3(256), 0, st, a);
   d2r_gemm_variant_tl = 31;
@@ -803,8 +800,7 @@ __global__ __launch_bounds__(256) void gemv_h16_kernel(GemmArgs g) {
 }
 template <typename E, int LAYOUT>
 static bool gemv_h16_try(const GemmArgs& a, int batch, hipStream_t st) {
-  static const int on = env_int("D2R_GEMM_GEMV", 1);
-  if (!on || LAYOUT != D2R_GEMM_NT || a.N != 1 || batch != 1 || a.M < 64 || a.K % 8 != 0 || !a.vecA || !d2r_aligned16(a.B)) return false;
+  if (LAYOUT != D2R_GEMM_NT || a.N != 1 || batch != 1 || a.M < 64 || a.K % 8 != 0 || !a.vecA || !d2r_aligned16(a.B)) return false;
   if (a.R || a.P || a.G || a.dbias || a.beta != 0.f) return false;
   hipLaunchKernelGGL((gemv_h16_kernel<E>), dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, st, a);
   d2r_gemm_variant_tl = 34;
@@ -832,7 +828,6 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     else if (g_tile == 7) bn = 1128;  // software-pipelined K-loop: 128x128 on four waves
     else if (g_tile == 8) bn = 1064;  //                             128x64
     else if (g_tile == 9) bn = 1129;  //                             128x128 on eight waves
-    else if (g_tile == 10) bn = (LAYOUT != D2R_GEMM_TN && a.N % 192 == 0) ? 193 : 129;  // 128x192 on eight waves
     // measured (profiles/gemm_ab_r01_e.log): the 128x64 LDS-DMA kernel beats the register-staged 64x64 tiles on every
     // NT / NN shape of the workload (351 vs 275, 548 vs 422, 616 vs 343 TFLOP/s ...); weight-gradient GEMMs that carry
     // the bias-gradient side product stay on the generic kernel
@@ -843,10 +838,9 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     // Round 3: the comparison above was made with every launch ALONE on the GPU.  In the training step two branch streams keep
     // two launches in flight most of the time, the chip is saturated, and what counts is bytes per flop: with the 128x128 tile for
     // every output of at least 128 columns the step is 2 % faster (1361-1366 against 1317-1342 samples/s on one box,
-    // profiles/tile_balance_r03.log; alone on the GPU a 4096x768x768 product takes 13 us with either tile).  D2R_GEMM_WIDE=0
-    // restores the shape-dependent choice.
+    // profiles/tile_balance_r03.log; alone on the GPU a 4096x768x768 product takes 13 us with either tile).
     else if (g_tile < 0 && g_glds && LAYOUT != D2R_GEMM_TN)
-      bn = ((g_wide && a.N >= 128) || a.N >= 1536 || (LAYOUT == D2R_GEMM_NT && a.K >= 2048 && a.N >= 128)) ? 129 : 64;
+      bn = a.N >= 128 ? 129 : 64;
     if (a.dbias) bn = 0;
     if constexpr (LAYOUT != D2R_GEMM_TN) {
       // 256 x 256 tiles on the deep-pipelined kernel (gemm8.hip) when the product fills the chip with them (tile code 11 forces them
@@ -893,7 +887,7 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
     // outputs (144 tiles) split 3 ways, not 4 (324 -> 385 TFLOP/s), 2304x768 (108 tiles) 4 ways, not 5 (249 -> 306).
     // 64x64 tiles: the best measured split of the 768x768 weight gradients is 6 (864 workgroups); more splits only
     // add slab traffic.  profiles/gemm_ab_r01_d.log.
-    static const int cap_small = env_int("D2R_SPLITK_CAP1", 896), cap_large = env_int("D2R_SPLITK_CAP3", 512);
+    constexpr int cap_small = 896, cap_large = 512;
     const int64_t capacity = tile <= 1 ? cap_small : cap_large;
     if (tiles < capacity) {
       int want = (int)(capacity / tiles);
@@ -960,7 +954,6 @@ static int gemm_desc_to_args(const d2r_gemm_desc* d, GemmArgs& a, int& batch) {
   a.sCb = d->sCb; a.sCh = d->sCh; a.sRb = d->sRb; a.sRh = d->sRh; a.sBiasB = d->s_bias_b;
   a.alpha = d->alpha; a.beta = d->beta; a.act = d->act; a.c_dtype = d->c_dtype; a.dtype = d->dtype;
   a.ws = nullptr; a.splits = 1; a.tiles_per_split = 0; a.xcd = g_xcd; a.band = 0;
-  static const int g_dbg = env_int("D2R_GEMM_DBG", 0);
   a.dbg = g_dbg;
   a.ts = nullptr;
   D2R_REQUIRE(!d->dbias || (d->layout == D2R_GEMM_TN && d->nb * d->nh == 1), "d2r_gemm: dbias needs the TN layout and batch 1");
@@ -1076,8 +1069,7 @@ static int launch_grouped_tn(const GemmArgs& base, const void* const* A, const v
       }
     }
     dim3 grid(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 64), n);
-    static const int rank_on = env_int("D2R_GEMM_RANK_TN", 1);
-    if (rank_on && a.K >= 1 && a.K <= 64 && (int64_t)a.M * a.N >= 4096) {
+    if (a.K >= 1 && a.K <= 64 && (int64_t)a.M * a.N >= 4096) {
       // reduction over one row per SAMPLE (pooled-vector linears of the routing cells): rank-K updates, see gemm_rank_tn_kernel
       d2r_gemm_variant_tl = 33;
       hipLaunchKernelGGL((gemm_rank_tn_kernel<T, true>), grid, dim3(256), 0, st, a, grp);

@@ -79,11 +79,13 @@ __device__ __forceinline__ void g8_wait_units(int units) {
 // ---- main loop: acc[mi][nj] (mi = mh*4 + i, nj = nh*2 + j) of this wave's 128 x 64 block of the tile at (m0, n0) ------------------
 // acc[mi][nj][r] = C[m0 + wr*128 + mh*64 + i*16 + fr][n0 + wc*64 + nh*32 + j*16 + fq*4 + r]   (fr = lane & 15, fq = lane >> 4)
 // BIAS (TN): accb[e][*] = sum_k A[k, m] for m = m0 + wr*128 + (wc>>1)*64 + ((wc&1)*2 + e)*16 + fr, when do_bias
-// VAR 0: the DMA instructions of a phase are issued in its load half (between the fragment reads and the first barrier);
-// VAR 1: they are issued INSIDE the phase's MFMA cluster (after the 3rd and the 9th MFMA), where their issue cost (60-180 cycles
-//        each in a load half) runs in the shadow of the matrix pipe; the counted waits then see one unit fewer in flight.
+// The DMA instructions of a phase are issued in its LOAD half (between the fragment reads and the first barrier).  Issuing them inside
+// the phase's MFMA cluster instead (behind the 3rd and the 9th MFMA, the counted waits then seeing one unit fewer in flight) was built
+// and measured slower on every shape: an LDS-DMA instruction holds the wave's issue for ~50 cycles wherever it sits, and inside the
+// cluster that lengthens the half both wave groups wait for (NT 4096^3 1299 against 1360 TFLOP/s, grouped weight gradients 883-928
+// against 971-1001: profiles/gemm8_probe_r04.log, "v1").
 // stamps: null, or (measurement builds) 64 s_memtime stamps per wave for workgroup 0: see G8_STAMP
-template <typename E, int LAYOUT, bool BIAS, int VAR>
+template <typename E, int LAYOUT, bool BIAS>
 __device__ __forceinline__ void g8_main(const E* __restrict__ A, const E* __restrict__ B, int M, int N, int K, int64_t lda, int64_t ldb,
                                         int m0, int n0, unsigned char* smem, f32x4 (&acc)[8][4], f32x4 (&accb)[2], bool do_bias,
                                         unsigned long long* stamps) {
@@ -127,11 +129,10 @@ __device__ __forceinline__ void g8_main(const E* __restrict__ A, const E* __rest
     }
   const int64_t strideA = A_KC ? 64 : 64 * lda, strideB = B_KC ? 64 : 64 * ldb;  // elements per K-tile
 
-  // issue piece i (or both: i < 0) of one unit of K-tile `tile` into buffer `buf`, advance the pointers
-  auto issue = [&](const E* (&p)[2], int unit_off, int buf, int tile, bool isA, int64_t stride, int64_t ld, int only) {
+  // issue the two pieces of one unit of K-tile `tile` into buffer `buf`, advance the pointers
+  auto issue = [&](const E* (&p)[2], int unit_off, int buf, int tile, bool isA, int64_t stride, int64_t ld) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (only >= 0 && only != i) continue;
       const E* src = p[i];
       if constexpr (RAGGED) {
         if (tile == nk - 1 && krem < 64) {  // (uniform) rows past the reduction length: zeros for A, the last valid row for B
@@ -144,8 +145,8 @@ __device__ __forceinline__ void g8_main(const E* __restrict__ A, const E* __rest
       p[i] += stride;
     }
   };
-  auto issueA = [&](int h, int buf, int tile, int only = -1) { issue(pa[h], h ? G8_A1 : G8_A0, buf, tile, true, strideA, lda, only); };
-  auto issueB = [&](int h, int buf, int tile, int only = -1) { issue(pb[h], h ? G8_B1 : G8_B0, buf, tile, false, strideB, ldb, only); };
+  auto issueA = [&](int h, int buf, int tile) { issue(pa[h], h ? G8_A1 : G8_A0, buf, tile, true, strideA, lda); };
+  auto issueB = [&](int h, int buf, int tile) { issue(pb[h], h ? G8_B1 : G8_B0, buf, tile, false, strideB, ldb); };
 
   // ---- per-lane LDS read addresses (buffer 0; the unit offsets and the fragment offsets are instruction immediates) -------------------
   const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
@@ -198,26 +199,12 @@ __device__ __forceinline__ void g8_main(const E* __restrict__ A, const E* __rest
     }                                                                                                    \
   } while (0)
   // the 16 MFMAs of quadrant (MH, NH); operands swapped: the accumulator tile is C^T, a lane owns ONE row and 4 consecutive columns
-  // ISSUE(piece): statement that issues DMA piece 0 / 1 of this phase's unit (VAR 1: run behind the 3rd and the 9th MFMA)
-#define G8_MFMA(MH, NH, BF, ISSUE)                                                                       \
+#define G8_MFMA(MH, NH, BF)                                                                              \
   do {                                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                       \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)       \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
-      acc[(MH) * 4 + i][(NH) * 2 + j] = H16<E>::mfma32(BF[j][kk], af[i][kk], acc[(MH) * 4 + i][(NH) * 2 + j]); \
-      if constexpr (VAR == 1) {                                                                          \
-        if (kk == 0 && i == 1 && j == 0) {                                                               \
-          __builtin_amdgcn_sched_barrier(0);                                                             \
-          ISSUE(0);                                                                                      \
-          __builtin_amdgcn_sched_barrier(0);                                                             \
-        }                                                                                                \
-        if (kk == 1 && i == 0 && j == 0) {                                                               \
-          __builtin_amdgcn_sched_barrier(0);                                                             \
-          ISSUE(1);                                                                                      \
-          __builtin_amdgcn_sched_barrier(0);                                                             \
-        }                                                                                                \
-      }                                                                                                  \
-    }                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+            acc[(MH) * 4 + i][(NH) * 2 + j] = H16<E>::mfma32(BF[j][kk], af[i][kk], acc[(MH) * 4 + i][(NH) * 2 + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
   } while (0)
@@ -270,9 +257,7 @@ __device__ __forceinline__ void g8_main(const E* __restrict__ A, const E* __rest
   G8_STAMP(1);
   if (wr == 1) g8_barrier();  // waves 4-7 run one barrier behind waves 0-3
 
-  // units still in flight behind the one a wait retires: VAR 0 issues this phase's unit BEFORE the wait, VAR 1 after it
-  constexpr int INF = VAR == 1 ? 3 : 4;
-#define G8_NOISSUE(piece) do { } while (0)
+  constexpr int INF = 4;  // units still in flight behind the one a wait retires (this phase's unit is issued BEFORE the wait)
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
     const unsigned bo = buf ? (unsigned)G8_BUF : 0u;
@@ -283,16 +268,13 @@ __device__ __forceinline__ void g8_main(const E* __restrict__ A, const E* __rest
     __builtin_amdgcn_sched_barrier(0);
     G8_READ_A(G8_A0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (VAR == 0) {
-      if (more1) issueB(1, buf ^ 1, t + 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    if (more1) issueB(1, buf ^ 1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
     g8_wait_units(more1 ? INF : 1);
     g8_barrier();
     G8_STAMP(sb + 0);
     g8_lgkm0();
-#define G8_ISSUE_P1(piece) do { if (more1) issueB(1, buf ^ 1, t + 1, piece); } while (0)
-    G8_MFMA(0, 0, bf0, G8_ISSUE_P1);
+    G8_MFMA(0, 0, bf0);
     G8_BIAS(0);
     G8_STAMP(sb + 1);
     g8_barrier();
@@ -300,45 +282,36 @@ __device__ __forceinline__ void g8_main(const E* __restrict__ A, const E* __rest
     // ---- phase 2: B1 of tile t; stage A1 of tile t+1; A1 of tile t retired --------------------------------------------------------------
     G8_READ_B(G8_B1, bf1);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (VAR == 0) {
-      if (more1) issueA(1, buf ^ 1, t + 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    if (more1) issueA(1, buf ^ 1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
     g8_wait_units(more1 ? INF : 0);
     g8_barrier();
     G8_STAMP(sb + 3);
     g8_lgkm0();
-#define G8_ISSUE_P2(piece) do { if (more1) issueA(1, buf ^ 1, t + 1, piece); } while (0)
-    G8_MFMA(0, 1, bf1, G8_ISSUE_P2);
+    G8_MFMA(0, 1, bf1);
     G8_STAMP(sb + 4);
     g8_barrier();
     G8_STAMP(sb + 5);
     // ---- phase 3: A1 of tile t; stage A0 of tile t+2 (its slot was last read in phase 1) ---------------------------------------------------
     G8_READ_A(G8_A1);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (VAR == 0) {
-      if (more2) issueA(0, buf, t + 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    if (more2) issueA(0, buf, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
     g8_barrier();
     G8_STAMP(sb + 6);
     g8_lgkm0();
-#define G8_ISSUE_P3(piece) do { if (more2) issueA(0, buf, t + 2, piece); } while (0)
-    G8_MFMA(1, 1, bf1, G8_ISSUE_P3);
+    G8_MFMA(1, 1, bf1);
     G8_BIAS(1);
     G8_STAMP(sb + 7);
     g8_barrier();
     G8_STAMP(sb + 8);
     // ---- phase 4: no reads (B0's fragments are still in registers); stage B0 of tile t+2; A0 / B0 of tile t+1 retired ---------------------
-    if constexpr (VAR == 0) {
-      if (more2) issueB(0, buf, t + 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    if (more2) issueB(0, buf, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
     if (more1) g8_wait_units(more2 ? INF : 2);
     g8_barrier();
     G8_STAMP(sb + 9);
-#define G8_ISSUE_P4(piece) do { if (more2) issueB(0, buf, t + 2, piece); } while (0)
-    G8_MFMA(1, 0, bf0, G8_ISSUE_P4);
+    G8_MFMA(1, 0, bf0);
     G8_STAMP(sb + 10);
     g8_barrier();
     G8_STAMP(sb + 11);
@@ -349,11 +322,6 @@ __device__ __forceinline__ void g8_main(const E* __restrict__ A, const E* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamps[wave * 64 + lane] = ((unsigned long long)st_hi << 32) | st_lo;
   }
-#undef G8_NOISSUE
-#undef G8_ISSUE_P1
-#undef G8_ISSUE_P2
-#undef G8_ISSUE_P3
-#undef G8_ISSUE_P4
 #undef G8_STAMP
 #undef G8_READ_A
 #undef G8_READ_B
@@ -386,7 +354,7 @@ __device__ __forceinline__ int g8_xcd_remap(int id, int nwg, int enable) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <typename E, int VAR>
+template <typename E>
 __global__ __launch_bounds__(512) void gemm8_wgrad_kernel(const G8GroupW g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G8_SMEM];
   const int L = g8_xcd_remap(blockIdx.x, g.ntiles, g.xcd);
@@ -409,7 +377,7 @@ __global__ __launch_bounds__(512) void gemm8_wgrad_kernel(const G8GroupW g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   accb[0] = accb[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool do_bias = P.dbias != nullptr && tile_n == 0;
-  g8_main<E, D2R_GEMM_TN, true, VAR>(reinterpret_cast<const E*>(P.A), reinterpret_cast<const E*>(P.B), M, N, P.K, P.lda, P.ldb, m0, n0, smem, acc, accb,
+  g8_main<E, D2R_GEMM_TN, true>(reinterpret_cast<const E*>(P.A), reinterpret_cast<const E*>(P.B), M, N, P.K, P.lda, P.ldb, m0, n0, smem, acc, accb,
                                      do_bias, D2R_G8_STAMPS ? g.stamps : nullptr);
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = wave >> 2, wc = wave & 3;
@@ -473,7 +441,7 @@ struct G8GroupF {
   G8ProbF p[G8_FMAX];
 };
 
-template <typename E, int LAYOUT, int VAR>
+template <typename E, int LAYOUT>
 __global__ __launch_bounds__(512) void gemm8_fwd_kernel(const G8GroupF g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G8_SMEM];
   const int L = g8_xcd_remap(blockIdx.x, g.ntiles, g.xcd);
@@ -508,7 +476,7 @@ __global__ __launch_bounds__(512) void gemm8_fwd_kernel(const G8GroupF g) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  g8_main<E, LAYOUT, false, VAR>(reinterpret_cast<const E*>(P.A), reinterpret_cast<const E*>(P.B), M, N, P.K, P.lda, P.ldb, m0, n0, smem, acc, accb, false,
+  g8_main<E, LAYOUT, false>(reinterpret_cast<const E*>(P.A), reinterpret_cast<const E*>(P.B), M, N, P.K, P.lda, P.ldb, m0, n0, smem, acc, accb, false,
                                  D2R_G8_STAMPS ? g.stamps : nullptr);
 
   // ---- epilogue: per wave and 64-row half, the block goes through LDS (8-byte stores from the accumulator layout, 16-byte row
@@ -560,22 +528,15 @@ __global__ __launch_bounds__(512) void gemm8_fwd_kernel(const G8GroupF g) {
 }
 
 template <typename E>
-void launch_fwd(const G8GroupF& g, int layout, int var, hipStream_t st) {
-  if (layout == D2R_GEMM_NT) {
-    if (var == 1) hipLaunchKernelGGL((gemm8_fwd_kernel<E, D2R_GEMM_NT, 1>), dim3(g.ntiles), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((gemm8_fwd_kernel<E, D2R_GEMM_NT, 0>), dim3(g.ntiles), dim3(512), 0, st, g);
-  } else {
-    if (var == 1) hipLaunchKernelGGL((gemm8_fwd_kernel<E, D2R_GEMM_NN, 1>), dim3(g.ntiles), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((gemm8_fwd_kernel<E, D2R_GEMM_NN, 0>), dim3(g.ntiles), dim3(512), 0, st, g);
-  }
+void launch_fwd(const G8GroupF& g, int layout, hipStream_t st) {
+  if (layout == D2R_GEMM_NT) hipLaunchKernelGGL((gemm8_fwd_kernel<E, D2R_GEMM_NT>), dim3(g.ntiles), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((gemm8_fwd_kernel<E, D2R_GEMM_NN>), dim3(g.ntiles), dim3(512), 0, st, g);
 }
 
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
-static int g8_var = 0;                          // kernel variant (A/B runs: d2r_gemm8_variant)
 static unsigned long long* g8_stamps = nullptr;  // measurement builds (-DD2R_G8_STAMPS=1): destination of workgroup 0's cycle stamps
-extern "C" void d2r_gemm8_variant(int var) { g8_var = var; }
 extern "C" void d2r_gemm8_debug_stamps(unsigned long long* dst) { g8_stamps = dst; }
 // Eligibility of one forward / dX problem for the 256-wide tiles (checked by the dispatcher in gemm.hip; everything else keeps the
 // 128-wide LDS-DMA kernels): 16-bit operands and output of one type, batch 1, K a multiple of 64 and at least 128, 16-byte aligned
@@ -613,8 +574,8 @@ int d2r_gemm8_fwd_launch(const GemmArgs* probs, int n, int layout, hipStream_t s
   for (int i = n; i < G8_FMAX; ++i) g.tile_end[i] = tiles;
   g.ntiles = tiles;
   g.stamps = g8_stamps;
-  if (probs[0].dtype == D2R_F16) launch_fwd<f16_t>(g, layout, g8_var, st);
-  else launch_fwd<bf16_t>(g, layout, g8_var, st);
+  if (probs[0].dtype == D2R_F16) launch_fwd<f16_t>(g, layout, st);
+  else launch_fwd<bf16_t>(g, layout, st);
   return d2r_check_launch("d2r_gemm8(fwd)");
 }
 
@@ -648,13 +609,8 @@ int d2r_gemm8_wgrad_launch(int dtype, int count, const int* M, const int* N, con
     for (int i = n; i < G8_WMAX; ++i) g.tile_end[i] = tiles;
     g.ntiles = tiles;
     g.stamps = g8_stamps;
-    if (dtype == D2R_F16) {
-      if (g8_var == 1) hipLaunchKernelGGL((gemm8_wgrad_kernel<f16_t, 1>), dim3(tiles), dim3(512), 0, st, g);
-      else hipLaunchKernelGGL((gemm8_wgrad_kernel<f16_t, 0>), dim3(tiles), dim3(512), 0, st, g);
-    } else {
-      if (g8_var == 1) hipLaunchKernelGGL((gemm8_wgrad_kernel<bf16_t, 1>), dim3(tiles), dim3(512), 0, st, g);
-      else hipLaunchKernelGGL((gemm8_wgrad_kernel<bf16_t, 0>), dim3(tiles), dim3(512), 0, st, g);
-    }
+    if (dtype == D2R_F16) hipLaunchKernelGGL((gemm8_wgrad_kernel<f16_t>), dim3(tiles), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm8_wgrad_kernel<bf16_t>), dim3(tiles), dim3(512), 0, st, g);
     if (int rc = d2r_check_launch("d2r_gemm8(wgrad)")) return rc;
   }
   return D2R_OK;

@@ -17,9 +17,6 @@
 #ifndef D2R_GEMM_PROBES
 #define D2R_GEMM_PROBES 0
 #endif
-#ifndef D2R_GEMM_ILV  // software-pipelined K-loop: DMA instructions of tile t+2 interleaved with the MFMAs (0: issued in one run; A/B by rebuild)
-#define D2R_GEMM_ILV 1
-#endif
 
 
 // XOR mask (in 16-byte chunks) of k-row k of a k-strided image with CH chunks per row.  One 32-lane group of ds_read_b64_tr_b16
@@ -35,19 +32,8 @@ __device__ __forceinline__ int kswz(int k) {
   else return (((k >> 1) & 1) | ((k >> 2) & 2)) << 1;
 }
 
-// Rows of 384 bytes (the 192-column tile: 24 chunks, not a power of two): chunk c of k-row k sits at position (c + kswz<8>(k)) mod 24.
-// Such rows alternate between the two halves of the banks like the 128-byte rows; the pair rotation by bits 1 and 3 of k puts the
-// eight rows of a transposing read on eight different 8-bank groups for every column (four consecutive pair positions mod 12 are
-// distinct mod 8, and never four apart).
 template <int CH>
-__device__ __forceinline__ int kpos(int c, int k) {
-  if constexpr (CH == 24) {
-    const int p = c + kswz<8>(k);
-    return p >= 24 ? p - 24 : p;
-  } else {
-    return c ^ kswz<CH>(k);
-  }
-}
+__device__ __forceinline__ int kpos(int c, int k) { return c ^ kswz<CH>(k); }
 
 // NWN waves along N (2: four waves, 4: eight waves per workgroup); a wave owns 64 rows x BN/NWN columns.
 // PIPE = 1: software-pipelined K-step (all fragment reads of the step issued up front behind counted lgkmcnt waits, the
@@ -134,13 +120,6 @@ __device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp,
       const int row = ins * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
       const int grow = min(n0 + row, g.N - 1);
       offB[i] = (int64_t)grow * g.ldb + c * 8;
-    } else if constexpr (BN == 192) {  // [64 k][192 n]: 384-byte rows, an instruction (1 KiB) covers two and two thirds of them
-      const int o = ins * 64 + lane;   // 16-byte chunk index in the linear image
-      const int krow = o / 24, pos = o - krow * 24;
-      int c = pos - kswz<8>(krow);     // inverse of kpos<24>
-      if (c < 0) c += 24;
-      const int col = min(n0 + c * 8, g.N - 8);
-      offB[i] = (int64_t)krow * g.ldb + col;
     } else if constexpr (BN == 128) {
       const int krow = ins * 4 + (lane >> 4), c = (lane & 15) ^ kswz<16>(krow);
       const int col = min(n0 + c * 8, g.N - 8);
@@ -295,14 +274,7 @@ __device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp,
       __builtin_amdgcn_sched_barrier(0);
       // every wave has its fragments in registers: buffer `cur` is free -> refill it with tile t+2 while the second half runs
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if constexpr (!D2R_GEMM_ILV) {
-        if (t + 2 < nk) issue(t + 2, cur);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = H16<E>::mfma32(bf1[j], af1[i], acc[i][j]);
-      } else {
+      {
         // the DMA instructions of tile t+2 go out BETWEEN the MFMAs of the second half-step (one per STRIDE MFMAs): issued in one
         // run they queue up behind the texture addresser (1 KiB = 16 cycles each, eight waves at once) and the wave's MFMAs wait
         constexpr int NM = TM * TN, ND = IA + IB, STRIDE = NM / ND > 0 ? NM / ND : 1;
@@ -331,12 +303,7 @@ __device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp,
   if (stamping) ph_t = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
-    if (PIPE == 2) {
-      // PIPE = 2: the next tile's DMA is issued BEHIND the first fragment reads of this step (below): the 270-470 cycles the six
-      // DMA instructions take to issue then run under the latency of those reads instead of in front of the step; at this point
-      // tile t is the only DMA in flight
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (t + 1 < nk) {
+    if (t + 1 < nk) {
       issue(t + 1, cur ^ 1);  // buffer cur^1 was last read in iteration t-1; every wave has passed its closing barrier
       GEMM_PHASE(ph_issue);
       if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -384,30 +351,6 @@ __device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp,
         }
       }
       if constexpr (!A_KCONT || !B_KCONT) lds_reads_done();  // (asm transposed reads are not tracked by the compiler)
-      if constexpr (PIPE == 2) {
-        if (kk == 0) {
-          // the DMA instructions of tile t+1 go out BETWEEN the MFMAs of the first half-step (buffer cur^1 was last read in
-          // iteration t-1, behind its closing barrier): one per STRIDE MFMAs, see the pipelined loop above
-          constexpr int NM = TM * TN, ND = IA + IB, STRIDE = NM / ND > 0 ? NM / ND : 1;
-          const bool more = t + 1 < nk;
-#pragma unroll
-          for (int m = 0; m < NM; ++m) {
-            const int i = m / TN, j = m % TN;
-            acc[i][j] = H16<E>::mfma32(bfr[j], af[i], acc[i][j]);
-            if (m % STRIDE == STRIDE - 1 && m / STRIDE < ND) {
-              __builtin_amdgcn_sched_barrier(0);
-              if (more) issue_one(t + 1, cur ^ 1, m / STRIDE);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-          if constexpr (ND > NM / STRIDE) {
-#pragma unroll
-            for (int r = NM / STRIDE; r < ND; ++r)
-              if (more) issue_one(t + 1, cur ^ 1, r);
-          }
-          continue;
-        }
-      }
       if (dbg == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
@@ -632,18 +575,6 @@ static void launch_glds(const GemmArgs& a, int bn, hipStream_t st) {
   static const GemmGroup no_group = {};
   const bool pipe = bn >= 1000;  // 1064 / 1128 / 1129: the software-pipelined K-loop
   if (pipe) bn -= 1000;
-  static const int late = getenv("D2R_GEMM_ISSUE_LATE") ? atoi(getenv("D2R_GEMM_ISSUE_LATE")) : 0;  // PIPE = 2 (A/B switch)
-  if (late && !pipe) {
-    if (bn == 129) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 4, 2>), dim3(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128)), dim3(512), 0, st, a, no_group);
-    else if (bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 2, 2>), dim3(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128)), dim3(256), 0, st, a, no_group);
-    else hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 64, 2, 2>), dim3(d2r_cdiv(a.N, 64), d2r_cdiv(a.M, 128)), dim3(256), 0, st, a, no_group);
-    return;
-  }
-  if (bn == 193) {  // 128 x 192 tile on eight waves (2 x 4, wave tile 64 x 48): a sixth less L2 -> LDS traffic per flop than 128 x 128
-    dim3 grid(d2r_cdiv(a.N, 192), d2r_cdiv(a.M, 128));
-    if constexpr (LAYOUT != D2R_GEMM_TN) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 192, 4>), grid, dim3(512), 0, st, a, no_group);
-    return;
-  }
   if (bn == 129) {  // 128 x 128 tile on EIGHT waves (2 x 4): per wave as the 128x64 kernel, a third less L2 traffic per flop
     dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128));
     if (pipe) hipLaunchKernelGGL((gemm_glds_kernel<E, LAYOUT, 128, 4, 1>), grid, dim3(512), 0, st, a, no_group);
@@ -670,7 +601,6 @@ extern "C" void d2r_gemm_debug_stamps(unsigned long long* dst) { g_gemm_stamps =
 int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStream_t st) {
   if (!d2r_is16(a.dtype) || batch != 1 || a.K % 64 != 0 || a.K < 128 || a.M < 128 || a.N < 64) return 0;
   if ((bn % 1000) == 129 && a.N < 128) return 0;
-  if (bn == 193 && (a.N < 192 || layout == D2R_GEMM_TN)) return 0;
   if (!a.vecA || !a.vecB) return 0;
   if (a.G && !(a.vecC && a.c_dtype == a.dtype)) return 0;  // the activation-gradient epilogue is in the vectorised path only
   const bool a_strided = layout == D2R_GEMM_TN, b_strided = layout != D2R_GEMM_NT;
@@ -680,17 +610,16 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
   ab.ts = g_gemm_stamps;
   {
     // column bands for wide outputs: the B panels of a band (band x BN x K x 2 bytes) should take about a third of the 4 MB L2
-    const int bnw = (bn % 1000) == 64 ? 64 : bn == 193 ? 192 : 128;
+    const int bnw = (bn % 1000) == 64 ? 64 : 128;
     const int gx = d2r_cdiv(a.N, bnw);
     const int64_t panel = (int64_t)bnw * a.K * 2;
     int band = (int)((int64_t)(1536 << 10) / (panel > 0 ? panel : 1));
     if (band < 2) band = 2;
-    static const int band_on = getenv("D2R_GEMM_BAND") ? atoi(getenv("D2R_GEMM_BAND")) : 1;
     // (not for deep reductions: at K = 3072 every band re-streams A row panels as large as the B band itself - measured 2-6 % slower
     //  alone on the GPU and +2 GB per step past L2 for the 128x64 dX kernel)
-    ab.band = (band_on && a.K <= 1536 && gx > band && gx * panel > (3 << 20)) ? band : 0;
+    ab.band = (a.K <= 1536 && gx > band && gx * panel > (3 << 20)) ? band : 0;
   }
-  d2r_gemm_variant_tl = bn == 193 ? 4 : ((bn % 1000) == 64 ? 1 : (bn % 1000) == 128 ? 2 : 3) + (bn >= 1000 ? 10 : 0);
+  d2r_gemm_variant_tl = ((bn % 1000) == 64 ? 1 : (bn % 1000) == 128 ? 2 : 3) + (bn >= 1000 ? 10 : 0);
   switch (layout) {
     case D2R_GEMM_NT: f16 ? launch_glds<f16_t, D2R_GEMM_NT>(ab, bn, st) : launch_glds<bf16_t, D2R_GEMM_NT>(ab, bn, st); break;
     case D2R_GEMM_NN: f16 ? launch_glds<f16_t, D2R_GEMM_NN>(ab, bn, st) : launch_glds<bf16_t, D2R_GEMM_NN>(ab, bn, st); break;
@@ -707,22 +636,7 @@ int d2r_gemm_glds_try(const GemmArgs& a, int layout, int batch, int bn, hipStrea
 int d2r_gemm_glds_wgrad_try(const GemmArgs& a, const GemmGroup& grp, int n, hipStream_t st) {
   if (!d2r_is16(a.dtype) || a.K < 128 || a.M < 128 || a.N < 128 || !a.vecA || !a.vecB || a.M % 8 != 0 || a.N % 8 != 0) return 0;
   d2r_gemm_variant_tl = 20;
-  // 256 x 128 tiles on eight waves (D2R_WGRAD_TILE256): three quarters of the L2 -> LDS bytes per flop of the 128 x 128 tile; these launches
-  // have a thousand tiles and 64-98 K-steps, so neither the grid quantisation nor the longer prologue of the wider tile matters
-  static const int tile256 = getenv("D2R_WGRAD_TILE256") ? atoi(getenv("D2R_WGRAD_TILE256")) : 0;
-  if (tile256 && a.M % 256 == 0) {
-    dim3 grid(d2r_cdiv(a.N, 128), a.M / 256, n);
-    if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, 1, 4>), grid, dim3(512), 0, st, a, grp);
-    else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, 1, 4>), grid, dim3(512), 0, st, a, grp);
-    return 1;
-  }
   dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), n);
-  static const int w8 = getenv("D2R_WGRAD_W8") ? atoi(getenv("D2R_WGRAD_W8")) : 0;  // the 128 x 128 tile on eight waves (wave tile 64 x 32)
-  if (w8) {
-    if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 4, 1, 1>), grid, dim3(512), 0, st, a, grp);
-    else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 4, 1, 1>), grid, dim3(512), 0, st, a, grp);
-    return 1;
-  }
   if (a.dtype == D2R_F16) hipLaunchKernelGGL((gemm_glds_kernel<f16_t, D2R_GEMM_TN, 128, 2, 1, 1>), grid, dim3(256), 0, st, a, grp);
   else hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, D2R_GEMM_TN, 128, 2, 1, 1>), grid, dim3(256), 0, st, a, grp);
   return 1;

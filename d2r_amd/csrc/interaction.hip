@@ -112,11 +112,20 @@ void plan_fwd(Arena& A, const Dims& d, int P, bool first, bool final, LayerF& L,
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------------------
+// global-batch-exact BatchNorm (d2r_interaction_desc.bn_sync): `buf` = this layer's four doubles, `ntotal` = scores of the global batch
+struct BnSync {
+  int (*fn)(void*, double*, void*) = nullptr;
+  void* user = nullptr;
+  double* buf = nullptr;
+  double ntotal = 0.0;
+};
+
 struct Ctx {
   int dt;
   void* st;
   void* ws;
   size_t wsb;
+  BnSync bn = {};
 };
 
 struct G {
@@ -354,7 +363,13 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(copy2d(L.g_S, (size_t)n * row, L.g_sg, row, row, B, c.st));
     TRY(copy2d((char*)L.g_S + row, (size_t)n * row, L.g_sl, (size_t)d.Lq * row, (size_t)d.Lq * row, B, c.st));
     TRY(lin(c, B * n, 1, E, L.g_S, E, lp[D2R_RL_GLAC_SAFW], L.g_a, D2R_ACT_NONE, nullptr, -1, D2R_F32));
-    TRY(d2r_saf_gate_fwd(L.g_a, B, n, p.bn_weight, p.bn_bias, p.bn_running_mean, p.bn_running_var, train, L.g_w, L.g_saved, c.st));
+    if (c.bn.fn && train) {  // statistics over the samples of every rank: local sums, the caller's all-reduce, then the gate
+      TRY(d2r_saf_gate_stats(L.g_a, B, n, c.bn.buf, c.st));
+      if (c.bn.fn(c.bn.user, c.bn.buf, c.st)) return d2r_fail(D2R_ERR_INVALID, "d2r_interaction_fwd: bn_sync failed");
+      TRY(d2r_saf_gate_fwd_ex(L.g_a, B, n, p.bn_weight, p.bn_bias, p.bn_running_mean, p.bn_running_var, train, L.g_w, L.g_saved, c.bn.buf, c.bn.ntotal, c.st));
+    } else {
+      TRY(d2r_saf_gate_fwd(L.g_a, B, n, p.bn_weight, p.bn_bias, p.bn_running_mean, p.bn_running_var, train, L.g_w, L.g_saved, c.st));
+    }
     TRY(d2r_cast(D2R_F32, L.g_w, c.dt, L.g_w16, (int64_t)B * n, c.st));
     G g(c.dt, c.dt, D2R_GEMM_NN, 1, E, n, L.g_w16, n, L.g_S, E, L.g_wsum, E);  // wsum[b] = w[b] @ S[b]
     g.batch(B, n, (int64_t)n * E, E);
@@ -514,7 +529,13 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(d2r_l2norm_bwd(c.dt, K.de[1], L.g_wsum, L.g_ne1, K.g_dwsum, B, E, c.st));
     // d w[b] = d wsum[b] S[b]^T (fp32), the gate's backward, then d S[b] = w[b]^T d wsum[b] + d a w_saf in ONE pass (rank-one products)
     TRY(d2r_saf_dweights(c.dt, K.g_dwsum, L.g_S, B, n, E, K.g_dwf, c.st));
-    TRY(d2r_saf_gate_bwd(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, K.bn2, K.bn2 + 1, c.st));
+    if (c.bn.fn && train) {
+      TRY(d2r_saf_gate_bwd_ex(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, K.bn2, K.bn2 + 1, 1, c.bn.buf + 2, c.bn.ntotal, c.st));
+      if (c.bn.fn(c.bn.user, c.bn.buf + 2, c.st)) return d2r_fail(D2R_ERR_INVALID, "d2r_interaction_bwd: bn_sync failed");
+      TRY(d2r_saf_gate_bwd_ex(L.g_a, nullptr, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, nullptr, nullptr, 2, c.bn.buf + 2, c.bn.ntotal, c.st));
+    } else {
+      TRY(d2r_saf_gate_bwd(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, K.bn2, K.bn2 + 1, c.st));
+    }
     TRY(acc32(c, K.bn2, p.g_bn_weight, 1));
     TRY(acc32(c, K.bn2 + 1, p.g_bn_bias, 1));
     TRY(d2r_cast(D2R_F32, K.g_daf, c.dt, K.g_da16, (int64_t)B * n, c.st));  // (the weight gradient of attn_sim_w below reads it as a GEMM operand)
@@ -690,6 +711,7 @@ int check(const d2r_interaction_desc* D, const char* fn, bool bwd, void* stream)
   D2R_REQUIRE(d2r_interaction_supported(D->dtype, D->Lq, D->Lk, D->ncell, D->heads_imrc),
               "%s: unsupported (bf16, 2..6 cells, token counts within the fused attention cores' limits)", fn);
   D2R_REQUIRE(D->layers && D->own && D->other && D->out && D->paths && D->arena && d2r_aligned16(D->arena), "%s: null / unaligned pointer", fn);
+  D2R_REQUIRE(!D->bn_sync || (D->bn_sync_buf && D->bn_world >= 1), "%s: bn_sync needs bn_sync_buf (4 doubles per layer) and bn_world >= 1", fn);
   D2R_REQUIRE(D->kv_all.w && D->kv_all.b && (!bwd || (D->kv_all.gw && D->kv_all.gb)), "%s: kv_all (the fused k|v projections of `other`) missing", fn);
   D2R_REQUIRE(D->arena_bytes >= d2r_interaction_arena_bytes(D->B, D->Lq, D->Lk, D->ncell, D->nlayer, D->hid_router, D->hid_imrc),
               "%s: arena too small", fn);
@@ -747,7 +769,9 @@ extern "C" int d2r_interaction_fwd(const d2r_interaction_desc* D, void* stream) 
     const bool first = l == 0, final = l == d.nl - 1;
     const int P = final ? 1 : nc;
     plan_fwd(A, d, P, first, final, L, kvall, l);
-    TRY(layer_fwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, L, D->out, D->paths + (size_t)l * nc * nc, total));
+    Ctx cl = c;
+    if (D->bn_sync) cl.bn = BnSync{D->bn_sync, D->bn_sync_user, D->bn_sync_buf + 4 * l, (double)D->bn_world * d.B * d.n};
+    TRY(layer_fwd(cl, d, D->layers[l], P, first, final, D->train, refs, D->other, L, D->out, D->paths + (size_t)l * nc * nc, total));
     for (int j = 0; j < nc && !final; ++j) refs[j] = L.outs[j];
   }
   return D2R_OK;
@@ -783,7 +807,9 @@ extern "C" int d2r_interaction_bwd(const d2r_interaction_desc* D, void* stream) 
       douts[j] = final ? (j == 0 ? (D->d_out ? D->d_out : zero_out) : nullptr) : K[l + 1].dx[j];
     }
     const float* dprobs = D->d_paths ? D->d_paths + (size_t)l * nc * nc : nullptr;
-    TRY(layer_bwd(c, d, D->layers[l], P, first, final, D->train, refs, D->other, F[l], K[l], douts, D->out, dprobs, total, dx, D->d_other, jobs));
+    Ctx cl = c;
+    if (D->bn_sync) cl.bn = BnSync{D->bn_sync, D->bn_sync_user, D->bn_sync_buf + 4 * l, (double)D->bn_world * d.B * d.n};
+    TRY(layer_bwd(cl, d, D->layers[l], P, first, final, D->train, refs, D->other, F[l], K[l], douts, D->out, dprobs, total, dx, D->d_other, jobs));
   }
   if (d.nkv) {
     // every cell and layer wrote its dK | dV block: the gradient w.r.t. `other` through ALL key / value projections is one product

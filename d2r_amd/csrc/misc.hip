@@ -5,16 +5,50 @@
 // =====================================================================================================
 // K6 SAF gate (models/XModules.py:380-381): one 1024-thread workgroup; a[B,n] fp32 is tiny (B*(Lq+1))
 // =====================================================================================================
+// Sum and sum of squares of the scores over this rank's samples (fp64): the global-batch-exact mode under data parallelism
+// all-reduces them and hands the totals to the gate (gstats), which then normalises with the statistics of the WHOLE batch as the
+// reference's BatchNorm1d(1) does on one GPU (models/XModules.py:376,381).
+__global__ __launch_bounds__(1024) void saf_gate_stats_kernel(const float* __restrict__ a, int N, double* __restrict__ sums) {
+  __shared__ double shd[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  double s = 0.0, q = 0.0;
+  for (int i = tid; i < N; i += blockDim.x) {
+    const double v = (double)a[i];
+    s += v;
+    q += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (lane == 0) shd[0][wave] = s, shd[1][wave] = q;
+  __syncthreads();
+  if (tid == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int i = 0; i < nw; ++i) ts += shd[0][i], tq += shd[1][i];
+    sums[0] = ts, sums[1] = tq;
+  }
+}
+
 __global__ __launch_bounds__(1024) void saf_gate_fwd_kernel(const float* __restrict__ a, int B, int n,
                                                             const float* __restrict__ bn_w,
                                                             const float* __restrict__ bn_b, float* running_mean,
                                                             float* running_var, int train, float* __restrict__ w,
-                                                            float* __restrict__ saved) {
+                                                            float* __restrict__ saved, const double* __restrict__ gstats,
+                                                            double ntotal) {
   __shared__ float sh[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int N = B * n;
   float mean, var;
-  if (train) {
+  if (train && gstats) {  // statistics of the global batch (all ranks): E[a], E[a^2] - E[a]^2 in fp64
+    const double m = gstats[0] / ntotal, v = gstats[1] / ntotal - m * m;
+    mean = (float)m, var = (float)(v > 0.0 ? v : 0.0);
+    if (tid == 0) {
+      running_mean[0] = 0.9f * running_mean[0] + 0.1f * mean;
+      running_var[0] = 0.9f * running_var[0] + 0.1f * var * (float)(ntotal / (ntotal > 1.0 ? ntotal - 1.0 : 1.0));
+    }
+  } else if (train) {
     float s = 0.f;
     for (int i = tid; i < N; i += blockDim.x) s += a[i];
     mean = block_sum(s, sh) / (float)N;
@@ -58,11 +92,23 @@ __global__ __launch_bounds__(1024) void saf_gate_bwd_kernel(const float* __restr
                                                             const float* __restrict__ bn_b,
                                                             const float* __restrict__ saved, int train,
                                                             float* __restrict__ da, float* __restrict__ d_bn_w,
-                                                            float* __restrict__ d_bn_b) {
+                                                            float* __restrict__ d_bn_b, int phase, double* __restrict__ gsums,
+                                                            double ntotal) {
+  // phase 0: the whole backward with this rank's own sums (local batch statistics).  Global-batch-exact mode: phase 1 stops behind
+  // stage 1 (d y in `da`, the LOCAL sums = this rank's share of the BatchNorm parameter gradients, and the fp64 sums for the
+  // all-reduce in gsums); phase 2 finishes with the all-reduced sums over the ntotal scores of the global batch.
   __shared__ float sh[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int N = B * n;
   const float mean = saved[0], rstd = saved[1], gw = bn_w[0], gb = bn_b[0];
+  if (phase == 2) {
+    const float m1 = (float)(gsums[0] / ntotal), m2 = (float)(gsums[1] / ntotal);
+    for (int i = tid; i < N; i += blockDim.x) {
+      const float xh = (a[i] - mean) * rstd;
+      da[i] = gw * rstd * (da[i] - m1 - xh * m2);
+    }
+    return;
+  }
   float sdy = 0.f, sdyx = 0.f;
   for (int b = wave; b < B; b += nw) {
     float s = 0.f;
@@ -93,7 +139,9 @@ __global__ __launch_bounds__(1024) void saf_gate_bwd_kernel(const float* __restr
   if (tid == 0) {
     d_bn_w[0] = tdyx;
     d_bn_b[0] = tdy;
+    if (phase == 1) gsums[0] = (double)tdy, gsums[1] = (double)tdyx;
   }
+  if (phase == 1) return;
   __syncthreads();
   const float m1 = tdy / (float)N, m2 = tdyx / (float)N;
   for (int i = tid; i < N; i += blockDim.x) {
@@ -110,20 +158,40 @@ __global__ __launch_bounds__(1024) void saf_gate_bwd_kernel(const float* __restr
 extern "C" int d2r_saf_gate_fwd(const float* a, int B, int n, const float* bn_weight, const float* bn_bias,
                                 float* running_mean, float* running_var, int train, float* w, float* saved,
                                 void* stream) {
+  return d2r_saf_gate_fwd_ex(a, B, n, bn_weight, bn_bias, running_mean, running_var, train, w, saved, nullptr, 0.0, stream);
+}
+
+extern "C" int d2r_saf_gate_stats(const float* a, int B, int n, double* sums, void* stream) {
+  D2R_REQUIRE(a && sums && B >= 1 && n >= 1, "d2r_saf_gate_stats: bad argument");
+  hipLaunchKernelGGL(saf_gate_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, B * n, sums);
+  return d2r_check_launch("d2r_saf_gate_stats");
+}
+
+extern "C" int d2r_saf_gate_fwd_ex(const float* a, int B, int n, const float* bn_weight, const float* bn_bias, float* running_mean,
+                                   float* running_var, int train, float* w, float* saved, const double* gstats, double ntotal,
+                                   void* stream) {
   D2R_REQUIRE(a && bn_weight && bn_bias && running_mean && running_var && w && saved, "d2r_saf_gate_fwd: null pointer");
   D2R_REQUIRE(B >= 1 && n >= 1, "d2r_saf_gate_fwd: bad shape");
+  D2R_REQUIRE(!gstats || ntotal >= (double)B * n, "d2r_saf_gate_fwd: the global element count is smaller than this rank's");
   hipLaunchKernelGGL(saf_gate_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, B, n, bn_weight, bn_bias,
-                     running_mean, running_var, train, w, saved);
+                     running_mean, running_var, train, w, saved, gstats, ntotal);
   return d2r_check_launch("d2r_saf_gate_fwd");
 }
 
 extern "C" int d2r_saf_gate_bwd(const float* a, const float* dw, int B, int n, const float* bn_weight,
                                 const float* bn_bias, const float* saved, int train, float* da, float* d_bn_weight,
                                 float* d_bn_bias, void* stream) {
-  D2R_REQUIRE(a && dw && bn_weight && bn_bias && saved && da && d_bn_weight && d_bn_bias, "d2r_saf_gate_bwd: null pointer");
+  return d2r_saf_gate_bwd_ex(a, dw, B, n, bn_weight, bn_bias, saved, train, da, d_bn_weight, d_bn_bias, 0, nullptr, 0.0, stream);
+}
+
+extern "C" int d2r_saf_gate_bwd_ex(const float* a, const float* dw, int B, int n, const float* bn_weight, const float* bn_bias,
+                                   const float* saved, int train, float* da, float* d_bn_weight, float* d_bn_bias, int phase,
+                                   double* gsums, double ntotal, void* stream) {
+  D2R_REQUIRE(a && bn_weight && bn_bias && saved && da && (phase == 2 || (dw && d_bn_weight && d_bn_bias)), "d2r_saf_gate_bwd: null pointer");
   D2R_REQUIRE(B >= 1 && n >= 1, "d2r_saf_gate_bwd: bad shape");
+  D2R_REQUIRE(phase == 0 || (phase >= 1 && phase <= 2 && gsums && train && ntotal >= (double)B * n), "d2r_saf_gate_bwd: bad phase / global sums");
   hipLaunchKernelGGL(saf_gate_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, dw, B, n, bn_weight, bn_bias,
-                     saved, train, da, d_bn_weight, d_bn_bias);
+                     saved, train, da, d_bn_weight, d_bn_bias, phase, gsums, ntotal);
   return d2r_check_launch("d2r_saf_gate_bwd");
 }
 

@@ -291,8 +291,7 @@ static int x2_launch(int ncore, const void* const* q, int64_t ldq, int64_t sqb, 
   a.mask = mask, a.ncore = ncore;
   a.ldq = ldq, a.sqb = sqb, a.ldk = ldk, a.skb = skb, a.ldv = ldv, a.svb = svb, a.ldo = ldo, a.sob = sob, a.ldr = ldr, a.srb = srb;
   a.B = B, a.Lq = Lq, a.Lk = Lk, a.scale = scale;
-  static const int dbg = getenv("D2R_X2_DBG") ? atoi(getenv("D2R_X2_DBG")) : 0;
-  a.dbg = dbg;
+  a.dbg = 0;
   const int bgrp = (B + 7) / 8 * 8;
   if (Lk <= 256) {
     // 32-query tiles halve the K / V re-reads; 16-query tiles double the workgroups: take 32 when that still fills the chip

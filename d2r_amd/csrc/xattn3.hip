@@ -792,6 +792,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 unsigned long long* g_x3_stamps = nullptr;  // tests/probes/xattn3_probe.py (d2r_xattn3_debug_stamps): cycle stamps of block 0
+int g_x3_dbg = 0;                            // ablation mode of the measurement build (d2r_xattn3_debug_mode)
 
 template <typename E>
 void x3_fill(X3Args<E>& a, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
@@ -805,8 +806,7 @@ void x3_fill(X3Args<E>& a, int ncore, const void* const* q, int64_t ldq, int64_t
   a.ldq = ldq, a.sqb = sqb, a.ldk = ldk, a.skb = skb, a.ldv = ldv, a.svb = svb, a.ldo = ldo, a.sob = sob, a.ldr = ldr, a.srb = srb;
   a.B = B, a.Lq = Lq, a.Lk = Lk, a.scale = scale;
   a.ntile = (Lq + QT - 1) / QT;
-  static const int dbg = getenv("D2R_X3_DBG") ? atoi(getenv("D2R_X3_DBG")) : 0;
-  a.dbg = dbg;
+  a.dbg = g_x3_dbg;
   a.ts = g_x3_stamps;
 }
 
@@ -845,8 +845,7 @@ int x3_dkv_launch(int ngroup, const void* const* W, const void* const* X, void* 
   }
   a.swb = (int64_t)Lq * lkp, a.ldw = lkp, a.B = B, a.ngroup = ngroup;
   // the compact kernel (two workgroups per CU) when every group fits its eight fragments per wave and 64 KB of LDS
-  static const int compact_on = getenv("D2R_X3_DKV2") ? atoi(getenv("D2R_X3_DKV2")) : 1;
-  bool compact = compact_on != 0;
+  bool compact = true;
   size_t lds = 0;
   for (int g = 0; g < ngroup && compact; ++g) {
     const int KP = (a.Kd[g] + 31) / 32 * 32, KS = KP / 32, nmt = (a.Md[g] + 15) / 16;
@@ -871,6 +870,7 @@ int x3_dkv_launch(int ngroup, const void* const* W, const void* const* X, void* 
 // s_memtime stamps of its four waves in dst [4][64] (0 start, 1 loop entry, 2+t end of score tile t, 18 softmax done, 19+t end of
 // value tile t, 35 ring released, 36 end); nullptr switches it off
 extern "C" void d2r_xattn3_debug_stamps(unsigned long long* dst) { g_x3_stamps = dst; }
+extern "C" void d2r_xattn3_debug_mode(int mode) { g_x3_dbg = mode; }  // acts on a -DD2R_X3_PROBES=1 build only
 
 int d2r_xattn3_fwd_try(int dtype, int ncore, const void* const* q, int64_t ldq, int64_t sqb, const void* const* k, int64_t ldk, int64_t skb,
                        const void* const* v, int64_t ldv, int64_t svb, void* const* o, int64_t ldo, int64_t sob, const void* const* residual,

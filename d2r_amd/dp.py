@@ -203,18 +203,25 @@ class FlatGradReducer:
 class DataParallel:
     def __init__(self, store: ParamStore, optimizer, model: torch.nn.Module, bucket_mb: int = 128, group=None,
                  overlap: bool = False, bucket_elems: Optional[int] = None, grad_comm_dtype: torch.dtype = torch.float32,
-                 shard_optimizer: bool = False, algorithm: str = "all_reduce", single_rank_collectives: bool = False):
+                 shard_optimizer: bool = False, algorithm: str = "all_reduce", single_rank_collectives: bool = False,
+                 global_batch_exact: bool = False):
         """grad_comm_dtype: torch.bfloat16 sends the gradient buckets as bf16 (see FlatGradReducer).
         algorithm: "all_reduce" or "reduce_scatter_all_gather" (module docstring).
         shard_optimizer: reduce-scatter of every bucket + AdamW on this rank's stripes + all-gather of the updated weights
         (same bytes on the links as the all-reduce); works with overlap: a bucket's scatter goes out when the bucket is complete.
         single_rank_collectives: with an initialised process group of ONE rank, issue every collective anyway (a one-GPU box
         executes the RCCL code path - in-place reduce_scatter_tensor, all_gather_into_tensor, the communication stream's ordering -
-        with results that must equal the plain step bit for bit: tests/test_gpu_trainer.py).  Off: world size 1 is a no-op."""
+        with results that must equal the plain step bit for bit: tests/test_gpu_trainer.py).  Off: world size 1 is a no-op.
+        global_batch_exact: the three batch-coupled points of the reference (BatchNorm1d(1) of the GLAC cells, the [B,B] similarity
+        matrices, the batch-softmax JS loss) see the GLOBAL batch (functional.DP_EXACT: two all-reduced doubles per BatchNorm and
+        direction, all-gathers of `paths` [b, 36(DR-1)+6] and of the cls vectors [b, 768]); the averaged gradients are then the
+        reference's gradients on the global batch.  Default: local-batch statistics and a local JS term per rank (DDP semantics)."""
         self.store, self.opt, self.model, self.group = store, optimizer, model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = self.world > 1 or (bool(single_rank_collectives) and dist.is_initialized())
+        from . import functional as F
+        F.DP_EXACT = (group, self.world, self.rank) if (global_batch_exact and self.active) else None
         if algorithm not in ALGORITHMS:
             raise ValueError(f"algorithm must be one of {ALGORITHMS}, got {algorithm!r}")
         self.shard_optimizer = bool(shard_optimizer) and self.active

@@ -71,7 +71,7 @@ _WS = {}
 # Weight-gradient GEMMs (dW = dY^T X) feed nothing but the optimiser: they are issued on a side stream per compute
 # stream so that they fill the CUs the (small, latency-bound) dX chain leaves idle.  Whoever consumes the flat
 # gradient buffer (optimiser step, all-reduce, zero_grad, a test reading .grad) calls wgrad_join() first.
-WGRAD_STREAMS = os.environ.get("D2R_WGRAD_STREAMS", "0") != "0"  # measured slower on MI355X (35.4 vs 33.7 ms/step): off
+WGRAD_STREAMS = False  # measured slower on MI355X (35.4 vs 33.7 ms/step): off
 _WGRAD = {}
 
 
@@ -110,11 +110,11 @@ def wgrad_streams():
 # tiles each — alone they need split-K slabs and a reduce launch) are queued per stream and shape and launched
 # sixteen at a time by d2r_gemm_tn_grouped (2x faster per GEMM, one launch instead of thirty-two).
 # ------------------------------------------------------------------------------------------------------
-DEFER_WGRAD = os.environ.get("D2R_DEFER_WGRAD", "1") != "0"
-DEFER_SHORT_WGRAD = os.environ.get("D2R_DEFER_SHORT_WGRAD", "1") != "0"  # also the rank-B updates of the pooled-vector linears
+DEFER_WGRAD = True
+DEFER_SHORT_WGRAD = True  # also the rank-B updates of the pooled-vector linears
 _WGRAD_Q = {}  # stream handle -> {"stream": torch stream, "jobs": {shape key: [job, ...]}}
 _WGRAD_FLUSH_AT = 32
-D2R_LAYER_GROUP = int(os.environ.get("D2R_LAYER_GROUP", "7"))  # encoder layers per grouped launch of their (large) weight gradients
+D2R_LAYER_GROUP = 7  # encoder layers per grouped launch of their (large) weight gradients
 # (measured at C2: 1 -> 32.6 ms/step, 2 -> 31.7, 4 / 6 / 13 -> 31.3-31.5; each stream runs 13 composite layers per step, so seven
 # gives groups of 7 + 6 and no single-problem launch; at most ~0.8 GB of scratch kept alive)
 
@@ -149,7 +149,7 @@ def _iparr(ptrs):
     return arr
 
 
-DEFER_LN = os.environ.get("D2R_DEFER_LN", "1") != "0"  # second stage of the encoder layers' LayerNorm backward: one launch per group of layers
+DEFER_LN = True  # second stage of the encoder layers' LayerNorm backward: one launch per group of layers
 
 
 def _defer_ln_sum(rows, D, ws_ptr, g_sink, b_sink, params, keepalive, flush_at=None):
@@ -622,6 +622,79 @@ class _MatmulNT(torch.autograd.Function):
         return da, db
 
 
+# ------------------------------------------------------------------------------------------------------
+# data parallelism, global-batch-exact mode (d2r_amd.dp.DataParallel(global_batch_exact=True)): the three places where
+# the reference couples the samples of a batch - the BatchNorm1d(1) of every GLAC cell (models/XModules.py:376,381), the [B,B]
+# path / cls similarity matrices and the batch-softmax JS loss (models/InteractionModule.py:53, models/modeling_unimo.py:845-849,
+# models/XModules.py:32-41) - see the WHOLE batch: BatchNorm sums are all-reduced (2 doubles, forward and backward), `paths` and the
+# cls vectors are all-gathered.  Every rank then computes the same JS term of the global batch and adds it to its local cross
+# entropy mean: the average of the ranks' losses is the reference's loss on the global batch, and the averaged gradients are its
+# gradients.  None: local-batch statistics and a local [b,b] JS term per rank (what DDP of the reference would give).
+# ------------------------------------------------------------------------------------------------------
+DP_EXACT = None  # (process group, world size, rank)
+
+
+class _GatherBatch(torch.autograd.Function):
+    """x [b, ...] of every rank -> [world * b, ...] (rank order).  Every rank evaluates the SAME function of the gathered tensor, so
+    the sum over ranks of the gradients w.r.t. this rank's rows is world x this rank's own copy: no communication in the backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import torch.distributed as dist
+        group, world, rank = DP_EXACT
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        ctx.meta = (world, rank, x.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        world, rank, b = ctx.meta
+        return g[rank * b:(rank + 1) * b] * float(world)
+
+
+def gather_batch(x):
+    return x if DP_EXACT is None else _GatherBatch.apply(x)
+
+
+def _allreduce_pair(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=DP_EXACT[0])
+
+
+_BN_SYNC_BUFS = {}  # id -> fp64 device tensor handed to a whole-module C call as bn_sync_buf
+
+
+def _bn_sync(user, pair, stream):
+    """d2r_interaction_desc.bn_sync: sums the two doubles at `pair` over the ranks (called from inside d2r_interaction_fwd / _bwd)."""
+    try:
+        buf = _BN_SYNC_BUFS[int(user)]
+        off = (int(pair) - buf.data_ptr()) // 8
+        assert 0 <= off <= buf.numel() - 2 and torch.cuda.current_stream().cuda_stream == (stream or 0)
+        _allreduce_pair(buf[off:off + 2])
+        return 0
+    except Exception:  # (an exception must not unwind through the C frames)
+        import traceback
+        traceback.print_exc()
+        return 1
+
+
+_BN_SYNC_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)(_bn_sync)
+
+
+def _bn_sync_fields(d, device):
+    """Fills the global-batch-exact BatchNorm fields of a d2r_interaction_desc (no-op outside that mode)."""
+    if DP_EXACT is None:
+        d.bn_sync, d.bn_sync_buf = None, None
+        return None
+    buf = torch.zeros(4 * d.nlayer, dtype=torch.float64, device=device)
+    _BN_SYNC_BUFS[id(buf)] = buf
+    d.bn_sync = C.cast(_BN_SYNC_CB, C.c_void_p)
+    d.bn_sync_user, d.bn_sync_buf, d.bn_world = id(buf), buf.data_ptr(), DP_EXACT[1]
+    return buf
+
+
 def matmul_nt(a, b):
     return _MatmulNT.apply(a, b)
 
@@ -630,8 +703,8 @@ def matmul_nt(a, b):
 # attention: O = softmax(scale * Q K^T + mask) V (+ residual), H heads; logits kept fp32
 # ------------------------------------------------------------------------------------------------------
 DETERMINISTIC = os.environ.get("D2R_DETERMINISTIC", "0") == "1"  # serialise the two routing modules' backward passes (bit-reproducible steps)
-FUSED_MHA = os.environ.get("D2R_FUSED_MHA", "1") != "0"  # 0: three-launch path (the only one for fp32)
-FUSED_XATTN = os.environ.get("D2R_FUSED_XATTN", "1") != "0"
+FUSED_MHA = True  # 0: three-launch path (the only one for fp32)
+FUSED_XATTN = True
 
 
 def _attn_fwd(q, k, v, geo, H, scale, mask, residual, dtype, device, p_drop=0.0):
@@ -1067,9 +1140,10 @@ class _Interaction(torch.autograd.Function):
         ws = _workspace(64 << 20, own.device)
         d.own, d.other, d.out, d.paths = own.data_ptr(), other.data_ptr(), out.data_ptr(), paths.data_ptr()
         d.arena, d.arena_bytes, d.splitk_ws, d.splitk_bytes = arena.data_ptr(), arena.numel(), ws.data_ptr(), ws.numel()
+        bnbuf = _bn_sync_fields(d, own.device)
         _lib.call("d2r_interaction_fwd", C.byref(d), _stream(), meta=dict(group="interaction_fwd"))
         ctx.save_for_backward(own, other, out)
-        ctx.d, ctx.keep, ctx.bundle = d, arena, bundle
+        ctx.d, ctx.keep, ctx.bundle = d, (arena, bnbuf), bundle
         return out, paths
 
     @staticmethod
@@ -1098,6 +1172,8 @@ class _Interaction(torch.autograd.Function):
         d.d_out, d.d_paths, d.d_own, d.d_other = _ptr(d_out), _ptr(d_paths), d_own.data_ptr(), d_other.data_ptr()
         d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
         _lib.call("d2r_interaction_bwd", C.byref(d), _stream(), meta=dict(group="interaction_bwd"))
+        if ctx.keep[1] is not None:
+            _BN_SYNC_BUFS.pop(id(ctx.keep[1]), None)
         ctx.keep = None
         for p in bundle.params:  # data-parallel bucket readiness (d2r_amd.dp): every sink of the module is written now
             cb = getattr(p, "_d2r_ready_cb", None)
@@ -1549,8 +1625,16 @@ class _SafGate(torch.autograd.Function):
         B, n = a.shape
         w = torch.empty_like(a)
         saved = torch.empty(2, dtype=torch.float32, device=a.device)
-        _lib.call("d2r_saf_gate_fwd", a.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(), running_mean.data_ptr(),
-                  running_var.data_ptr(), 1 if train else 0, w.data_ptr(), saved.data_ptr(), _stream())
+        ctx.exact = train and DP_EXACT is not None
+        if ctx.exact:  # statistics over the samples of every rank
+            sums = torch.empty(2, dtype=torch.float64, device=a.device)
+            _lib.call("d2r_saf_gate_stats", a.data_ptr(), B, n, sums.data_ptr(), _stream())
+            _allreduce_pair(sums)
+            _lib.call("d2r_saf_gate_fwd_ex", a.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(), running_mean.data_ptr(),
+                      running_var.data_ptr(), 1, w.data_ptr(), saved.data_ptr(), sums.data_ptr(), float(DP_EXACT[1] * B * n), _stream())
+        else:
+            _lib.call("d2r_saf_gate_fwd", a.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(), running_mean.data_ptr(),
+                      running_var.data_ptr(), 1 if train else 0, w.data_ptr(), saved.data_ptr(), _stream())
         ctx.save_for_backward(a, bn_w, bn_b, saved)
         ctx.train = train
         return w
@@ -1562,6 +1646,15 @@ class _SafGate(torch.autograd.Function):
         B, n = a.shape
         da = torch.empty_like(a)
         dbw, dbb = torch.empty_like(bn_w), torch.empty_like(bn_b)
+        if ctx.exact:
+            gs = torch.empty(2, dtype=torch.float64, device=a.device)
+            nt = float(DP_EXACT[1] * B * n)
+            _lib.call("d2r_saf_gate_bwd_ex", a.data_ptr(), dw.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(), saved.data_ptr(), 1,
+                      da.data_ptr(), dbw.data_ptr(), dbb.data_ptr(), 1, gs.data_ptr(), nt, _stream())
+            _allreduce_pair(gs)
+            _lib.call("d2r_saf_gate_bwd_ex", a.data_ptr(), None, B, n, bn_w.data_ptr(), bn_b.data_ptr(), saved.data_ptr(), 1,
+                      da.data_ptr(), None, None, 2, gs.data_ptr(), nt, _stream())
+            return da, dbw, dbb, None, None, None
         _lib.call("d2r_saf_gate_bwd", a.data_ptr(), dw.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(),
                   saved.data_ptr(), 1 if ctx.train else 0, da.data_ptr(), dbw.data_ptr(), dbb.data_ptr(), _stream())
         return da, dbw, dbb, None, None, None

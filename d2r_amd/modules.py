@@ -523,6 +523,7 @@ class _InteractionBase(D2RModule):
                 for layer in [self.dynamic_itr_l0, *self.dynamic_itr_l1, self.dynamic_itr_l2]:
                     if "glac" in layer.cell_names:
                         layer.glac.SAF_module.bn.num_batches_tracked += 1
+            paths = F.gather_batch(paths)  # (global-batch-exact data parallelism: the paths of every rank's samples)
             return [out], F.matmul_nt(paths, paths)
         B = text.shape[0]
         layers = [self.dynamic_itr_l0, *self.dynamic_itr_l1, self.dynamic_itr_l2]
@@ -538,7 +539,7 @@ class _InteractionBase(D2RModule):
             plist.append(pm.reshape(B, -1))
         out, pf = self.dynamic_itr_l2(refs, text, image, kvs[-1])
         plist.append(pf.reshape(B, -1))
-        paths = torch.cat(plist, dim=-1)  # fp32 [B, 36(DR-1)+6]; DR_step=2 (extension): cat(l0, l2)
+        paths = F.gather_batch(torch.cat(plist, dim=-1))  # fp32 [B, 36(DR-1)+6]; DR_step=2 (extension): cat(l0, l2)
         return out, F.matmul_nt(paths, paths)
 
 
@@ -554,11 +555,11 @@ class Reversed_InteractionModule(_InteractionBase):
 # ------------------------------------------------------------------------------------------------------
 # encoders
 # ------------------------------------------------------------------------------------------------------
-EARLY_SELF_LAYERS = os.environ.get("D2R_EARLY_SELF", "1") != "0"
-INTERLEAVE_ENCODERS = os.environ.get("D2R_INTERLEAVE", "1") != "0"  # issue the two encoders layer by layer in alternation
-COMPOSITE_LAYERS = os.environ.get("D2R_COMPOSITE", "1") != "0"  # whole encoder layers as one C call (bf16 only)
-COMPOSITE_HEAD = os.environ.get("D2R_COMPOSITE_HEAD", "1") != "0"  # Block fusion + fc + cross entropy + loss as one C call each way (fp32)
-COMPOSITE_ROUTING = os.environ.get("D2R_COMPOSITE_ROUTING", "1") != "0"  # whole interaction modules as one C call (bf16 only)
+EARLY_SELF_LAYERS = True
+INTERLEAVE_ENCODERS = True  # issue the two encoders layer by layer in alternation
+COMPOSITE_LAYERS = True  # whole encoder layers as one C call (bf16 only)
+COMPOSITE_HEAD = True  # Block fusion + fc + cross entropy + loss as one C call each way (fp32)
+COMPOSITE_ROUTING = True  # whole interaction modules as one C call (bf16 only)
 
 
 def _layer_bundle(layer, x):
@@ -781,17 +782,13 @@ class UnimoEncoder(D2RModule):
         self.vision_layers = nn.ModuleList([CLIPEncoderLayer(vision_config) for _ in range(vision_config.num_hidden_layers)])
         self.text_layer = nn.ModuleList([BertLayer(text_config) for _ in range(text_config.num_hidden_layers)])
 
-    def run_vision(self, v, gate=None):
-        for i, layer in enumerate(self.vision_layers):
-            if gate is not None:
-                gate("vision", i)  # (FusedAdamW.overlap_with_forward: this layer's weights of the previous step's update are in place)
+    def run_vision(self, v):
+        for layer in self.vision_layers:
             v = layer(v)
         return v
 
-    def run_text(self, t, key_mask, gate=None):
-        for i, layer in enumerate(self.text_layer):
-            if gate is not None:
-                gate("text", i)
+    def run_text(self, t, key_mask):
+        for layer in self.text_layer:
             t = layer(t, key_mask)
         return t
 
@@ -854,7 +851,6 @@ class UnimoModel(D2RModule):
         self.text_pooler = BertPooler() if add_pooling_layer else None  # dead (ingest assert needs it)
         self.use_streams = os.environ.get("D2R_STREAMS", "1") != "0"
         self._streams = None
-        self._param_gate = None  # set by FusedAdamW.overlap_with_forward(model)
 
     def _head_bundle(self, fc):
         """The cached HeadBundle when the one-call head applies (fp32 parameters with gradient sinks, the 20 + 20 merge groups
@@ -895,10 +891,7 @@ class UnimoModel(D2RModule):
         if two:
             main = torch.cuda.current_stream()
             if self._streams is None:
-                # (D2R_STREAM_PRIO: priority of the two branch streams; -1 = above the optimiser stream of
-                #  FusedAdamW.overlap_with_forward, whose HBM-bound workgroups then only take the slots the branches leave free)
-                prio = int(os.environ.get("D2R_STREAM_PRIO", "0"))
-                self._streams = (torch.cuda.Stream(priority=prio), torch.cuda.Stream(priority=prio))
+                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
                 for st in self._streams:
                     F.register_compute_stream(st)  # joined at the end of every backward pass
             sT, sV = self._streams
@@ -910,16 +903,9 @@ class UnimoModel(D2RModule):
             sV.wait_stream(main)
         else:
             on_t = on_v = contextlib.nullcontext
-        # Optional gate of FusedAdamW.overlap_with_forward(): the previous step's parameter update runs on its own stream, chunk by
-        # chunk in the order the forward pass needs the weights; a gate makes the CURRENT stream wait for the chunk it names.
-        gate = self._param_gate
         with on_v():
-            if gate is not None:
-                gate("vision", -1)
             v_enc = self.vision_pre_layrnorm(self.vision_embeddings(pixel_values))
         with on_t():
-            if gate is not None:
-                gate("text", -1)
             t_enc = self.text_embeddings(input_ids, token_type_ids)
         if two and INTERLEAVE_ENCODERS:
             # The host needs about as long to enqueue a step as the GPU needs to run it: a whole encoder issued before the other
@@ -927,31 +913,23 @@ class UnimoModel(D2RModule):
             # layer i + 1 of either (autograd replays the same alternation backwards).
             for i, (lv, lt) in enumerate(zip(self.encoder.vision_layers, self.encoder.text_layer)):
                 with on_v():
-                    if gate is not None:
-                        gate("vision", i)
                     v_enc = lv(v_enc)
                 with on_t():
-                    if gate is not None:
-                        gate("text", i)
                     t_enc = lt(t_enc, key_mask)
         else:
             with on_v():
-                v_enc = self.encoder.run_vision(v_enc, gate)
+                v_enc = self.encoder.run_vision(v_enc)
             with on_t():
-                t_enc = self.encoder.run_text(t_enc, key_mask, gate)
+                t_enc = self.encoder.run_text(t_enc, key_mask)
         # The extra self layers and cls poolers read their OWN encoder's output only: issued in front of the barrier, the shorter
         # branch (text: 128 tokens against 197) runs them while the other encoder is still busy (EARLY_SELF_LAYERS = False: behind it).
         def self_layers():
             with on_t():
-                if gate is not None:
-                    gate("all", 0)
                 t_out = t_enc
                 for layer in self.self_text:
                     t_out = layer(t_out, key_mask)
                 tc = self.text_cls_pool(t_out, fp32=True)
             with on_v():
-                if gate is not None:
-                    gate("all", 0)
                 v_out = v_enc
                 for layer in self.self_vision:
                     v_out = layer(v_out)
@@ -975,10 +953,12 @@ class UnimoModel(D2RModule):
             t_cls, v_cls = self_layers()
         with on_t():
             (emb_t,), sim_paths = self.itr_module(t_enc, v_enc)
+            t_cls = F.gather_batch(t_cls)  # (global-batch-exact data parallelism: the [B,B] matrices span the global batch)
             js1 = F.js_div(sim_paths, F.matmul_nt(t_cls, t_cls))
             tp = self.text_pool(emb_t, fp32=True)
         with on_v():
             (emb_v,), rev_sim_paths = self.Reversed_itr_module(t_enc, v_enc)
+            v_cls = F.gather_batch(v_cls)
             js2 = F.js_div(rev_sim_paths, F.matmul_nt(v_cls, v_cls))
             vp_ = self.vision_pool(emb_v, fp32=True)
         if two:

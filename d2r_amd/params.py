@@ -179,9 +179,6 @@ class ParamStore:
     def zero_grad(self):
         from .functional import wgrad_join
         wgrad_join()  # weight-gradient GEMMs of the step may still be accumulating on their side streams
-        guard = getattr(self, "_zero_guard", None)
-        if guard is not None:
-            guard()  # (FusedAdamW.overlap_with_forward: the update on the optimiser stream still reads the gradients)
         self.flat_g.zero_()  # one memset node
 
     def live_numel(self) -> int:
@@ -207,7 +204,6 @@ class FusedAdamW:
         self.element_ranges = None
         self.shard_gather = None
         self.dp_group = None
-        self._defer = None  # overlap_with_forward()
         names = {0: "other", 1: "text", 2: "vision", 3: "fc"}
         self.param_groups = []
         for g, (a, b) in sorted(store.group_ranges.items()):
@@ -218,15 +214,6 @@ class FusedAdamW:
             self._hyper_buffers()
 
     def zero_grad(self, set_to_none: bool = False):
-        D = getattr(self, "_defer", None)
-        if D is not None and D["pending"]:  # behind the update on its stream; "everything" is done when the buffer is clear
-            # (also behind whatever the launching stream and, through its join, the branch streams wrote since: a zero_grad() that
-            #  follows a backward pass without a step in between must not clear the buffer under those writes)
-            D["stream"].wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(D["stream"]):
-                self.store.zero_grad()
-                D["all"].record()
-            return
         self.store.zero_grad()
 
     # -- loss scaling for the fp16 compute dtype (the job torch.cuda.amp.GradScaler does for the reference's users) ----------
@@ -305,76 +292,9 @@ class FusedAdamW:
                 out.append((x, y))
         return out
 
-    # -- the update overlapped with the NEXT forward pass --------------------------------------------------------------------------
-    def overlap_with_forward(self, model, chunks: int = 4):
-        """The AdamW pass is pure HBM traffic (30 bytes per parameter, 1.9 ms for 353.6 M parameters) with nothing beside it at the
-        end of a step, while the forward pass that follows is MFMA- and L2-bound.  After this call ``step()`` issues the update on
-        its own HIP stream in the order the forward pass consumes the weights - the two encoder groups in `chunks` pieces each
-        (embeddings + first layers first, text and vision alternating), then everything else - and ``zero_grad()`` follows on the
-        same stream.  The model's forward waits, on the stream that is about to read them, for exactly the piece it needs
-        (UnimoModel._param_gate): encoder layer i for its chunk, everything behind the encoders for the whole update.  The
-        arithmetic is the same launches over the same elements: results are bit-identical to the plain step.
-        Anything else that reads parameters or moments on another stream calls ``join()`` first (state_dict() does)."""
-        if self.element_ranges is not None:
-            raise ValueError("overlap_with_forward() and the sharded optimiser exclude each other (the weight all-gather needs the whole update)")
-        inner = model.model if hasattr(model, "model") and hasattr(model.model, "_param_gate") else model
-        if not hasattr(inner, "_param_gate"):
-            raise ValueError("overlap_with_forward(): the model has no parameter gate (UnimoModel)")
-        st = self.store
-        firsts = {"text": {}, "vision": {}}  # layer index -> flat offset of the layer's first parameter
-        for name, _, off, _, g in st.entries:
-            for kind, key in (("text", ".encoder.text_layer."), ("vision", ".encoder.vision_layers.")):
-                if key in name and g == (1 if kind == "text" else 2):
-                    i = int(name.split(key)[1].split(".")[0])
-                    firsts[kind][i] = min(firsts[kind].get(i, off), off)
-        plan, chunk_of = [], {}
-        per_kind = {}
-        for kind, gi in (("text", 1), ("vision", 2)):
-            pg = next((p for p in self.param_groups if p["name"] == kind), None)
-            if pg is None or not firsts[kind]:
-                continue
-            a, b = pg["range"]
-            nl = max(firsts[kind]) + 1
-            c = max(1, min(int(chunks), nl))
-            cuts = [firsts[kind][(nl * k) // c] for k in range(1, c)]  # chunk k starts at layer nl*k/c
-            bounds = [a] + cuts + [b]
-            assert all(x < y for x, y in zip(bounds, bounds[1:])) and all((x - a) % 4 == 0 for x in cuts), bounds
-            per_kind[kind] = [((kind, k), pg, bounds[k], bounds[k + 1]) for k in range(c)]
-            chunk_of[kind] = [min(c - 1, (i * c) // nl) for i in range(nl)]
-        for k in range(max((len(v) for v in per_kind.values()), default=0)):
-            for kind in ("text", "vision"):
-                if kind in per_kind and k < len(per_kind[kind]):
-                    plan.append(per_kind[kind][k])
-        for pg in self.param_groups:
-            if pg["name"] not in per_kind and pg["range"][1] > pg["range"][0]:
-                plan.append((("rest", pg["name"]), pg, pg["range"][0], pg["range"][1]))
-        import os
-        self._defer = dict(stream=torch.cuda.Stream(priority=int(os.environ.get("D2R_OPT_PRIO", "0"))), plan=plan, chunk_of=chunk_of, pending=False,
-                           events={tag: torch.cuda.Event() for tag, _, _, _ in plan}, all=torch.cuda.Event())
-        st._zero_guard = self.join  # a direct ParamStore.zero_grad() on another stream first waits for the update
-        inner._param_gate = self._gate
-
-    def _gate(self, kind, layer):
-        D = self._defer
-        if D is None or not D["pending"]:
-            return
-        cur = torch.cuda.current_stream()
-        if kind in D["chunk_of"]:
-            cur.wait_event(D["events"][(kind, D["chunk_of"][kind][max(layer, 0)])])
-        else:
-            cur.wait_event(D["all"])
-
-    def join(self):
-        """The current stream waits for an update (and zero_grad) still running on the optimiser stream."""
-        D = getattr(self, "_defer", None)
-        if D is not None and D["pending"]:
-            torch.cuda.current_stream().wait_stream(D["stream"])
-
     def step(self):
         from .functional import wgrad_join
         wgrad_join()
-        if getattr(self, "_defer", None) is not None:
-            return self._step_overlapped()
         used = self.loss_scale  # the scale this step's backward ran with (the host may change it below)
         skip = None
         if self._scaler is not None:
@@ -388,28 +308,6 @@ class FusedAdamW:
                 _lib.call("d2r_adamw_step", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
                           self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, st.lp_dtype, b - a, pg["lr"], self.betas[0],
                           self.betas[1], self.eps, pg["weight_decay"], self.step_count, self.grad_scale / used, skip, _stream())
-        if self._scaler is not None:
-            self._scaler_after_step()
-
-    def _step_overlapped(self):
-        D = self._defer
-        used = self.loss_scale
-        skip = None
-        if self._scaler is not None:
-            self._scaler_before_step()  # (launching stream: the non-finite check needs every gradient)
-            skip = self._scaler["flag"].data_ptr()
-        self.step_count += 1
-        st = self.store
-        D["stream"].wait_stream(torch.cuda.current_stream())  # every gradient is final, the skip flag is set
-        with torch.cuda.stream(D["stream"]):
-            for tag, pg, a, b in D["plan"]:
-                lp = None if st.flat_lp is None else st.flat_lp.data_ptr() + 2 * a
-                _lib.call("d2r_adamw_step", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
-                          self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, st.lp_dtype, b - a, pg["lr"], self.betas[0],
-                          self.betas[1], self.eps, pg["weight_decay"], self.step_count, self.grad_scale / used, skip, _stream())
-                D["events"][tag].record()
-            D["all"].record()
-        D["pending"] = True
         if self._scaler is not None:
             self._scaler_after_step()
 
@@ -451,7 +349,6 @@ class FusedAdamW:
     def state_dict(self):
         """Under the sharded optimiser a rank's moments are current for its own stripes only: they are all-gathered first (a
         collective - every rank must call state_dict()), so that the result is the same complete state on every rank."""
-        self.join()
         if self.element_ranges is not None and self.shard_gather is not None:
             self.shard_gather(self.m)
             self.shard_gather(self.v)

@@ -94,8 +94,6 @@ class MSDTrainer:
                                grad_comm_dtype=torch.bfloat16 if getattr(self.args, "dp_grad_comm", "f32") == "bf16" else torch.float32,
                                shard_optimizer=shard, algorithm=getattr(self.args, "dp_algorithm", "all_reduce"))
         self.dp.broadcast_parameters()
-        if not shard and os.environ.get("D2R_OPT_OVERLAP", "0") == "1":  # (opt-in: measured no gain on MI355X)
-            self.optimizer.overlap_with_forward(self.model)  # the update of step N runs beside the forward pass of step N+1
         if self.train_data is not None:
             self.scheduler = LinearWarmupSchedule(self.optimizer, self.args.warmup_ratio * self.train_num_steps,
                                                   self.train_num_steps)
@@ -194,7 +192,6 @@ class MSDTrainer:
         # Data parallel: every rank evaluates the WHOLE dev set (the loaders of d2r_amd.run shard only the training set), on
         # identical weights and — after the line below — identical BatchNorm running statistics, so every rank takes the
         # same best-model decision and rank 0's checkpoint is the model all ranks hold.
-        self.optimizer.join()  # (an overlapped update may still be running on the optimiser stream)
         self.dp.sync_buffers()
         self.model.eval()
         self.logger.info("***** Running evaluate *****")

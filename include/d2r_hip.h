@@ -16,7 +16,7 @@
  *   - dtype of activations/weights `T` is D2R_F32, D2R_BF16 or D2R_F16 (IEEE half: BASELINE.json configs[4]); every
  *     entry point that says "16-bit" takes either of the two and runs the same kernel with the other MFMA operand type;
  *     accumulation, softmax statistics, router logits, biases, LayerNorm parameters and all reductions are fp32;
- *   - deterministic: fixed reduction order, no float atomics except the embedding-table scatter-add.
+ *   - deterministic: fixed reduction order, no float atomics anywhere (the embedding-table gradient is a fixed-order gather-sum).
  */
 #ifndef D2R_HIP_H
 #define D2R_HIP_H
@@ -124,23 +124,8 @@ int d2r_gemm_tn_grouped(int dtype, int M, int N, int K, int64_t lda, int64_t ldb
 int d2r_gemm_tn_grouped_v(int dtype, int count, const int* M, const int* N, const int* K, const int64_t* lda, const int64_t* ldb,
                           const int64_t* ldc, const void* const* h_A, const void* const* h_B, float* const* h_C, float* const* h_dbias,
                           float beta, void* stream);
-/* tuning switches for A/B measurements (tests/bench_gemm.py): LDS buffers (1|2), vectorised bf16 epilogue (0|1),
- * forced tile (-1 auto, 1: 64x64, 2: 128x64, 3: 128x128, 4..9 / 100..101: LDS-DMA variants).  Defaults are the measured
- * winners.  Debug aid: the setting (like the D2R_GEMM_* environment switches read at load time) is PROCESS-GLOBAL and not
- * thread-safe; the rest of the ABI carries no state between calls. */
-void d2r_gemm_tuning(int nbuf, int vepi, int tile);
-/* Measurement aid (bench.py's roofline leg; NOT part of the drop-in surface, not thread-safe against concurrent reads):
- * while on, d2r_gemm and d2r_gemm_tn_grouped - including the calls made inside the whole-layer / whole-module entry points -
- * bracket each launch with HIP events on the launching stream.  d2r_gemm_timer(1) clears and arms, d2r_gemm_timer(0)
- * disarms; d2r_gemm_timer_read waits for the recorded events and returns per launch: family = dtype * 8 + layout * 2 +
- * grouped + 100 * kernel variant (0 generic tiles, 1 LDS-DMA 128x64, 2 / 3 LDS-DMA 128x128 on four / eight waves, 20 grouped
- * LDS-DMA weight gradients, 21 grouped generic, 22 grouped batched 16-bit, 30 skinny fp32, 31 skinny 16-bit), flops, algorithmic bytes (operands
- * once, output once, twice when accumulated), milliseconds.  The single-head attention entry points record as well: family
- * 10001 = d2r_xattn_fwd_multi (one launch), 10002 = d2r_xattn_bwd_multi (its launches together; bytes = 2 x forward).  Returns the
- * number of records copied (or, with family == NULL, the number pending, which it discards). */
-int d2r_gemm_timer(int on);
-int d2r_gemm_timer_read(int* family, double* flops, double* bytes, float* ms, int capacity);
-
+/* (measurement aids - per-launch timers, kernel-choice overrides, cycle stamps - are declared in d2r_hip_probes.h: not part of the
+ * drop-in surface, process-global, not thread-safe; the library itself reads no environment variable) */
 /* Data parallelism: there is deliberately NO d2r_comm_* entry point.  The gradient reduction of the path is a sum of the flat
  * fp32 gradient buffer over ranks; the host side (d2r_amd/dp.py) issues it as bucketed torch.distributed collectives - RCCL
  * all-reduce, or reduce-scatter + all-gather per bucket - on a communication stream ordered behind the compute streams.  The
@@ -258,6 +243,18 @@ int d2r_saf_gate_fwd(const float* a, int B, int n, const float* bn_weight, const
                      void* stream);
 int d2r_saf_gate_bwd(const float* a, const float* dw, int B, int n, const float* bn_weight, const float* bn_bias,
                      const float* saved, int train, float* da, float* d_bn_weight, float* d_bn_bias, void* stream);
+/* Global-batch-exact BatchNorm under data parallelism ("optional"): the reference's BatchNorm1d(1) normalises over all
+ * B*(Lq+1) scores of the WHOLE batch (models/XModules.py:376,381).  d2r_saf_gate_stats leaves this rank's fp64 sums {sum a, sum a^2}
+ * in `sums`; the caller all-reduces them over the ranks and passes the totals (and the global element count) to d2r_saf_gate_fwd_ex.
+ * Backward: phase 1 of d2r_saf_gate_bwd_ex stops behind the sigmoid / l1norm part (d y in `da`, this rank's share of the BatchNorm
+ * parameter gradients in d_bn_weight / d_bn_bias, fp64 {sum dy, sum dy*xhat} in gsums); after the all-reduce phase 2 finishes `da`
+ * with the global sums.  gstats = NULL / phase 0: local-batch statistics (= d2r_saf_gate_fwd / _bwd). */
+int d2r_saf_gate_stats(const float* a, int B, int n, double* sums, void* stream);
+int d2r_saf_gate_fwd_ex(const float* a, int B, int n, const float* bn_weight, const float* bn_bias, float* running_mean,
+                        float* running_var, int train, float* w, float* saved, const double* gstats, double ntotal, void* stream);
+int d2r_saf_gate_bwd_ex(const float* a, const float* dw, int B, int n, const float* bn_weight, const float* bn_bias,
+                        const float* saved, int train, float* da, float* d_bn_weight, float* d_bn_bias, int phase, double* gsums,
+                        double ntotal, void* stream);
 
 /* The two rank-one products around the gate in the BACKWARD pass of the SAF-weighted sum wsum[b] = w[b] @ S[b]
  * (models/XModules.py:382-384; S [B,n,E], 16-bit): dw[b,i] = <dwsum[b,:], S[b,i,:]> (fp32 [B,n]) and
@@ -483,6 +480,15 @@ typedef struct {
    * (`other` is the same tensor in every layer, models/DynamicInteraction.py:95-102): one GEMM with N = 13,824 at DR_step 3 in
    * the forward pass, one dX and one dW product in the backward pass.  The D2R_RL_*_KV entries of `layers` are then unused. */
   d2r_linear_params kv_all;
+  /* Optional, data parallelism in the global-batch-exact mode: the BatchNorm1d(1) of every GLAC cell takes its statistics over the
+   * samples of ALL ranks.  bn_sync(user, pair, stream) must SUM the two fp64 values at the device address `pair` over the ranks,
+   * ordered on `stream` (e.g. an RCCL all-reduce), and return 0; it is called twice per routing layer and direction from inside the
+   * call (the library itself has no communication).  bn_sync_buf: device scratch of 4 doubles per routing layer; bn_world: number
+   * of ranks (the global score count is bn_world * B * (Lq + 1)).  bn_sync = NULL: local-batch statistics. */
+  int (*bn_sync)(void* user, double* pair, void* stream);
+  void* bn_sync_user;
+  double* bn_sync_buf;
+  int bn_world;
 } d2r_interaction_desc;
 int d2r_interaction_supported(int dtype, int Lq, int Lk, int ncell, int heads_imrc);
 size_t d2r_interaction_arena_bytes(int B, int Lq, int Lk, int ncell, int nlayer, int hid_router, int hid_imrc);

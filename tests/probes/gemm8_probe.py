@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 if "stamps" in sys.argv[1:]:  # the measurement build (D2R_G8_STAMPS=1 python -m d2r_amd.build, copied beside this file)
     _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libd2r_hip_stamps.so")
 lib = _lib.load()
-VARS = [int(v) for v in os.environ.get("G8_VARS", "0,1").split(",")]
+VARS = [0]  # (a second loop variant - DMA issue inside the MFMA cluster - was measured slower and removed: profiles/gemm8_probe_r04.log "v1")
 args = sys.argv[1:]
 do_check = "check" in args or not any(a in args for a in ("check", "time", "stamps"))
 do_time = "time" in args or not any(a in args for a in ("check", "time", "stamps"))
@@ -165,7 +165,6 @@ def time_fwd():
                     for v in [-1] + VARS:
                         lib.d2r_gemm_tuning(1, 1, 110 if v < 0 else 111)  # -1: the 128-wide kernels' own choice, else the wide tiles forced
                         lib.d2r_gemm_tuning(1, 1, -1 if v < 0 else 11)
-                        lib.d2r_gemm8_variant(max(v, 0))
                         res.setdefault(v, []).append(timeit(run))
                 tt = timeit((lambda: torch.matmul(a, b.t())) if layout == GEMM_NT else (lambda: torch.matmul(a, b)))
                 fl = 2.0 * M * N * K
@@ -195,7 +194,6 @@ def time_tn():
             for rnd in range(2):
                 for v in [-1] + VARS:
                     lib.d2r_gemm_tuning(1, 1, 102 if v < 0 else 103)
-                    lib.d2r_gemm8_variant(max(v, 0))
                     res.setdefault(v, []).append(timeit(call, 10))
             out.append(f"beta={beta:.0f}: 128-wide {min(res[-1]) * 1e6:7.1f} us {fl / min(res[-1]) / 1e12:5.0f} TF | " +
                        " | ".join(f"gemm8 v{v} {min(res[v]) * 1e6:7.1f} us {fl / min(res[v]) / 1e12:5.0f} TF" for v in VARS))
@@ -212,7 +210,6 @@ def stamps():
     lib.d2r_gemm8_debug_stamps(C.c_void_p(buf.data_ptr()))
     td = torch.bfloat16
     for v in VARS:
-        lib.d2r_gemm8_variant(v)
         lib.d2r_gemm_tuning(1, 1, 11)
         for name in ("NT 4096x4096x4096", "NT 4096x3072x768", "TN encoder 7 layers T=4096"):
             if name.startswith("NT"):
@@ -250,7 +247,6 @@ if "stamps" in args:
     sys.exit(0)
 if do_check:
     for v in VARS:
-        lib.d2r_gemm8_variant(v)
         print(f"--- kernel variant {v}", flush=True)
         bad += check_fwd()
         if "TN" in lay:

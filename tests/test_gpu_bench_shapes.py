@@ -446,3 +446,44 @@ def test_tumemo_and_stress_shapes_vs_oracle(gpu, shape, mode):
         assert e_logit <= 1e-3 and e_loss <= 1e-3 and cos >= 0.98, (e_logit, e_loss, cos)
     else:
         assert e_logit <= 5e-3 and e_loss <= 5e-3 and cos >= 0.85, (e_logit, e_loss, cos)  # measured 1.1e-3 / 3.9e-4 / 0.90
+
+
+@pytest.mark.parametrize("shape,batch", [(C4, 8), (C5, 16)], ids=["C4-shard", "C5-shard"])
+def test_full_depth_model_at_the_per_gpu_shard_is_finite_and_bit_reproducible(gpu, shape, batch):
+    """BASELINE configs[3] / configs[4] run on 8 GPUs with a global batch of 64 / 128: the PER-GPU shard (8 / 16 samples) of the FULL model
+    (12 + 12 encoder layers) in the 16-bit dtype the config names, forward + backward, twice from the same state - the host oracle cannot
+    run these sizes in test time, so the properties checked are size-independent: every output and every parameter gradient is finite,
+    no live parameter is left without a gradient, and the two passes agree bit for bit (one compute stream: fixed reduction orders, no
+    float atomics; with the two branch streams the step is covered by test_training_step_is_bit_reproducible_with_the_two_branch_streams)."""
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    from bench import synthetic_batch
+    c = shape
+    dtype = c["lowp"]
+    torch.manual_seed(2023)
+    tc = TextConfig(num_hidden_layers=12, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vc = VisionConfig(num_hidden_layers=12, image_size=c["image_size"], patch_size=c["patch"])
+    model = M.UnimoModelF(default_args(DR_step=c["dr"], num_cells=c["cells"]), vc, tc, num_classes=c["classes"])
+    model.to(gpu).set_compute_dtype(dtype).train()
+    model.model.use_streams = False
+    store = ParamStore(model, dtype)
+    data = synthetic_batch(batch, c["seq"], c["image_size"], gpu, seed=3, classes=c["classes"])
+    lscale = 1024.0 if dtype == torch.float16 else 1.0
+    runs = []
+    for _ in range(2):
+        store.zero_grad()
+        loss, logits = model(*data)
+        (loss * lscale).backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), logits.detach().clone(), store.flat_g.clone()))
+    (l0, g0, f0), (l1, g1, f1) = runs
+    assert logits.shape == (batch, c["classes"]) and bool(torch.isfinite(l0)) and bool(torch.isfinite(g0).all())
+    assert bool(torch.isfinite(f0).all()), "non-finite parameter gradient"
+    dead = [n for n, _, o, k, _ in store.entries if float(f0[o:o + k].abs().max()) == 0.0]
+    # (key biases in front of a softmax and the like have a mathematically zero gradient but still receive rounding noise; a tensor
+    #  that is exactly zero would mean its backward never ran)
+    assert not dead, f"live parameters without a gradient: {dead[:6]}"
+    assert torch.equal(l0, l1) and torch.equal(g0, g1), "forward pass is not reproducible"
+    bad = [n for n, _, o, k, _ in store.entries if not torch.equal(f0[o:o + k], f1[o:o + k])]
+    assert not bad, f"{len(bad)} parameter gradients differ between two identical passes, first {bad[:5]}"

@@ -196,7 +196,7 @@ def test_cli_smoke(gpu, tmp_path):
     assert "Test Eval results" in r.stderr and os.path.exists(os.path.join(str(tmp_path), "best_model.pth"))
 
 
-def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4, layers=1, overlap_chunks=0, dtype=torch.bfloat16):
+def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4, layers=1, dtype=torch.bfloat16):
     from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
     model, args = _tiny(dtype, layers=layers)
     model.load_state_dict(sd, strict=True)
@@ -207,8 +207,6 @@ def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4, layers=1, overlap_ch
     opt = FusedAdamW(store, lr=1e-3)
     if dtype == torch.float16:
         opt.enable_loss_scaling(init_scale=2.0 ** 10)
-    if overlap_chunks:
-        opt.overlap_with_forward(model, chunks=overlap_chunks)
     sched = LinearWarmupSchedule(opt, 2, 10)
     losses = []
     if not use_graph:
@@ -262,26 +260,6 @@ def test_streams_and_graph_replay_are_bit_identical_to_single_stream_eager(gpu):
                 bad = (a != b).nonzero().flatten()
                 names = sorted({n for n, o, k in got[4] if ((bad >= o) & (bad < o + k)).any()})
                 raise AssertionError(f"{tag}: {what} differs in {bad.numel()} elements of {names[:12]} ({len(names)} tensors)")
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-def test_update_overlapped_with_the_next_forward_is_bit_identical(gpu, dtype):
-    """FusedAdamW.overlap_with_forward: the update of step N on its own stream, chunk by chunk in forward order, the forward pass
-    of step N+1 gated per encoder layer, zero_grad behind the update - against the plain step (same launches, same elements:
-    weights, moments and losses must agree exactly), with one and two compute streams, and with the fp16 loss scaler (whose
-    non-finite check has to precede every piece of the update)."""
-    from oracle import d2r_oracle as O
-    cfg = O.OracleConfig(text_layers=3, vision_layers=3, image_size=64, patch_size=32)
-    sd = O.seeded_state_dict(cfg, seed=5, router_bias="normal")
-    batch = tuple(t.to(gpu) for t in O.synthetic_batch(cfg, 4, 12, seed=9))
-    base = _run_steps(gpu, sd, batch, False, False, n=5, layers=3, dtype=dtype)
-    assert base[0][-1] != base[0][0]
-    for chunks, use_streams in ((1, False), (2, True), (3, True)):
-        got = _run_steps(gpu, sd, batch, False, use_streams, n=5, layers=3, overlap_chunks=chunks, dtype=dtype)
-        tag = f"chunks={chunks} streams={use_streams}"
-        assert got[0] == base[0], (tag, got[0], base[0])
-        for what, a, b in zip(("w", "m", "v"), got[1:4], base[1:4]):
-            assert torch.equal(a, b), f"{tag}: {what} differs in {int((a != b).sum())} elements"
 
 
 def test_data_parallel_two_ranks_on_one_gpu(gpu, tmp_path):
@@ -355,3 +333,104 @@ def test_rccl_collectives_execute_on_one_rank(gpu, tmp_path):
     assert res["same_rs_ag"], "in-place reduce_scatter_tensor + all_gather_into_tensor (one rank) changed the result"
     assert res["same_shard"] and res["same_shard_overlap"], "the sharded optimiser over RCCL (one rank) changed the result"
     assert res["cos_bf16"] >= 0.9 and all(l == l for l in res["losses_bf16"]), (res["cos_bf16"], res["losses_bf16"])
+
+
+@pytest.mark.parametrize("lowp", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_fifty_step_convergence_of_the_16_bit_paths_follows_the_fp32_path(gpu, lowp):
+    """Training fidelity of the benchmarked compute mode beyond single-step gradient statistics: the same model (2 + 2 encoder layers,
+    DR_step 3, default init), the same LEARNABLE synthetic data (the label is a function of the first text token and of the image's
+    mean brightness; 16 batches of 8 visited in the same order) and the same AdamW settings, trained for 50 steps on the fp32 HIP path
+    (the parity reference: its gradients equal the oracle's to 1e-6) and on the 16-bit path (fp16 with the dynamic loss scale, bf16).
+    Checked: both runs learn (mean loss of the last ten steps well below the first ten), no fp16 step is dropped after the scale has
+    settled, and the 16-bit loss curve stays within a band of the fp32 curve step by step."""
+    from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
+    torch.manual_seed(7)
+    model0, _ = _tiny(torch.float32, layers=2)
+    sd = {k: v.detach().clone() for k, v in model0.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    batches = []
+    for _ in range(16):
+        ids = torch.randint(1000, 30000, (8, 16), generator=g)
+        ids[:, 0] = 101
+        key = torch.randint(0, 3, (8,), generator=g)
+        ids[:, 1] = 2000 + key * 7919            # the class is written into the second token ...
+        images = torch.randn(8, 3, 64, 64, generator=g) + (key.float().view(8, 1, 1, 1) - 1.0)  # ... and into the image's brightness
+        batches.append(tuple(t.to(gpu) for t in (ids, torch.ones(8, 16, dtype=torch.long), torch.zeros(8, 16, dtype=torch.long), key, images)))
+
+    def run(dtype):
+        model, _ = _tiny(dtype, layers=2)
+        model.load_state_dict(sd, strict=True)
+        model.to(gpu).train()
+        model.set_compute_dtype(dtype)
+        store = ParamStore(model, dtype)
+        opt = FusedAdamW(store, lr=1e-4, fc_lr=5e-3)
+        if dtype == torch.float16:
+            opt.enable_loss_scaling(init_scale=2.0 ** 12)
+        sched = LinearWarmupSchedule(opt, 5, 60)
+        losses = []
+        for step in range(50):
+            ids, mask, tt, labels, images = batches[step % len(batches)]
+            loss, _ = model(ids, mask, tt, labels, images)
+            opt.backward(loss)
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        skipped = opt._scaler["skipped"] if opt._scaler is not None else 0
+        return losses, skipped
+
+    ref, _ = run(torch.float32)
+    got, skipped = run(lowp)
+    head, tail = sum(ref[:10]) / 10, sum(ref[-10:]) / 10
+    print(f"    [{str(lowp)[6:]}] fp32 loss {head:.4f} -> {tail:.4f}; 16-bit {sum(got[:10]) / 10:.4f} -> {sum(got[-10:]) / 10:.4f}; "
+          f"max |difference| {max(abs(a - b) for a, b in zip(got, ref)):.4f}; dropped steps {skipped}")
+    assert all(l == l and abs(l) < 1e4 for l in got), got
+    assert tail < 0.75 * head, f"the fp32 run did not learn: {head:.4f} -> {tail:.4f}"
+    assert sum(got[-10:]) / 10 < 0.75 * (sum(got[:10]) / 10), "the 16-bit run did not learn"
+    assert skipped <= 2, f"{skipped} fp16 steps dropped by the overflow check"
+    # Band.  The loss falls from ~1.0 to ~-0.1 (the JS term enters with a negative weight) within these 50 steps, steeply in the middle:
+    # rounding differences that compound through the updates show up as a PHASE shift of the descent, so single steps may differ by
+    # a sizeable fraction of the drop (measured on MI355X: 0.16 fp16) while ten-step window means stay within a few hundredths
+    # (measured, fp16 / bf16: 0.024 / 0.021 in the first window, 0.082 / 0.083 in the second - the 16-bit runs trail the fp32 run by
+    # about one step while the loss drops by 0.1-0.2 per step - then 0.015 / 0.027, 0.004 / 0.013 and 0.002 / 0.003 on the plateau).
+    # Window means are held to 12 % of the starting loss, single steps to 25 %, and the last window - where the runs have converged -
+    # to 2 %.
+    scale = max(head, 0.5)
+    worst = max(abs(a - b) for a, b in zip(got, ref))
+    wins = [abs(sum(got[i:i + 10]) - sum(ref[i:i + 10])) / 10 for i in range(0, 50, 10)]
+    curves = "\n    fp32   " + " ".join(f"{v:.3f}" for v in ref) + "\n    16-bit " + " ".join(f"{v:.3f}" for v in got)
+    assert worst <= 0.25 * scale, f"16-bit loss curve leaves the fp32 curve: max |difference| {worst:.4f} (fp32 starts at {head:.4f})" + curves
+    assert max(wins) <= 0.12 * scale, f"ten-step window means differ by {wins} (fp32 starts at {head:.4f})" + curves
+    assert wins[-1] <= 0.02 * scale, f"the plateaus differ by {wins[-1]:.4f}" + curves
+
+
+def test_global_batch_exact_data_parallelism_matches_the_full_batch_oracle(gpu, tmp_path):
+    """SURVEY 8e, the optional exact mode: two ranks (cuda:0, gloo) with half of a global batch of four each reproduce the ORACLE's
+    loss, logits and gradients of the four samples together - BatchNorm1d(1) statistics of the GLAC cells over all ranks' samples
+    (models/XModules.py:376,381), [B,B] similarity matrices and JS loss over the global batch (models/modeling_unimo.py:845-849) -
+    in the fp32 mode (op-by-op path) tightly and in the fp16 mode (whole-module C calls with the bn_sync callback) within its
+    rounding; the default local-statistics mode does not (control)."""
+    import signal
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "probes", "dp_exact_two_ranks.py"), str(tmp_path)]
+    proc = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                            env=dict(os.environ, D2R_PROBE_DUMP_S="150"))
+    try:
+        out, err = proc.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        pytest.fail("the two ranks did not finish in 300 s: hang.\n--- stdout\n" + out[-3000:] + "\n--- stderr\n" + err[-6000:])
+    assert proc.returncode == 0, "exact-mode probe failed\n--- stdout\n" + out[-3000:] + "\n--- stderr\n" + err[-6000:]
+    print(out)
+    for rank in (0, 1):
+        res = torch.load(os.path.join(str(tmp_path), f"rank{rank}.pt"))
+        f32, f16 = res["f32"], res["fp16"]
+        assert f32["e_loss"] <= 2e-5 and f32["e_logit"] <= 2e-5 and f32["cos"] >= 0.9999 and abs(f32["norm_ratio"] - 1.0) <= 1e-3, f32
+        assert f16["e_loss"] <= 1e-3 and f16["e_logit"] <= 1e-3 and f16["cos"] >= 0.98, f16
+        assert res["local_mode_loss_gap"] >= 1e-4, ("the local-statistics mode reproduced the full-batch loss: vacuous test", res["local_mode_loss_gap"])

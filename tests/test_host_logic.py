@@ -147,15 +147,21 @@ def test_ingest_consumes_every_key_of_real_huggingface_checkpoints():
 
 def test_library_exports_every_declared_symbol():
     from d2r_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "d2r_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(d2r_[a-z0-9_]+)\s*\(", hdr))
+    def declared_in(name):
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        return set(re.findall(r"\b(d2r_[a-z0-9_]+)\s*\(", hdr))
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["d2r_hip.h", "d2r_hip_probes.h"]
+    declared = declared_in("d2r_hip.h")           # the drop-in surface
+    probes = declared_in("d2r_hip_probes.h")      # measurement aids
     assert len(declared) >= 40
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert probes == set(_lib.PROBE_SIGNATURES), (probes ^ set(_lib.PROBE_SIGNATURES))
+    declared |= probes
     assert os.path.exists(_lib.LIB_PATH), "libd2r_hip.so missing: run __graft_entry__.build()"
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in include/d2r_hip.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     lib.d2r_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.d2r_version()
     # argument validation works without a GPU (no launch happens): bad layout / null pointers -> negative status
