@@ -84,6 +84,8 @@ def build_parser():
                         "(combines with --dp_overlap; the RCCL reduce-scatter / all-gather calls are rehearsed with gloo only so far)")
     p.add_argument("--dp_algorithm", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
                    help="gradient reduction per bucket: RCCL's all-reduce, or its two phases issued explicitly")
+    p.add_argument("--dp_exact", action="store_true", help="data parallelism: BatchNorm statistics of the GLAC cells, the [B,B] similarity "
+                   "matrices and the JS loss over the GLOBAL batch (the reference's single-GPU semantics) instead of per rank")
     p.add_argument("--cleanup_output", action="store_true", help="reference behaviour: rmtree('./output') at the end")
     return p
 

@@ -92,7 +92,8 @@ class MSDTrainer:
         self.dp = DataParallel(self.store, self.optimizer, self.model,
                                overlap=bool(getattr(self.args, "dp_overlap", False)),
                                grad_comm_dtype=torch.bfloat16 if getattr(self.args, "dp_grad_comm", "f32") == "bf16" else torch.float32,
-                               shard_optimizer=shard, algorithm=getattr(self.args, "dp_algorithm", "all_reduce"))
+                               shard_optimizer=shard, algorithm=getattr(self.args, "dp_algorithm", "all_reduce"),
+                               global_batch_exact=bool(getattr(self.args, "dp_exact", False)))
         self.dp.broadcast_parameters()
         if self.train_data is not None:
             self.scheduler = LinearWarmupSchedule(self.optimizer, self.args.warmup_ratio * self.train_num_steps,
