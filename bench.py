@@ -261,7 +261,7 @@ def main():
         was_overlap, dp.overlap = dp.overlap, False  # no readiness hooks / collectives inside the capture
         with torch.cuda.graph(graph):
             static["loss"], static["logits"] = model(*batch)
-            static["loss"].backward()
+            opt.backward(static["loss"])  # (fp16: the root gradient is the loss scale's device scalar, see stage_hyper)
             if world == 1:
                 opt.step_captured()
                 opt.zero_grad()
@@ -272,8 +272,10 @@ def main():
             if world == 1:
                 opt.stage_hyper()
                 graph.replay()
+                opt.after_replay()
             else:
                 dp.begin_step()
+                opt.refresh_root_grad()
                 graph.replay()
                 dp.reduce_gradients()
                 opt.step()

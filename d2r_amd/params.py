@@ -246,8 +246,20 @@ class FusedAdamW:
             sc["root_grad_value"] = self.loss_scale
         loss.backward(gradient=g)
 
+    def refresh_root_grad(self):
+        """Before replaying a captured ``backward``: the graph holds the root gradient's address, so a changed loss scale is
+        written into it in place."""
+        sc = self._scaler
+        if sc is not None and sc.get("root_grad") is not None and sc.get("root_grad_value") != self.loss_scale:
+            sc["root_grad"].fill_(self.loss_scale)
+            sc["root_grad_value"] = self.loss_scale
+
     def _scaler_before_step(self):
         """Consumes the previous step's overflow flag (its copy has long landed), then arms the check for this step."""
+        self._scaler_consume()
+        self._scaler_arm()
+
+    def _scaler_consume(self):
         sc = self._scaler
         if sc["event"] is not None:
             sc["event"].synchronize()
@@ -261,6 +273,10 @@ class FusedAdamW:
                 if sc["good"] >= sc["growth_interval"]:
                     sc["good"] = 0
                     self.loss_scale = min(self.loss_scale * 2.0, sc["max_scale"])
+            sc["event"] = None
+
+    def _scaler_arm(self):
+        sc = self._scaler
         st = self.store
         sc["flag"].zero_()
         _lib.call("d2r_grad_nonfinite", st.flat_g.data_ptr(), st.n, sc["flag"].data_ptr(), _stream())
@@ -322,6 +338,11 @@ class FusedAdamW:
     def stage_hyper(self):
         """Call BEFORE replaying a captured step: advances the step count and uploads {lr, bias corrections,
         grad_scale} of every group (one small async H2D copy on the current stream)."""
+        if self._scaler is not None:
+            # the previous replay's overflow flag decides this step's scale; the root gradient the captured backward starts
+            # from is a device scalar, rewritten IN PLACE (the graph holds its address) when the scale moved
+            self._scaler_consume()
+            self.refresh_root_grad()
         self.step_count += 1
         cpu, dev = self._hyper_buffers()
         b1, b2 = (float(torch.tensor(b, dtype=torch.float32)) for b in self.betas)  # the f32 values the kernel sees
@@ -332,11 +353,19 @@ class FusedAdamW:
         dev.copy_(cpu)  # pageable source: the runtime stages it before returning, so `cpu` may be rewritten at once
 
     def step_captured(self):
-        """The launches recorded into a hipGraph (no host-side scalars)."""
+        """The launches recorded into a hipGraph (no host-side scalars).  With loss scaling on, the captured backward must have
+        been ``opt.backward(loss)`` (root gradient = the scale's device scalar); the overflow check and the skip flag are part
+        of the capture, and the host calls ``after_replay()`` behind every replay to fetch the flag."""
         from .functional import wgrad_join
         wgrad_join()
         st = self.store
         _, dev = self._hyper_buffers()
+        skip = None
+        if self._scaler is not None:
+            if self.element_ranges is not None:
+                raise RuntimeError("step_captured: the sharded optimiser's overflow flag needs a collective, which is not captured")
+            self._scaler_arm()
+            skip = self._scaler["flag"].data_ptr()
         for i, pg in enumerate(self.param_groups):
             a, b = pg["range"]
             if b <= a:
@@ -344,7 +373,12 @@ class FusedAdamW:
             lp = None if st.flat_lp is None else st.flat_lp.data_ptr() + 2 * a
             _lib.call("d2r_adamw_step_dev", st.flat_w.data_ptr() + 4 * a, st.flat_g.data_ptr() + 4 * a,
                       self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, lp, st.lp_dtype, b - a, dev.data_ptr() + 16 * i,
-                      self.betas[0], self.betas[1], self.eps, pg["weight_decay"], None, _stream())
+                      self.betas[0], self.betas[1], self.eps, pg["weight_decay"], skip, _stream())
+
+    def after_replay(self):
+        """Behind a replay of a captured step: starts the copy of the overflow flag (no-op without loss scaling)."""
+        if self._scaler is not None:
+            self._scaler_after_step()
 
     def state_dict(self):
         """Under the sharded optimiser a rank's moments are current for its own stripes only: they are all-gathered first (a

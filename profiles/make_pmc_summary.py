@@ -32,6 +32,16 @@ def family(name: str):
 
     if "splitk_reduce" in name:
         return "gemm_splitk_reduce", True
+    # round 4: the 256 x 256 deep-pipelined kernels (gemm8.hip) and the grouped launches of the 128-wide kernel (same tiles: same row)
+    m = re.search(r"gemm8_wgrad_kernelIDF16([b_])", name)
+    if m:
+        return "gemm_%s_TN_grouped_ldsdma256x256" % ("bf16" if m.group(1) == "b" else "f16"), True
+    m = re.search(r"gemm8_fwd_kernelIDF16([b_])Li(\d)E", name)
+    if m:
+        return "gemm_%s_%s_ldsdma256x256" % ("bf16" if m.group(1) == "b" else "f16", lay[int(m.group(2))]), True
+    m = re.search(r"gemm_glds_group_kernelIDF16([b_])Li(\d)E", name)
+    if m:
+        return "gemm_%s_%s_ldsdma128x128w8" % ("bf16" if m.group(1) == "b" else "f16", lay[int(m.group(2))]), True
     # round 3: <E, LAYOUT, BN, NWN, PIPE, MODE> (MODE 1 grouped weight gradients, 2 grouped + batched 16-bit output); E = bf16 (b) / fp16 (_)
     m = re.search(r"gemm_glds_kernelIDF16([b_])Li(\d)ELi(\d+)ELi(\d)ELi(\d)ELi(\d)E", name)
     if m:

@@ -196,7 +196,7 @@ def test_cli_smoke(gpu, tmp_path):
     assert "Test Eval results" in r.stderr and os.path.exists(os.path.join(str(tmp_path), "best_model.pth"))
 
 
-def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4, layers=1, dtype=torch.bfloat16):
+def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4, layers=1, dtype=torch.bfloat16, init_scale=2.0 ** 10):
     from d2r_amd.params import FusedAdamW, LinearWarmupSchedule, ParamStore
     model, args = _tiny(dtype, layers=layers)
     model.load_state_dict(sd, strict=True)
@@ -206,7 +206,7 @@ def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4, layers=1, dtype=torc
     store = ParamStore(model, dtype)
     opt = FusedAdamW(store, lr=1e-3)
     if dtype == torch.float16:
-        opt.enable_loss_scaling(init_scale=2.0 ** 10)
+        opt.enable_loss_scaling(init_scale=init_scale)
     sched = LinearWarmupSchedule(opt, 2, 10)
     losses = []
     if not use_graph:
@@ -222,23 +222,47 @@ def _run_steps(gpu, sd, batch, use_graph, use_streams, n=4, layers=1, dtype=torc
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm caches/workspaces; no optimiser step, so the weights are untouched
             loss, _ = model(*batch)
-            loss.backward()
+            opt.backward(loss)
             opt.zero_grad()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss, _ = model(*batch)
-            loss.backward()
+            opt.backward(loss)  # fp16: the root gradient is the loss scale's device scalar
             opt.step_captured()
             opt.zero_grad()
         for _ in range(n):
             opt.stage_hyper()
             g.replay()
+            opt.after_replay()
             sched.step()
             losses.append(float(loss))
     torch.cuda.synchronize()
+    if dtype == torch.float16:
+        opt._scaler_consume()  # the last step's flag
+        losses.append(("skipped", opt._scaler["skipped"], "scale", opt.loss_scale, "count", opt.step_count))
     return losses, store.flat_w.clone(), opt.m.clone(), opt.v.clone(), [(n, o, k) for n, _, o, k, _ in store.entries]
+
+
+@pytest.mark.parametrize("init_scale", [2.0 ** 10, 2.0 ** 20])
+def test_fp16_graph_replay_scales_the_loss_and_skips_like_eager(gpu, init_scale):
+    """fp16 steps replayed from a hipGraph carry the whole loss-scaling protocol: scaled root gradient (device scalar, rewritten
+    when the scale moves), overflow check and the AdamW skip flag inside the capture, the host halving one step late.  Weights,
+    moments, losses, the number of skipped steps and the final scale equal eager stepping bit for bit - at a scale that never
+    overflows and at 2^20, where the first steps do (the scale walks down until the gradients fit)."""
+    from oracle import d2r_oracle as O
+    cfg = O.OracleConfig(text_layers=1, vision_layers=1, image_size=64, patch_size=32)
+    sd = O.seeded_state_dict(cfg, seed=5, router_bias="normal")
+    batch = tuple(t.to(gpu) for t in O.synthetic_batch(cfg, 4, 12, seed=9))
+    base = _run_steps(gpu, sd, batch, False, True, n=9, dtype=torch.float16, init_scale=init_scale)
+    got = _run_steps(gpu, sd, batch, True, True, n=9, dtype=torch.float16, init_scale=init_scale)
+    assert got[0] == base[0], (got[0], base[0])
+    skipped = base[0][-1][1]
+    assert (skipped > 0) == (init_scale > 2.0 ** 15) and skipped < 8, base[0][-1]
+    assert base[0][-2] != base[0][0]  # it trains
+    for what, a, b in zip(("w", "m", "v"), got[1:4], base[1:4]):
+        assert torch.equal(a, b), what
 
 
 def test_streams_and_graph_replay_are_bit_identical_to_single_stream_eager(gpu):
