@@ -256,26 +256,30 @@ def main():
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        graph, graph_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         static = {}
         was_overlap, dp.overlap = dp.overlap, False  # no readiness hooks / collectives inside the capture
         with torch.cuda.graph(graph):
             static["loss"], static["logits"] = model(*batch)
-            opt.backward(static["loss"])  # (fp16: the root gradient is the loss scale's device scalar, see stage_hyper)
-            if world == 1:
+            opt.backward(static["loss"])  # (fp16: the root gradient is the loss scale's device scalar)
+        if world == 1:
+            # the optimiser is its own graph: its per-step scalars are uploaded between the two replays, after the overflow flag
+            # of the PREVIOUS step has been read (it landed long ago) - the eager protocol, and the host never waits
+            with torch.cuda.graph(graph_opt):
                 opt.step_captured()
                 opt.zero_grad()
         del was_overlap  # at N > 1 the captured fwd+bwd is followed by the plain (non-overlapped) bucketed all-reduce
         log("hipGraph of the step captured")
 
         def step():
+            opt.refresh_root_grad()
             if world == 1:
-                opt.stage_hyper()
                 graph.replay()
+                opt.stage_hyper()
+                graph_opt.replay()
                 opt.after_replay()
             else:
                 dp.begin_step()
-                opt.refresh_root_grad()
                 graph.replay()
                 dp.reduce_gradients()
                 opt.step()

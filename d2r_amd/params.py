@@ -336,20 +336,27 @@ class FusedAdamW:
         return self._hyper_cpu, self._hyper_dev
 
     def stage_hyper(self):
-        """Call BEFORE replaying a captured step: advances the step count and uploads {lr, bias corrections,
-        grad_scale} of every group (one small async H2D copy on the current stream)."""
+        """Call BEFORE replaying the captured optimiser launches: advances the step count and uploads {lr, bias corrections,
+        grad_scale} of every group (one small async H2D copy on the current stream).
+
+        With loss scaling the protocol of a replayed step is the eager one, launch for launch:
+            opt.refresh_root_grad(); <replay forward+backward>; opt.stage_hyper(); <replay step_captured + zero_grad>;
+            opt.after_replay()
+        stage_hyper divides by the scale the backward just ran with, THEN consumes the previous step's overflow flag (which may
+        halve the scale for the next step and takes the dropped step out of the count) - exactly what step() does.  Captured as
+        two graphs, the host never waits for the device (the flag it reads is a step old); with everything in ONE graph
+        stage_hyper comes before the replay and its flag read waits for the previous replay to finish (correct, same
+        numbers, but the host cannot run ahead)."""
+        used = self.loss_scale
         if self._scaler is not None:
-            # the previous replay's overflow flag decides this step's scale; the root gradient the captured backward starts
-            # from is a device scalar, rewritten IN PLACE (the graph holds its address) when the scale moved
             self._scaler_consume()
-            self.refresh_root_grad()
         self.step_count += 1
         cpu, dev = self._hyper_buffers()
         b1, b2 = (float(torch.tensor(b, dtype=torch.float32)) for b in self.betas)  # the f32 values the kernel sees
         bc1 = 1.0 - b1 ** self.step_count
         bc2s = math.sqrt(1.0 - b2 ** self.step_count)
         for i, pg in enumerate(self.param_groups):
-            cpu[i, 0], cpu[i, 1], cpu[i, 2], cpu[i, 3] = pg["lr"], bc1, bc2s, self.grad_scale / self.loss_scale
+            cpu[i, 0], cpu[i, 1], cpu[i, 2], cpu[i, 3] = pg["lr"], bc1, bc2s, self.grad_scale / used
         dev.copy_(cpu)  # pageable source: the runtime stages it before returning, so `cpu` may be rewritten at once
 
     def step_captured(self):
