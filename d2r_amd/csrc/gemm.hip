@@ -476,7 +476,7 @@ extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
   g_vepi = vepi;
   if (tile == 100 || tile == 101) g_wgrad_glds = tile - 100;  // A/B switch of the grouped weight-gradient kernel (0: 64x64 generic)
   else if (tile == 102 || tile == 103) g_gemm8_wgrad = tile - 102;  // 256 x 256 deep-pipelined grouped weight gradients off / on
-  else if (tile == 110 || tile == 111) g_gemm8 = tile - 110;        // 256 x 256 forward / dX products off / on
+  else if (tile >= 110 && tile <= 113) g_gemm8 = tile - 110;        // 256 x 256 forward / dX products off / on / (A/B: 2 = not with an activation in the epilogue, 3 = only without any second operand)
   else if (tile == 120 || tile == 121) g_group = tile - 120;        // grouped launches of d2r_gemm_group off / on
   else if (tile >= 2000) g_dbg = tile - 2000;
   else if (tile >= 1000) g_gemm8_min = tile - 1000;
@@ -499,6 +499,8 @@ int d2r_gemm8_wgrad_launch(int dtype, int count, const int* M, const int* N, con
                            const void* const* A, const void* const* B, float* const* C, float* const* dbias, float beta, hipStream_t st);
 // One workgroup per CU: a launch of t tiles runs in ceil(t / 256) rounds.  The wide tiles pay when the last round is well filled.
 static bool gemm8_pays(const GemmArgs& a) {
+  if (g_gemm8 == 2 && (a.act != 0 || a.G != nullptr)) return false;
+  if (g_gemm8 == 3 && (a.act != 0 || a.G != nullptr || a.R != nullptr || a.P != nullptr)) return false;
   const int64_t t = (int64_t)d2r_cdiv(a.M, 256) * d2r_cdiv(a.N, 256);
   if (t < g_gemm8_min) return false;
   const int64_t rounds = (t + 255) / 256;

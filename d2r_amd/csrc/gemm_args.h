@@ -177,6 +177,24 @@ __device__ __forceinline__ void lds_reads_done() {
 // element from fully unrolled loops expands the seven-way switch (with erff / tanhf / expf bodies) at every call site:
 // the 128x64 kernel grew to 30,000 instructions whose instruction-cache misses cost a third of a K = 768 GEMM.  These
 // helpers take the switch ONCE per 8-wide pack; the callers keep the pack loop rolled.
+// The 16-bit epilogues evaluate erf / exp / the sigmoid's division with the hardware transcendentals (v_exp_f32, v_rcp_f32: about one
+// ulp) and erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute): the result is rounded to an 8- or 11-bit significand next, and
+// libm's erff / expf / IEEE division cost 30-60 VALU instructions per element - with 128 outputs per lane of a 256 x 256 tile that was
+// more issue time than the K = 768 main loop (measured in the step: 49.7 / 57.8 us for the GELU forward / backward products against
+// 28 us without an activation).  The fp32 kernels (routers, head) keep libm.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// erfc(|z|) from e = exp(-z^2)
+__device__ __forceinline__ float as_erfc_abs(float az, float e) {
+  const float t = fast_rcp(fmaf(0.3275911f, az, 1.f));
+  return ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t * e;
+}
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)), given e = exp(-x^2 / 2)
+__device__ __forceinline__ float fast_phi(float x, float e) {
+  const float h = 0.5f * as_erfc_abs(fabsf(x) * 0.70710678118654752f, e);
+  return x >= 0.f ? 1.f - h : h;
+}
+
 template <int N>
 __device__ __forceinline__ void act_apply_vec(int act, float (&v)[N]) {
   switch (act) {
@@ -190,11 +208,11 @@ __device__ __forceinline__ void act_apply_vec(int act, float (&v)[N]) {
       break;
     case D2R_ACT_GELU:
 #pragma unroll
-      for (int j = 0; j < N; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+      for (int j = 0; j < N; ++j) v[j] *= fast_phi(v[j], fast_exp(-0.5f * v[j] * v[j]));
       break;
     case D2R_ACT_QUICK_GELU:
 #pragma unroll
-      for (int j = 0; j < N; ++j) v[j] = v[j] / (1.f + expf(-1.702f * v[j]));
+      for (int j = 0; j < N; ++j) v[j] *= fast_rcp(1.f + fast_exp(-1.702f * v[j]));
       break;
     case D2R_ACT_TANH_RELU:
 #pragma unroll
@@ -222,14 +240,14 @@ __device__ __forceinline__ void act_grad_mul_vec(int act, const float (&r)[N], f
     case D2R_ACT_GELU:
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        const float cdf = 0.5f * (1.f + erff(r[j] * 0.70710678118654752f));
-        v[j] *= cdf + r[j] * 0.3989422804014327f * expf(-0.5f * r[j] * r[j]);
+        const float e = fast_exp(-0.5f * r[j] * r[j]);
+        v[j] *= fast_phi(r[j], e) + r[j] * 0.3989422804014327f * e;
       }
       break;
     case D2R_ACT_QUICK_GELU:
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        const float sg = 1.f / (1.f + expf(-1.702f * r[j]));
+        const float sg = fast_rcp(1.f + fast_exp(-1.702f * r[j]));
         v[j] *= sg + 1.702f * r[j] * sg * (1.f - sg);
       }
       break;

@@ -1,0 +1,5 @@
+# two bench runs of the timed step (no legs) + the per-shape GEMM table of the step
+F="--steps 40 --warmup 6 --no-cpu-baseline --no-fp32-leg --no-alt-leg --no-host-leg --no-roofline"
+for r in 1 2 3; do timeout -k 10 200 python bench.py $F "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['fwd_bwd_only']['ms_per_step_per_rank'], d['final_loss'])"; done
