@@ -191,6 +191,7 @@ PROBE_SIGNATURES = {
     "d2r_gemm8_debug_stamps": (None, [vp]),
     "d2r_xattn3_debug_stamps": (None, [vp]),
     "d2r_xattn3_debug_mode": (None, [i32]),
+    "d2r_adamw_probe_mode": (None, [i32, i32]),
 }
 
 

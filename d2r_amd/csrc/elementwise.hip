@@ -303,7 +303,30 @@ extern "C" int d2r_copy_rows(void* dst, int64_t dst_pitch, const void* src, int6
 }
 
 // ---- K14 AdamW over a flat fp32 range (modules/train.py:287-322; torch.optim.AdamW semantics) -----------
-template <typename H>
+typedef float f32x4nt __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ Pack<float, 4> ld4(const float* p) {
+  if constexpr (NT) {
+    const f32x4nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(p));
+    Pack<float, 4> r;
+    r.v[0] = t.x, r.v[1] = t.y, r.v[2] = t.z, r.v[3] = t.w;
+    return r;
+  } else {
+    return ld_pack<float, 4>(p);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float* p, const Pack<float, 4>& v) {
+  if constexpr (NT) {
+    f32x4nt t;
+    t.x = v.v[0], t.y = v.v[1], t.z = v.v[2], t.w = v.v[3];
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4nt*>(p));
+  } else {
+    st_pack<float, 4>(p, v);
+  }
+}
+
+template <typename H, bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     H* __restrict__ w16, int64_t n, float lr, float b1, float b2,
@@ -328,13 +351,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
     wi -= (lr / bc1) * (mi / denom);
   };
   for (int64_t k = tid; k < n4; k += nthreads) {
-    Pack<float, 4> pw = ld_pack<float, 4>(w + k * 4), pg = ld_pack<float, 4>(g + k * 4);
-    Pack<float, 4> pm = ld_pack<float, 4>(m + k * 4), pv = ld_pack<float, 4>(v + k * 4);
+    Pack<float, 4> pw = ld4<NT>(w + k * 4), pg = ld4<NT>(g + k * 4);
+    Pack<float, 4> pm = ld4<NT>(m + k * 4), pv = ld4<NT>(v + k * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) upd(pw.v[j], pg.v[j], pm.v[j], pv.v[j]);
-    st_pack<float, 4>(w + k * 4, pw);
-    st_pack<float, 4>(m + k * 4, pm);
-    st_pack<float, 4>(v + k * 4, pv);
+    st4<NT>(w + k * 4, pw);
+    st4<NT>(m + k * 4, pm);
+    st4<NT>(v + k * 4, pv);
     if (w16) {
       Pack<H, 4> ph;
 #pragma unroll
@@ -350,6 +373,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
   }
 }
 
+static int g_adamw_nt = 0, g_adamw_blocks = 0;  // A/B (include/d2r_hip_probes.h): non-temporal loads / stores, grid cap
+extern "C" void d2r_adamw_probe_mode(int nt, int blocks) { g_adamw_nt = nt, g_adamw_blocks = blocks; }
+
 static int adamw_launch(const char* name, float* w, const float* g, float* m, float* v, void* w16, int w16_dtype, int64_t n, float lr,
                         float b1, float b2, float eps, float wd, float bc1, float bc2s, float gscale, const float* d_hyper,
                         const int* d_skip, void* stream) {
@@ -358,13 +384,19 @@ static int adamw_launch(const char* name, float* w, const float* g, float* m, fl
               "%s: the 16-bit shadow must be 8-byte aligned and D2R_BF16 or D2R_F16 (got dtype %d)", name, w16_dtype);
   if (n == 0) return D2R_OK;
   int blocks = (int)((n / 4 + 256) / 256);
-  if (blocks > 2048) blocks = 2048;
-  if (w16 && w16_dtype == D2R_F16)
-    hipLaunchKernelGGL(adamw_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (f16_t*)w16, n, lr, b1, b2, eps, wd,
-                       bc1, bc2s, gscale, d_hyper, d_skip);
-  else
-    hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (bf16_t*)w16, n, lr, b1, b2, eps,
-                       wd, bc1, bc2s, gscale, d_hyper, d_skip);
+  const int cap = g_adamw_blocks > 0 ? g_adamw_blocks : 2048;
+  if (blocks > cap) blocks = cap;
+#define D2R_ADAMW_LAUNCH(H, NT) \
+  hipLaunchKernelGGL((adamw_kernel<H, NT>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (H*)w16, n, lr, b1, b2, eps, wd, bc1, bc2s, \
+                     gscale, d_hyper, d_skip)
+  if (w16 && w16_dtype == D2R_F16) {
+    if (g_adamw_nt) D2R_ADAMW_LAUNCH(f16_t, true);
+    else D2R_ADAMW_LAUNCH(f16_t, false);
+  } else {
+    if (g_adamw_nt) D2R_ADAMW_LAUNCH(bf16_t, true);
+    else D2R_ADAMW_LAUNCH(bf16_t, false);
+  }
+#undef D2R_ADAMW_LAUNCH
   return d2r_check_launch(name);
 }
 

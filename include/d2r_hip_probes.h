@@ -38,6 +38,9 @@ void d2r_gemm8_debug_stamps(unsigned long long* dst);   /* 256-wide kernel: [8 w
 void d2r_xattn3_debug_stamps(unsigned long long* dst);  /* cross-attention forward: [4 waves][64] */
 void d2r_xattn3_debug_mode(int mode);                   /* ablation mode of the cross-attention forward (measurement build) */
 
+/* A/B of the AdamW kernel: non-temporal loads / stores of the fp32 streams (0 / 1), cap of the grid in workgroups (0 = default 2048). */
+void d2r_adamw_probe_mode(int nt, int blocks);
+
 #ifdef __cplusplus
 }
 #endif
