@@ -31,6 +31,10 @@ if os.environ.get("D2R_X3_PROBES", "0") != "0":  # measurement build of the cros
 if os.environ.get("D2R_G8_STAMPS", "0") != "0":  # measurement build of the 256-wide GEMM (tests/probes/gemm8_probe.py stamps)
     EXTRA_FLAGS["gemm8.hip"] = ["-DD2R_G8_STAMPS=1"]
 
+if os.environ.get("D2R_FAST_ACT", "0") != "0":  # hardware exp / rcp and a polynomial erfc in the 16-bit GEMM epilogues (gemm_args.h: -0.25 ms per step, not the default)
+    for f_ in ("gemm.hip", "gemm_glds.hip", "gemm8.hip"):
+        EXTRA_FLAGS[f_] = EXTRA_FLAGS.get(f_, []) + ["-DD2R_FAST_ACT=1"]
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
