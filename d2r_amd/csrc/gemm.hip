@@ -408,6 +408,7 @@ static int g_dbg = 0;  // ablation switches of the measurement build (-DD2R_GEMM
 static int g_gemm8 = 1;
 static int g_group = 1;  // d2r_gemm_group: grouped launches of independent forward / dX products (d2r_gemm_tuning tile 120 / 121: off / on)
 static int g_gemm8_wgrad = 1;  // ... for the grouped weight gradients (tile 102 / 103)
+static int g_splitk = 1;  // in-kernel split-K of the 128-wide kernel for deep reductions over a partial round of tiles (tile 130 / 131: off / on)
 static int g_gemm8_min = 150;  // fewest 256 x 256 tiles of a forward / dX product that takes them (tile 1000 + n sets it)
 
 // ---- optional per-launch timing of the GEMM entry points (bench.py's roofline leg) -----------------------------------------
@@ -477,6 +478,7 @@ extern "C" void d2r_gemm_tuning(int nbuf, int vepi, int tile) {
   if (tile == 100 || tile == 101) g_wgrad_glds = tile - 100;  // A/B switch of the grouped weight-gradient kernel (0: 64x64 generic)
   else if (tile == 102 || tile == 103) g_gemm8_wgrad = tile - 102;  // 256 x 256 deep-pipelined grouped weight gradients off / on
   else if (tile >= 110 && tile <= 113) g_gemm8 = tile - 110;        // 256 x 256 forward / dX products off / on / (A/B: 2 = not with an activation in the epilogue, 3 = only without any second operand)
+  else if (tile == 130 || tile == 131) g_splitk = tile - 130;        // in-kernel split-K of the 128-wide kernel off / on
   else if (tile == 120 || tile == 121) g_group = tile - 120;        // grouped launches of d2r_gemm_group off / on
   else if (tile >= 2000) g_dbg = tile - 2000;
   else if (tile >= 1000) g_gemm8_min = tile - 1000;
@@ -498,6 +500,8 @@ int d2r_gemm8_wgrad_ok(int dtype, int M, int N, int K, int64_t lda, int64_t ldb,
 int d2r_gemm8_wgrad_launch(int dtype, int count, const int* M, const int* N, const int* K, const int64_t* lda, const int64_t* ldb, const int64_t* ldc,
                            const void* const* A, const void* const* B, float* const* C, float* const* dbias, float beta, hipStream_t st);
 // One workgroup per CU: a launch of t tiles runs in ceil(t / 256) rounds.  The wide tiles pay when the last round is well filled.
+int d2r_gemm_glds_splitk_plan(const GemmArgs& a, int layout, int batch, size_t ws_bytes, size_t* slab_bytes);
+int d2r_gemm_glds_splitk_launch(const GemmArgs& a, int layout, hipStream_t st);
 static bool gemm8_pays(const GemmArgs& a) {
   if (g_gemm8 == 2 && (a.act != 0 || a.G != nullptr)) return false;
   if (g_gemm8 == 3 && (a.act != 0 || a.G != nullptr || a.R != nullptr || a.P != nullptr)) return false;
@@ -852,6 +856,17 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
         return d2r_gemm8_fwd_launch(&a, 1, LAYOUT, st);
       }
     }
+    if (bn == 129 && g_splitk && ws) {  // deep reductions over a partial round of tiles: split K inside the launch (gemm_glds.hip)
+      size_t slab = 0;
+      const int want = d2r_gemm_glds_splitk_plan(a, LAYOUT, batch, ws_bytes, &slab);
+      if (want > 1) {
+        GemmArgs b = a;
+        b.splits = want, b.tiles_per_split = 0, b.ws = (float*)ws;
+        b.kflags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + ((ws_bytes - 4096) & ~(size_t)15));  // (the last 4 KiB of a workspace: zero at first use, kept zero)
+        d2r_gemm_variant_tl = 3;
+        return d2r_gemm_glds_splitk_launch(b, LAYOUT, st);
+      }
+    }
     if (bn) {
       GemmArgs b = a;
       b.ws = nullptr; b.splits = 1; b.tiles_per_split = 0;
@@ -895,7 +910,8 @@ static int launch_layout(GemmArgs a, int batch, hipStream_t st, void* ws, size_t
       int want = (int)(capacity / tiles);
       if (want > 16) want = 16;
       if (want > nk / 2) want = nk / 2;
-      while (want > 1 && (size_t)want * ((size_t)a.M * a.N + (a.dbias ? a.M : 0)) * sizeof(float) > ws_bytes) --want;
+      const size_t slab_bytes = ws_bytes > 4096 ? ws_bytes - 4096 : 0;  // (the last 4 KiB hold the tile counters of the in-kernel split-K)
+      while (want > 1 && (size_t)want * ((size_t)a.M * a.N + (a.dbias ? a.M : 0)) * sizeof(float) > slab_bytes) --want;
       if (want > 1) {
         a.tiles_per_split = d2r_cdiv(nk, want);
         a.splits = d2r_cdiv(nk, a.tiles_per_split);

@@ -82,6 +82,7 @@ struct GemmArgs {
   int m_store;  // same mode: rows stored (<= M; M itself is the multiple of 8 the operand loads are clamped to)
   int dbg;  // timing experiments (D2R_GEMM_DBG): 1 = no MFMA, 2 = no DMA issue, 3 = no epilogue stores
   unsigned long long* ts;  // timing experiments (d2r_gemm_debug_stamps): s_memtime stamps of workgroup (0,0) of the LDS-DMA kernel, [waves][8]
+  unsigned* kflags;  // in-kernel split-K of the LDS-DMA kernel (gemm_glds_splitk_kernel): arrival counters per output tile, zero between launches
 };
 
 // Loads VEC consecutive elements [c0, c0+VEC) of a row; zero outside [0, climit) or when !row_ok.

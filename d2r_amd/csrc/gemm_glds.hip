@@ -45,8 +45,8 @@ __device__ __forceinline__ int kpos(int c, int k) { return c ^ kswz<CH>(k); }
 // + batch index, operands at grp.A/B/C[group] + batch * g.sAb / sBb / sCb; the reduction length need not be a multiple of 64
 // (as in mode 1); rows are LOADED up to g.M (a multiple of 8) and STORED up to g.m_store.  Serves the key-side products of the
 // cross-attention backward (dV = P^T dO, dK = dS^T Q for every sample of up to four attention problems: one launch).
-template <typename E, int LAYOUT, int BN, int NWN, int PIPE, int MODE, int NWM>
-__device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp, int tile_m, int tile_n, int z) {
+template <typename E, int LAYOUT, int BN, int NWN, int PIPE, int MODE, int NWM, bool SPLITK = false>
+__device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp, int tile_m, int tile_n, int z, int split = 0) {
   constexpr bool WGRAD = MODE == 1;        // fp32 accumulate epilogue + bias gradient
   constexpr bool RAGGED = MODE != 0;       // grouped launch (3-D tile order), ragged reduction length
   typedef typename H16<E>::v8 h8;  // E: E or f16_t (same tiles and LDS images; the MFMA opcode differs)
@@ -194,7 +194,14 @@ __device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp,
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int nk = RAGGED ? nk_w : g.K / BK;
+  int nk = RAGGED ? nk_w : g.K / BK;
+  if constexpr (SPLITK) {  // this workgroup reduces K-tiles [kb, ke) of the product: the operand pointers move, the loop shortens
+    static_assert(MODE == 0 && PIPE == 0, "split-K is built for the plain forward / dX loop");
+    const int kb = nk * split / g.splits, ke = nk * (split + 1) / g.splits;
+    A += A_KCONT ? (int64_t)kb * BK : (int64_t)kb * BK * g.lda;
+    B += B_KCONT ? (int64_t)kb * BK : (int64_t)kb * BK * g.ldb;
+    nk = ke - kb;
+  }
   // fragments of K-substep kk (32 k) from the staged tile at bA / bB
   auto read_frags = [&](const unsigned char* bA, const unsigned char* bB, int kk, h8 (&af)[TM], h8 (&bfr)[TN]) {
 #pragma unroll
@@ -374,6 +381,62 @@ __device__ __forceinline__ void gemm_glds_body(GemmArgs g, const GemmGroup& grp,
   }
   GEMM_STAMP(2);
 
+  if constexpr (SPLITK) {
+    // The `splits` workgroups of an output tile (grid z = split index, dispatched in order: every producer is resident or done before its
+    // finisher starts) meet here.  Producers 0 .. splits-2 park their accumulators in the workspace - accumulator layout: lane-contiguous
+    // 16-byte packs, the finisher's lanes hold the same elements - release them and count themselves in; the finisher (the last split)
+    // waits for the count, adds the parked partials in split order (fixed summation order: deterministic) and runs the epilogue.  The
+    // counter is back at zero when the finisher is done: launches on one stream reuse the workspace without a clear in between.
+    // Cache traffic: the workgroups of a tile sit on different XCDs, whose L2s are not coherent with each other.  The partials therefore
+    // travel as agent-scope RELAXED atomic accesses (64-bit; sc1: write-through on the store side, no stale hit on the load side), and
+    // the hand-over is "stores complete (vmcnt 0) -> barrier -> relaxed counter increment" / "relaxed counter poll -> barrier -> loads": no
+    // release / acquire fence anywhere - on gfx950 those are whole-L2 write-backs and invalidates, and an acquire inside the poll loop
+    // invalidated the XCD's L2 under the producers' feet (first version: 35 -> 90 us for the 4096 x 768 x 3072 product).
+    const int tile_id = tile_m * gridDim.x + tile_n;
+    constexpr int PER = TM * TN * NW * 64 * 2;  // 64-bit words per parked tile
+    typedef unsigned long long u64;
+    u64* park = reinterpret_cast<u64*>(g.ws) + (int64_t)tile_id * (g.splits - 1) * PER + tid;
+    unsigned* cnt = g.kflags + tile_id;
+    if (split + 1 < g.splits) {
+      u64* dst = park + (int64_t)split * PER;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const u64 lo = (u64)__float_as_uint(acc[i][j][0]) | ((u64)__float_as_uint(acc[i][j][1]) << 32);
+          const u64 hi = (u64)__float_as_uint(acc[i][j][2]) | ((u64)__float_as_uint(acc[i][j][3]) << 32);
+          __hip_atomic_store(dst + ((i * TN + j) * 2 + 0) * (NW * 64), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(dst + ((i * TN + j) * 2 + 1) * (NW * 64), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      // bounded wait (a producer is never behind its finisher in dispatch order; the bound only keeps a broken launch from hanging the GPU)
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(g.splits - 1)) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    for (int sp = 0; sp + 1 < g.splits; ++sp) {
+      const u64* src = park + (int64_t)sp * PER;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const u64 lo = __hip_atomic_load(src + ((i * TN + j) * 2 + 0) * (NW * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const u64 hi = __hip_atomic_load(src + ((i * TN + j) * 2 + 1) * (NW * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[i][j] = f32x4{acc[i][j][0] + __uint_as_float((unsigned)lo), acc[i][j][1] + __uint_as_float((unsigned)(lo >> 32)),
+                            acc[i][j][2] + __uint_as_float((unsigned)hi), acc[i][j][3] + __uint_as_float((unsigned)(hi >> 32))};
+        }
+    }
+    __syncthreads();  // (every wave has its partials before the counter is handed back)
+    if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
   if constexpr (WGRAD) {
     // acc[i][j][r] = C[wm0 + i*16 + fr][wn0 + j*16 + fq*4 + r]: one 16-byte fp32 pack per lane and tile
     float* Cg = reinterpret_cast<float*>(g.C);
@@ -479,6 +542,73 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_glds_kernel(GemmArgs g, G
   if constexpr (MODE != 0) xcd_tile_3d(g.xcd, tile_m, tile_n, z);
   else xcd_tile(g.xcd, tile_m, tile_n, g.band);
   gemm_glds_body<E, LAYOUT, BN, NWN, PIPE, MODE, NWM>(g, grp, tile_m, tile_n, z);
+}
+
+// ---- in-kernel split-K of the 128 x 128 eight-wave kernel (NT / NN, forward / dX products) ---------------------------------------------
+// The N = 768 products of the path with a deep reduction (FFN down-projection and its mirror in the backward pass, the q|k|v dX, the
+// d_other product of a routing module: K = 2304 ... 13,824) have 192 or 300 output tiles of 36-216 K-tiles each: three quarters of a
+// round of workgroups, or one and a sixth.  Splitting K over 2-4 workgroups per tile fills the CUs (two workgroups per CU interleave
+// their latencies); the partial sums meet inside the launch (gemm_glds_body, SPLITK) instead of in a reduce launch.  Measured alone on
+// the GPU (tests/probes/splitk_probe.py, profiles/splitk_probe_r04.log): the meeting costs about 10 us per launch, so K = 13,824
+// gains 17-23 % (134 -> 107 us, 190 -> 157 us) while K = 2304 / 3072 end within -10 ... +14 % of the unsplit launch: the plan below
+// takes products with K >= 6144 only (the two d_other products of a step).
+template <typename E, int LAYOUT>
+__global__ __launch_bounds__(512) void gemm_glds_splitk_kernel(GemmArgs g) {
+  // XCD-aware tile order inside a plane of the grid (z = split index; the planes are dispatched one after the other)
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
+  int id = blockIdx.y * gx + blockIdx.x;
+  if (g.xcd && nwg >= 16) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tile_m = id / gx, tile_n = id - tile_m * gx;
+  static const GemmGroup no_group = {};
+  gemm_glds_body<E, LAYOUT, 128, 4, 0, 0, 2, true>(g, no_group, tile_m, tile_n, 0, blockIdx.z);
+}
+
+// Launches the split-K variant; the caller (gemm.hip) has checked the shape and carved the workspace (d2r_gemm_glds_splitk_plan).
+int d2r_gemm_glds_splitk_launch(const GemmArgs& a, int layout, hipStream_t st) {
+  dim3 grid(d2r_cdiv(a.N, 128), d2r_cdiv(a.M, 128), a.splits);
+  const bool f16 = a.dtype == D2R_F16;
+  if (layout == D2R_GEMM_NT) {
+    if (f16) hipLaunchKernelGGL((gemm_glds_splitk_kernel<f16_t, D2R_GEMM_NT>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_glds_splitk_kernel<bf16_t, D2R_GEMM_NT>), grid, dim3(512), 0, st, a);
+  } else if (layout == D2R_GEMM_NN) {
+    if (f16) hipLaunchKernelGGL((gemm_glds_splitk_kernel<f16_t, D2R_GEMM_NN>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_glds_splitk_kernel<bf16_t, D2R_GEMM_NN>), grid, dim3(512), 0, st, a);
+  } else {
+    return d2r_fail(D2R_ERR_INVALID, "d2r_gemm(split-K): layout");
+  }
+  return d2r_check_launch("d2r_gemm(glds split-K)");
+}
+
+// How many workgroups per output tile (1 = no split), from a model of the launch: rounds of up to 512 resident workgroups (two per CU),
+// a round with more than 256 runs its K-tiles 1.37 x slower per workgroup (two workgroups share a CU: profiles/tile_balance_r03.log).
+int d2r_gemm_glds_splitk_plan(const GemmArgs& a, int layout, int batch, size_t ws_bytes, size_t* slab_bytes) {
+  *slab_bytes = 0;
+  if (layout == D2R_GEMM_TN || batch != 1 || !d2r_is16(a.dtype) || a.c_dtype != a.dtype || !a.vecA || !a.vecB || !a.vecC) return 1;
+  if (a.K % 64 != 0 || a.K < 6144 || a.M < 128 || a.N < 128 || a.dbias) return 1;  // (measured: below K = 6144 the meeting costs what the split gains)
+  if (layout != D2R_GEMM_NT && a.N % 8 != 0) return 1;
+  const int64_t tiles = (int64_t)d2r_cdiv(a.M, 128) * d2r_cdiv(a.N, 128);
+  if (tiles > 448 || tiles > 1024 || ws_bytes < 8192) return 1;
+  const int nk = a.K / 64;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 4; ++s) {
+    if (nk / s < 8) break;
+    if (s > 1 && (size_t)tiles * (s - 1) * (128 * 128 * 4) > ws_bytes - 4096) break;
+    int64_t left = tiles * s;
+    double cost = 0.0;
+    while (left > 0) {
+      const int64_t now = left > 512 ? 512 : left;
+      cost += (double)nk / s * (now > 256 ? 1.37 : 1.0);
+      left -= now;
+    }
+    if (s > 1) cost += 30.0 + 8.0 * (s - 2);  // the meeting, in K-tile times (0.3 us): park 64 KB, count in, poll, fetch - about 10 us per launch, measured
+    if (cost < best_cost - 1e-9) best_cost = cost, best = s;
+  }
+  if (best > 1) *slab_bytes = (size_t)tiles * (best - 1) * (128 * 128 * 4);
+  return best;
 }
 
 // ---- grouped forward / dX launch: up to 16 INDEPENDENT problems of one layout and type on the 128 x 128 eight-wave tiles ------------

@@ -154,7 +154,7 @@ int lin(const Ctx& c, int M, int N, int K, const void* x, int64_t ldx, const d2r
   if (cdt < 0) cdt = dt;
   G g(dt, cdt, D2R_GEMM_NT, M, N, K, x, ldx, p.w, K, y, N);
   g.d.bias = p.b, g.d.act = act, g.d.residual = res, g.d.ldr = N;
-  if (M <= 64) g.ws(c);
+  if (M <= 64 || K >= 6144) g.ws(c);  // (pooled vectors: split-K slabs; very deep reductions: split K inside the launch)
   return d2r_gemm(&g.d, c.st);
 }
 
@@ -164,7 +164,7 @@ int dxg(const Ctx& c, int M, int Kf, int Nf, const void* dy, int64_t ldy, const 
   if (dt < 0) dt = c.dt;
   G g(dt, dt, D2R_GEMM_NN, M, Kf, Nf, dy, ldy, w, Kf, dx, ldc);
   g.d.beta = beta, g.d.residual = res, g.d.ldr = Kf, g.d.grad_ref = gref, g.d.grad_act = gact;
-  if (M <= 64) g.ws(c);
+  if (M <= 64 || Nf >= 6144) g.ws(c);  // (pooled vectors: split-K slabs; the d_other product, K = 13,824: split K inside the launch)
   return d2r_gemm(&g.d, c.st);
 }
 

@@ -310,6 +310,7 @@ def _workspace(nbytes: int, device, stream: Optional[int] = None) -> torch.Tenso
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        ws[-4096:].zero_()  # tile counters of the in-kernel split-K GEMM (include/d2r_hip.h, d2r_gemm_desc.workspace): zero at first use, kept zero
         _WS[key] = ws
     return ws
 

@@ -85,7 +85,10 @@ typedef struct {
   const void* residual; int64_t ldr, sRb, sRh;
   void* preact;  /* same ld/strides as C */
   /* optional scratch for deterministic split-K (GEMMs with few output tiles and a long reduction: weight
-   * gradients, M<=32 router/pooler products); used only when batch == 1.  NULL disables split-K. */
+   * gradients, M<=32 router/pooler products; 16-bit NT / NN products with K >= 2048 over at most 448 tiles of 128 x 128, whose
+   * partial sums meet inside the launch); used only when batch == 1.  NULL disables split-K.  The LAST 4 KiB of the workspace
+   * hold the tile counters of the in-launch variant: they must be zero before the first use and are zero again when a launch has
+   * finished; launches that share a workspace must be ordered (one stream). */
   void* workspace; size_t workspace_bytes;
   int64_t s_bias_b;  /* bias stride per outer batch index b (grouped linears: one bias row per group); 0 = shared */
   /* TN layout, batch == 1 only: dbias[m] += sum_k A[k,m] (fp32 [M], ACCUMULATED) — the bias gradient of a linear

@@ -233,3 +233,84 @@ def test_grouped_launch_of_independent_products_is_bit_identical_to_separate_lau
     a, b, c0, bias, res, gref, act, beta, gact = ops[1]
     ref = torch.tanh(a.double() @ (b.double().t() if layout == 0 else b.double()) + bias.double())
     assert float((grp[1].double() - ref).abs().max()) <= 2.5 * ULP[lowp] * float(ref.abs().max()) + 1e-6
+
+
+# ---- in-launch split-K of the 128-wide kernel (gemm_glds_splitk_kernel) --------------------------------------------------------------
+SPLITK_CASES = [
+    # M, N, K, options: N = 768-class products with a deep reduction (two, three or four workgroups per output tile; K >= 6144 splits)
+    (4096, 768, 6144, dict(bias=True, res=True)),           # 192 tiles, 96 K-tiles
+    (6304, 768, 13824, dict(beta=1.0)),                     # d_other of the text-branch routing module: 300 tiles, ragged rows, accumulated
+    (4096, 768, 13824, dict()),                             # ... of the image-branch module: 216 K-tiles
+    (300, 520, 64 * 101, dict(bias=True, act=3, pad=8)),    # ragged rows and columns, an odd K-tile count, gelu + saved pre-activation
+    (4096, 768, 3072, dict(bias=True)),                     # below the threshold: the workspace must not change the launch
+]
+
+
+@pytest.mark.parametrize("lowp", LOWP, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("layout", [0, 1], ids=["NT", "NN"])
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=lambda c: "x".join(map(str, c[:3])))
+def test_in_launch_split_k_products(case, layout, lowp, gpu):
+    """Deep reductions over a partial round of 128 x 128 tiles run with 2-4 workgroups per tile whose partial sums meet inside the
+    launch (d2r_gemm_desc.workspace given): same bound as the unsplit kernel against the fp64 product, bit-identical to itself over
+    repeats on ONE workspace (the tile counters are back at zero after every launch), the workspace's slab region may hold anything,
+    and without a workspace (or with the family switched off) the unsplit kernel answers within a rounding of the 16-bit result."""
+    from d2r_amd import _lib
+    from d2r_amd import functional as F
+    M, N, K, kw = case
+    g = torch.Generator(device=gpu).manual_seed(M + N + K + layout)
+    a = (torch.randn(M, K, device=gpu, generator=g) * 0.5).to(lowp)
+    b = (torch.randn((N, K) if layout == 0 else (K, N), device=gpu, generator=g) * 0.5).to(lowp)
+    ldc = N + kw.get("pad", 0)
+    c0 = torch.randn(M, ldc, device=gpu, generator=g).to(lowp)
+    bias = torch.randn(N, device=gpu, generator=g) if kw.get("bias") else None
+    res = torch.randn(M, N, device=gpu, generator=g).to(lowp) if kw.get("res") else None
+    act, beta = kw.get("act", 0), kw.get("beta", 0.0)
+    dt = _lib.BF16 if lowp == torch.bfloat16 else _lib.F16
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    ws.fill_(0xA5)  # garbage in the slab region ...
+    ws[-4096:].zero_()  # ... the counters start at zero (the contract of d2r_gemm_desc.workspace)
+
+    def run(workspace):
+        c = c0.clone()
+        pre = torch.zeros(M, ldc, device=gpu, dtype=lowp) if act == 3 else None
+        F.gemm(layout, M, N, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), dtype=dt, c_dtype=dt,
+               bias=None if bias is None else bias.data_ptr(), act=act, residual=None if res is None else res.data_ptr(),
+               ldr=0 if res is None else res.stride(0), beta=beta, preact=None if pre is None else pre.data_ptr(), splitk_ws=workspace)
+        torch.cuda.synchronize()
+        return c, pre
+
+    c, pre = run(ws)
+    assert int(ws[-4096:].view(torch.int32).abs().max()) == 0, "a tile counter was left behind"
+    ref = a.double() @ (b.double().t() if layout == 0 else b.double())
+    if bias is not None:
+        ref = ref + bias.double()
+    pre_ref = ref
+    if act == 3:
+        ref = torch.nn.functional.gelu(ref.to(lowp).double())
+    if res is not None:
+        ref = ref + res.double()
+    if beta:
+        ref = ref + beta * c0[:, :N].double()
+    scale = float(ref.abs().max())
+    err = float((c[:, :N].double() - ref).abs().max())
+    assert err <= 2.5 * ULP[lowp] * scale + 1e-6, f"max err {err:.3e} at scale {scale:.3e}"
+    assert torch.equal(c[:, N:], c0[:, N:]), "the padding columns of the output rows were written"
+    if pre is not None:
+        assert float((pre[:, :N].double() - pre_ref).abs().max()) <= 1.5 * ULP[lowp] * float(pre_ref.abs().max()) + 1e-6
+    for _ in range(4):
+        c2, _ = run(ws)
+        assert torch.equal(c2, c), "repeat differs: the partial sums met in a different order, or a stale partial was read"
+    plain, _ = run(None)
+    # (two roundings between the fp32 sum and the stored value - the LDS-staged 16-bit result, then the residual / accumulate add - so
+    #  two neighbouring values: 2 x 2^-10 x scale for fp16)
+    assert float((plain[:, :N].double() - c[:, :N].double()).abs().max()) <= 4.0 * ULP[lowp] * scale + 1e-6
+    if K < 6144:
+        assert torch.equal(plain, c)
+    else:  # (a split sums K in a different order: the fp32 sums differ in their last bits, some 16-bit results with them)
+        assert not torch.equal(plain, c), "the product was not split: the test does not exercise the meeting"
+    _lib.load().d2r_gemm_tuning(1, 1, 130)
+    try:
+        off, _ = run(ws)
+    finally:
+        _lib.load().d2r_gemm_tuning(1, 1, 131)
+    assert torch.equal(off, plain), "with the family switched off a workspace must not change the launch"
