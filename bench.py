@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}  # dense peaks (MI355X_MICROARCH.md); fp16 and bf16 share one
 PRECISION_NOTE = {
     "fp16": "fp16 MFMA operands + fp16 activation storage; fp32 accumulation, LayerNorm/BatchNorm/softmax statistics, poolers, Block, "
             "loss and master weights; dynamic loss scale with the overflow check inside the step. Logits/loss within 1e-3 of the "
@@ -332,6 +332,7 @@ def main():
         "metric": "samples/sec fwd+bwd", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "precision": PRECISION_NOTE[args.dtype], "data": "synthetic",
+        "headline_dtype_history": "value is the fp16 compute mode since round 3 (BENCH_r01 / r02: bf16); the bf16 mode of this build is bf16_path",
         "config": {"workload": "%s: synthetic MVSA-Single-style batch, per-GPU batch %d, seq_len %d, %d image tokens, "
                                "DR_step %d, %d cells per routing layer, %d classes, %d+%d encoder layers, random-init weights, dropout %g; "
                                "step = fwd+bwd+grad-allreduce+AdamW"
@@ -480,7 +481,7 @@ def main():
             ent = {"kernel": name, "launches_per_step": calls // 2, "ms_per_step": round(r["ms"] / 2, 4),
                    "avg_us": round(r["ms"] * 1e3 / calls, 2)}
             if name.startswith("gemm_"):
-                key = "f32" if "f32" in name else "bf16"  # (fp16 and bf16 share the dense MFMA peak)
+                key = "f32" if "f32" in name else ("fp16" if "_f16_" in name else "bf16")
                 ach = r["flops"] / t_s / 1e12
                 ent.update(bound="mfma", achieved=round(ach, 2), peak=MFMA_PEAK_TF[key], unit="TFLOP/s",
                            frac=round(ach / MFMA_PEAK_TF[key], 4), algo_bytes_per_launch=round(r["bytes"] / calls))

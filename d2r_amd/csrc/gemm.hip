@@ -427,8 +427,12 @@ static std::vector<GemmTimerRec> g_timer_recs;
 static std::mutex g_timer_mu;
 static volatile int g_timer_on = 0;
 
+// An op that is itself timed (d2r_xattn_bwd_multi) may reach GEMM entry points with scopes of their own (its second-generation fallback):
+// only the OUTERMOST scope of a thread records, or the same GPU time would appear under two families.
+static thread_local int g_timer_depth = 0;
 D2RTimerScope::D2RTimerScope(hipStream_t stream, int fam, double fl, double by) : family(fam), flops(fl), bytes(by), st(stream) {
   if (fam < 10000) d2r_gemm_variant_tl = 0;
+  if (g_timer_depth++ > 0) return;
   if (!g_timer_on) return;
   if (hipEventCreate(&e0) != hipSuccess) return;
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
@@ -436,6 +440,7 @@ D2RTimerScope::D2RTimerScope(hipStream_t stream, int fam, double fl, double by) 
   armed = true;
 }
 D2RTimerScope::~D2RTimerScope() {
+  --g_timer_depth;
   if (!armed) return;
   GemmTimerRec rec;
   rec.family = family < 10000 ? family + 100 * d2r_gemm_variant_tl : family;
