@@ -32,13 +32,18 @@ for init_seed, batch_seed in ((2023, 6), (2023, 7), (2023, 8), (2023, 9), (7, 6)
     (loss * 1024.0).backward()
     torch.cuda.synchronize()
     dot = ng = nr = 0.0
+    side = [0.0, 0.0, 0.0]  # parameters that do not sit behind Block's signed square root (they see the JS loss only)
     for name, p in model.named_parameters():
         ref = osd[name].grad
         if ref is None or p.grad is None:
             continue
         got = p.grad.detach().double().cpu() / 1024.0
-        dot += float((got * ref).sum()); ng += float(got.pow(2).sum()); nr += float(ref.pow(2).sum())
+        d_, g_, r_ = float((got * ref).sum()), float(got.pow(2).sum()), float(ref.pow(2).sum())
+        dot += d_; ng += g_; nr += r_
+        if name.startswith(("model.self_text", "model.self_vision", "model.text_cls_pool", "model.vision_cls_pool")):
+            side = [side[0] + d_, side[1] + g_, side[2] + r_]
     cos = dot / (ng * nr) ** 0.5
     out.append(cos)
-    print("init %4d batch %2d: loss err %.2e  cos %.4f  |g|/|ref| %.3f" % (init_seed, batch_seed, abs(float(loss) - float(lo)), cos, (ng / nr) ** 0.5), flush=True)
+    print("init %4d batch %2d: loss err %.2e  cos %.4f  |g|/|ref| %.3f  side cos %.5f" % (init_seed, batch_seed, abs(float(loss) - float(lo)), cos, (ng / nr) ** 0.5,
+          side[0] / max((side[1] * side[2]) ** 0.5, 1e-300)), flush=True)
 print("min %.4f median %.4f max %.4f" % (min(out), sorted(out)[len(out) // 2], max(out)))

@@ -529,6 +529,65 @@ def test_default_init_gradients_vs_oracle(gpu, dtype):
         assert min(part_cos.values()) >= 0.7, part_cos
 
 
+def test_default_init_fp16_gradient_statistics_over_seeds(gpu):
+    """The cosine of the fp16 gradient against the fp64 oracle is a heavy-tailed statistic: every gradient that
+    reaches the encoders passes through Block's signed square root, whose derivative 0.5 / sqrt|z| is unbounded at zero, so a draw in which
+    an element of z lands near zero is dominated by the fp16 rounding of the pooled vectors.  The single-seed gate above (seed 2023 / 6)
+    is one draw; this test holds the DISTRIBUTION over eight (init, batch) seeds and, per draw, what does not depend on the tail:
+      * every draw: loss within 1e-4 of the oracle, and the parameters that do not sit behind Block (the extra self layers and cls
+        poolers: they see the JS loss only) at cosine >= 0.9995 (measured 0.99992-0.99997) - the per-draw check of the backward kernels;
+      * over the draws: median cosine >= 0.9 and at least six of eight >= 0.75.
+    Measured on MI355X with three builds that differ in rounding-level details of two kernels (profiles/grad_cos_seeds_r04.log):
+    medians 0.973 / 0.944 / 0.984, minima 0.29 / 0.18 / 0.82, seven or eight of eight above 0.75."""
+    O, _ = _oracle()
+    from d2r_amd import modules as M
+    from d2r_amd.config import TextConfig, VisionConfig, default_args
+    from d2r_amd.params import ParamStore
+    dtype = torch.float16
+    layers, B, L = 2, 4, 24
+    cosines = []
+    for init_seed, batch_seed in ((2023, 6), (2023, 7), (2023, 8), (2023, 9), (7, 6), (11, 6), (13, 7), (17, 8)):
+        torch.manual_seed(init_seed)
+        tc = TextConfig(num_hidden_layers=layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        vc = VisionConfig(num_hidden_layers=layers, image_size=96, patch_size=32)
+        model = M.UnimoModelF(default_args(), vc, tc)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        cfg = O.OracleConfig(text_layers=layers, vision_layers=layers, image_size=96, patch_size=32)
+        ids, mask, tt, labels, images = O.synthetic_batch(cfg, B, L, seed=batch_seed)
+        osd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+               for k, v in sd.items()}
+        lo, _, _ = O.forward(osd, cfg, ids, mask, tt, labels, images.double(), train=True)
+        lo.backward()
+        model.to(gpu).set_compute_dtype(dtype).train()
+        ParamStore(model, dtype)
+        loss, _ = model(ids.to(gpu), mask.to(gpu), tt.to(gpu), labels.to(gpu), images.to(gpu))
+        _backward(loss, dtype, list(model.parameters()))
+        torch.cuda.synchronize()
+        dot = ng = nr = 0.0
+        side = [0.0, 0.0, 0.0]
+        for name, p in model.named_parameters():
+            ref = osd[name].grad
+            if ref is None or p.grad is None:
+                continue
+            got = p.grad.detach().double().cpu()
+            assert torch.isfinite(got).all(), name
+            d_, g_, r_ = float((got * ref).sum()), float(got.pow(2).sum()), float(ref.pow(2).sum())
+            dot, ng, nr = dot + d_, ng + g_, nr + r_
+            if name.startswith(("model.self_text", "model.self_vision", "model.text_cls_pool", "model.vision_cls_pool")):
+                side = [side[0] + d_, side[1] + g_, side[2] + r_]
+        cos = dot / (ng * nr) ** 0.5
+        cos_side = side[0] / max((side[1] * side[2]) ** 0.5, 1e-300)
+        e_loss = abs(float(loss) - float(lo))
+        print(f"    init {init_seed} batch {batch_seed}: loss err {e_loss:.2e} cosine {cos:.4f} (not behind Block: {cos_side:.5f})")
+        assert e_loss <= 1e-4, (init_seed, batch_seed, e_loss)
+        assert cos_side >= 0.9995, (init_seed, batch_seed, cos_side)
+        cosines.append(cos)
+    ranked = sorted(cosines)
+    median = 0.5 * (ranked[3] + ranked[4])
+    print(f"    cosines {[round(c, 4) for c in cosines]}: median {median:.4f}, min {ranked[0]:.4f}")
+    assert median >= 0.9 and sum(c >= 0.75 for c in cosines) >= 6, cosines
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(1, 1), (3, 5)], ids=lambda s: f"B{s[0]}L{s[1]}")
 def test_degenerate_shapes_vs_oracle(gpu, shape, dtype):
