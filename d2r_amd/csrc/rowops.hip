@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             T* __restrict__ dX, float* __restrict__ ws,
                                                             const T* __restrict__ dres) {
   constexpr int VEC = PackOf<T>::N;
-  extern __shared__ float sh[];  // [4][2][D]
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [4][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int npk = D / VEC;
   float dg[MAXP][VEC], db[MAXP][VEC], gm[MAXP][VEC];
@@ -401,10 +401,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int i = 0; i < MAXP; ++i) {
     const int pk = lane + i * 64;
     if (pk < npk) {
+      // 16-byte LDS stores (a lane's VEC consecutive columns): written one float at a time the lanes of a wave are 32 bytes apart and hit
+      // eight banks - SQ_LDS_BANK_CONFLICT was 59 % of this kernel's LDS cycles (tests/probes/pmc_lds.sh, round 4)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        sh[(wave * 2 + 0) * D + pk * VEC + j] = dg[i][j];
-        sh[(wave * 2 + 1) * D + pk * VEC + j] = db[i][j];
+      for (int j = 0; j < VEC; j += 4) {
+        Pack<float, 4> pg, pb;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pg.v[u] = dg[i][j + u], pb.v[u] = db[i][j + u];
+        st_pack<float, 4>(&sh[(wave * 2 + 0) * D + pk * VEC + j], pg);
+        st_pack<float, 4>(&sh[(wave * 2 + 1) * D + pk * VEC + j], pb);
       }
     }
   }
