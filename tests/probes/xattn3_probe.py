@@ -4,7 +4,10 @@ NOTE: D2R_X3_DBG / D2R_X3_STAMPS act only on a measurement build of the library:
 import os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from d2r_amd import _lib, functional as F
+from d2r_amd import _lib
+if os.environ.get("PROBE_LIB"):  # A/B of two builds of the library in one GPU call
+    _lib.LIB_PATH = os.path.abspath(os.environ["PROBE_LIB"])
+from d2r_amd import functional as F
 
 dev = torch.device("cuda:0")
 E, B, nc = 768, 32, 3
