@@ -136,6 +136,8 @@ SIGNATURES = {
     "d2r_lerp_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),
     "d2r_lerp_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "d2r_add": (i32, [i32, vp, vp, vp, i64, vp]),
+    "d2r_add2": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "d2r_act_bwd2": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
     "d2r_dropout": (i32, [i32, vp, vp, vp, i64, f32, C.c_uint64, vp]),
     "d2r_lincomb": (i32, [C.POINTER(vp), C.POINTER(f32), i32, vp, vp]),
     "d2r_axpby": (i32, [i32, f32, vp, f32, vp, i64, vp]),

@@ -570,8 +570,7 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
   TRY(grp.flush(c));
   if (nc > 1) TRY(d2r_l2norm_bwd(c.dt, K.g_dl2, L.g_loc, L.g_nloc, K.g_dloc, T, E, c.st));
   if (nc > 4) {
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dQs, L.r_Qs, K.r_dQsp, TEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.r_dKs, L.r_Ks, K.r_dKsp, TEn, c.st));
+    TRY(d2r_act_bwd2(c.dt, D2R_ACT_TANH, K.r_dQs, L.r_Qs, K.r_dQsp, K.r_dKs, L.r_Ks, K.r_dKsp, TEn, c.st));
   }
   // --- group B2: the first linears, backwards ------------------------------------------------------------------------------------------------
   if (nc > 2) {
@@ -651,8 +650,7 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     TRY(dxg(c, B, E, E, K.g_dglo, E, lp[D2R_RL_GLAC_GLO].w, K.g_ddg, E));
     defer(jobs, B, E, E, K.g_dglo, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO]);
     TRY(d2r_sqdiff_bwd(c.dt, L.g_pt, L.g_pi, K.g_ddg, K.g_dpt, K.g_dpi, BEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.g_dpt, L.g_pt, K.g_dptp, BEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.g_dpi, L.g_pi, K.g_dpip, BEn, c.st));
+    TRY(d2r_act_bwd2(c.dt, D2R_ACT_TANH, K.g_dpt, L.g_pt, K.g_dptp, K.g_dpi, L.g_pi, K.g_dpip, BEn, c.st));
     TRY(dxg(c, B, E, E, K.g_dptp, E, lp[D2R_RL_GLAC_TPOOL].w, dx[1], TEe, 1.f));  // token 0 of every sample
     defer(jobs, B, E, E, K.g_dptp, E, x, TEe, lp[D2R_RL_GLAC_TPOOL]);
     TRY(dxg(c, B, E, E, K.g_dpip, E, lp[D2R_RL_GLAC_IPOOL].w, d_other, SEe, 1.f));
@@ -666,10 +664,8 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     defer(jobs, B, E, E, K.s_dz, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2]);
     TRY(dxg(c, B, E, E, K.s_dz1p, E, lp[D2R_RL_GESC_MLP0].w, K.s_dab, E));
     defer(jobs, B, E, E, K.s_dz1p, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0]);
-    TRY(d2r_add(c.dt, K.s_da1, K.s_dab, K.s_dat, BEn, c.st));
-    TRY(d2r_add(c.dt, K.s_db1, K.s_dab, K.s_dbt, BEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dat, L.s_a, K.s_dap, BEn, c.st));
-    TRY(d2r_act_bwd(c.dt, D2R_ACT_TANH, K.s_dbt, L.s_b, K.s_dbp, BEn, c.st));
+    TRY(d2r_add2(c.dt, K.s_da1, K.s_dab, K.s_dat, K.s_db1, K.s_dab, K.s_dbt, BEn, c.st));
+    TRY(d2r_act_bwd2(c.dt, D2R_ACT_TANH, K.s_dat, L.s_a, K.s_dap, K.s_dbt, L.s_b, K.s_dbp, BEn, c.st));
     TRY(dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f));
     defer(jobs, B, E, E, K.s_dap, E, x, TEe, lp[D2R_RL_GESC_TPOOL]);
     TRY(dxg(c, B, E, E, K.s_dbp, E, lp[D2R_RL_GESC_IPOOL].w, d_other, SEe, 1.f));

@@ -185,6 +185,11 @@ int d2r_lerp_bwd(int dtype, const void* g, const void* a, const void* b, const v
  * (seed, i): the backward pass calls the same entry point on dy with the same seed — no mask is stored. */
 int d2r_dropout(int dtype, const void* x, const void* add, void* y, int64_t n, float p, uint64_t seed, void* stream);
 int d2r_add(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
+/* two independent problems of one size in one launch (element for element the arithmetic of two d2r_add / d2r_act_bwd calls): the
+ * text / image and a / b pairs of per-sample vectors in the routing cells' backward (models/Cells.py:179-218, :222-255) */
+int d2r_add2(int dtype, const void* a1, const void* b1, void* out1, const void* a2, const void* b2, void* out2, int64_t n, void* stream);
+int d2r_act_bwd2(int dtype, int act, const void* dY1, const void* ref1, void* dX1, const void* dY2, const void* ref2, void* dX2, int64_t n,
+                 void* stream);
 /* out[0] = sum_k h_coef[k] * x_k[0]  (n <= 8 fp32 device scalars): loss = CE - w1*JS1 - w2*JS2 */
 int d2r_lincomb(const float* const* h_x, const float* h_coef, int n, float* out, void* stream);
 /* y = alpha*x + beta*y (dtype T), used for gradient accumulation ; cast between dtypes */

@@ -1072,3 +1072,30 @@ def test_xattn_multi_launch_matches_single_launches(gpu, lowp, cfg):
         dk_ref = dS64.transpose(1, 2) @ q[c].double().cpu()
         check(f"dv[{c}]", b[1][c][..., E:], dv_ref, lowp)
         check(f"dk[{c}]", b[1][c][..., :E], dk_ref, lowp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "fp16"])
+def test_dual_elementwise_launches_equal_two_single_launches(gpu, dtype):
+    """d2r_add2 / d2r_act_bwd2 run two independent problems of one size in one launch (the text / image and a / b pairs of the routing
+    cells' backward): element for element the arithmetic of two single calls, so the results are bit-identical - also for a size
+    that is not a multiple of the pack width and for unaligned operands (the scalar tail / scalar path)."""
+    from d2r_amd import _lib
+    from d2r_amd import functional as F
+    dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype]
+    st = F._stream()
+    g = torch.Generator(device=gpu).manual_seed(3)
+    for n, off in ((32 * 768, 0), (1003, 0), (4099, 1)):
+        t = [torch.randn(n + 8, device=gpu, generator=g).to(dtype)[off:off + n] for _ in range(4)]
+        for act in (_lib.ACT_TANH, _lib.ACT_RELU):
+            o1, o2, p1, p2 = (torch.empty(n + 8, device=gpu, dtype=dtype)[off:off + n] for _ in range(4))
+            _lib.call("d2r_act_bwd", dt, act, t[0].data_ptr(), t[1].data_ptr(), o1.data_ptr(), n, st)
+            _lib.call("d2r_act_bwd", dt, act, t[2].data_ptr(), t[3].data_ptr(), o2.data_ptr(), n, st)
+            _lib.call("d2r_act_bwd2", dt, act, t[0].data_ptr(), t[1].data_ptr(), p1.data_ptr(), t[2].data_ptr(), t[3].data_ptr(), p2.data_ptr(), n, st)
+            torch.cuda.synchronize()
+            assert torch.equal(o1, p1) and torch.equal(o2, p2), (n, off, "act_bwd2")
+        o1, o2, p1, p2 = (torch.empty(n + 8, device=gpu, dtype=dtype)[off:off + n] for _ in range(4))
+        _lib.call("d2r_add", dt, t[0].data_ptr(), t[1].data_ptr(), o1.data_ptr(), n, st)
+        _lib.call("d2r_add", dt, t[2].data_ptr(), t[1].data_ptr(), o2.data_ptr(), n, st)
+        _lib.call("d2r_add2", dt, t[0].data_ptr(), t[1].data_ptr(), p1.data_ptr(), t[2].data_ptr(), t[1].data_ptr(), p2.data_ptr(), n, st)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, p1) and torch.equal(o2, p2), (n, off, "add2")
