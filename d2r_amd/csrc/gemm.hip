@@ -695,7 +695,7 @@ static bool rank_tn_f32_try(const GemmArgs& a, int batch, hipStream_t st) {
 // saved pre-activation, activation, activation gradient of a reference, residual, beta), 16-bit or fp32 output.  Replaces, per
 // call, a 32x64-tile launch over split-K slabs plus its reduce launch (about 110 launches per training step).
 template <typename E, int LAYOUT>
-__global__ __launch_bounds__(256) void gemm_skinny_h16_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_skinny_h16_body(const GemmArgs& g, int n0) {
   typedef typename H16<E>::v8 E8;
   typedef typename H16<E>::v4 E4;
   constexpr int MAXS = 8;  // k-steps of 32 per wave and pass: K = 1024 per pass
@@ -706,7 +706,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_h16_kernel(GemmArgs g) {
   const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const E* A = reinterpret_cast<const E*>(g.A);
   const E* B = reinterpret_cast<const E*>(g.B);
-  const int n0 = blockIdx.x * 16;
   const int col = min(n0 + fr, g.N - 1);  // clamped: the matching outputs are not stored
   const int r0 = min(fr, g.M - 1), r1 = min(16 + fr, g.M - 1);
   const bool two = g.M > 16;
@@ -776,14 +775,48 @@ __global__ __launch_bounds__(256) void gemm_skinny_h16_kernel(GemmArgs g) {
     store_c(g.C, g.c_dtype, ci, v);
   }
 }
-
 template <typename E, int LAYOUT>
-static bool skinny_h16_try(const GemmArgs& a, int batch, hipStream_t st) {
+__global__ __launch_bounds__(256) void gemm_skinny_h16_kernel(GemmArgs g) {
+  gemm_skinny_h16_body<E, LAYOUT>(g, blockIdx.x * 16);
+}
+// up to four INDEPENDENT skinny products in one launch (grid y = problem): the per-sample linears of different routing cells that are
+// ready at the same point of a layer (text pool | image pool of GLAC's global branch and of GESC, ...) - 7 us of latency each for
+// microseconds of nothing.  Every workgroup runs the body of the single launch: bit-identical results.
+constexpr int D2R_SKINNY_GROUP_MAX = 4;
+struct SkinnyGroup {
+  GemmArgs a[D2R_SKINNY_GROUP_MAX];
+};
+template <typename E, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_skinny_h16_group_kernel(SkinnyGroup grp) {
+  const GemmArgs& g = grp.a[blockIdx.y];
+  const int n0 = blockIdx.x * 16;
+  if (n0 >= g.N) return;  // (the grid is as wide as the widest problem)
+  gemm_skinny_h16_body<E, LAYOUT>(g, n0);
+}
+
+template <int LAYOUT>
+static bool skinny_h16_ok(const GemmArgs& a, int batch) {
   if (!g_skinny || batch != 1 || a.M > 32 || a.M < 1 || a.K < 64 || a.K % 32 != 0 || a.dbias || !a.vecA || !a.vecB) return false;
   if (LAYOUT == D2R_GEMM_NN && a.N % 16 != 0) return false;  // (a 16-column slab per workgroup is loaded unguarded)
+  return true;
+}
+template <typename E, int LAYOUT>
+static bool skinny_h16_try(const GemmArgs& a, int batch, hipStream_t st) {
+  if (!skinny_h16_ok<LAYOUT>(a, batch)) return false;
   hipLaunchKernelGGL((gemm_skinny_h16_kernel<E, LAYOUT>), dim3(d2r_cdiv(a.N, 16)), dim3(256), 0, st, a);
   d2r_gemm_variant_tl = 31;
   return true;
+}
+template <typename E, int LAYOUT>
+static void skinny_h16_group_launch(const GemmArgs* probs, int n, hipStream_t st) {
+  SkinnyGroup grp = {};
+  int gx = 1;
+  for (int i = 0; i < n; ++i) {
+    grp.a[i] = probs[i];
+    gx = std::max(gx, d2r_cdiv(probs[i].N, 16));
+  }
+  hipLaunchKernelGGL((gemm_skinny_h16_group_kernel<E, LAYOUT>), dim3(gx, n), dim3(256), 0, st, grp);
+  d2r_gemm_variant_tl = 31;
 }
 
 // ---- 16-bit matrix-vector product: C[M,1] = act(alpha * A[M,K] b[K] + bias) (N = 1, e.g. the SAF scores a = S w of 4-6 thousand rows):
@@ -1054,6 +1087,39 @@ extern "C" int d2r_gemm_group(const d2r_gemm_desc* descs, int n, void* stream) {
         }
         GemmTimerScope timed(st, dtype * 8 + layout * 2, fl, by);
         if (int rc = d2r_gemm_glds_group_launch(probs.data(), m, layout, st)) return rc;
+      }
+    }
+  }
+  // the per-sample products (at most 32 rows): up to four of one layout and type per launch
+  for (int layout : {D2R_GEMM_NT, D2R_GEMM_NN}) {
+    for (int dtype : {D2R_BF16, D2R_F16}) {
+      std::vector<int> idx;
+      for (int i = 0; i < n; ++i) {
+        const d2r_gemm_desc& d = descs[i];
+        if (grouped[i] || !g_group || g_tile >= 0 || d.layout != layout || d.dtype != dtype || d.M == 0 || d.N == 0 || d.M > 32) continue;
+        int batch = 1;
+        if (int rc = gemm_desc_to_args(&d, args[i], batch)) return rc;
+        if (layout == D2R_GEMM_NT ? skinny_h16_ok<D2R_GEMM_NT>(args[i], batch) : skinny_h16_ok<D2R_GEMM_NN>(args[i], batch)) idx.push_back(i);
+      }
+      if (idx.size() < 2) continue;
+      for (size_t first = 0; first + 1 < idx.size(); first += D2R_SKINNY_GROUP_MAX) {  // (a last problem alone: its own launch below)
+        const int m = (int)std::min<size_t>(D2R_SKINNY_GROUP_MAX, idx.size() - first);
+        GemmArgs probs[D2R_SKINNY_GROUP_MAX];
+        double fl = 0, by = 0;
+        for (int k = 0; k < m; ++k) {
+          const int i = idx[first + k];
+          probs[k] = args[i], grouped[i] = 1;
+          fl += gemm_desc_flops(&descs[i]), by += gemm_desc_bytes(&descs[i]);
+        }
+        GemmTimerScope timed(st, dtype * 8 + layout * 2, fl, by);
+        if (dtype == D2R_F16) {
+          if (layout == D2R_GEMM_NT) skinny_h16_group_launch<f16_t, D2R_GEMM_NT>(probs, m, st);
+          else skinny_h16_group_launch<f16_t, D2R_GEMM_NN>(probs, m, st);
+        } else {
+          if (layout == D2R_GEMM_NT) skinny_h16_group_launch<bf16_t, D2R_GEMM_NT>(probs, m, st);
+          else skinny_h16_group_launch<bf16_t, D2R_GEMM_NN>(probs, m, st);
+        }
+        if (int rc = d2r_check_launch("d2r_gemm_group(skinny)")) return rc;
       }
     }
   }

@@ -325,16 +325,29 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
       TRY(d2r_xattn_fwd_multi(c.dt, ncore, qa, E, TEe, ka, d.ldkv, (int64_t)d.Lk * d.ldkv, va, d.ldkv, (int64_t)d.Lk * d.ldkv, oa, E, TEe, nullptr, E,
                               TEe, nullptr, la, B, d.Lq, d.Lk, E, XSCALE, c.st));
   }
-  // --- GLAC (cell 1), global branch: per-sample vectors -------------------------------------------------------------------------------
-  if (nc > 1) {
-    const void* x = refs[1];
-    TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GLAC_TPOOL], L.g_pt, D2R_ACT_TANH));
-    TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GLAC_IPOOL], L.g_pi, D2R_ACT_TANH));
-    TRY(d2r_sqdiff_fwd(c.dt, L.g_pt, L.g_pi, L.g_dg, (int64_t)B * E, c.st));
-    TRY(lin(c, B, E, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO], L.g_glo));
-    TRY(d2r_l2norm_fwd(c.dt, L.g_glo, L.g_l2g, L.g_nglo, B, E, c.st));
-    TRY(lin(c, B, E, E, L.g_l2g, E, lp[D2R_RL_GLAC_FC2], L.g_sg));
-    TRY(d2r_sqdiff_fwd(c.dt, x, L.g_c, L.g_sq, (int64_t)T * E, c.st));  // local branch: (t - c)^2 behind the core
+  // --- the per-sample vector chains: GLAC's (cell 1) global branch and GESC (cell 5).  Both read only the layer's inputs and are independent
+  //     of each other: their linears (32 rows: latency, not work) go in lock step, one grouped launch per stage (d2r_gemm_group) --------
+  {
+    Group pg;
+    if (nc > 1) pg.lin(c, B, E, E, refs[1], TEe, lp[D2R_RL_GLAC_TPOOL], L.g_pt, D2R_ACT_TANH);
+    if (nc > 1) pg.lin(c, B, E, E, other, SEe, lp[D2R_RL_GLAC_IPOOL], L.g_pi, D2R_ACT_TANH);
+    if (nc > 5) pg.lin(c, B, E, E, refs[5], TEe, lp[D2R_RL_GESC_TPOOL], L.s_a, D2R_ACT_TANH);
+    if (nc > 5) pg.lin(c, B, E, E, other, SEe, lp[D2R_RL_GESC_IPOOL], L.s_b, D2R_ACT_TANH);
+    TRY(pg.flush(c));
+    if (nc > 1) TRY(d2r_sqdiff_fwd(c.dt, L.g_pt, L.g_pi, L.g_dg, (int64_t)B * E, c.st));
+    if (nc > 5) TRY(d2r_add(c.dt, L.s_a, L.s_b, L.s_ab, (int64_t)B * E, c.st));
+    if (nc > 1) pg.lin(c, B, E, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO], L.g_glo);
+    if (nc > 5) pg.lin(c, B, E, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0], L.s_z1, D2R_ACT_TANH);
+    TRY(pg.flush(c));
+    if (nc > 1) TRY(d2r_l2norm_fwd(c.dt, L.g_glo, L.g_l2g, L.g_nglo, B, E, c.st));
+    if (nc > 1) pg.lin(c, B, E, E, L.g_l2g, E, lp[D2R_RL_GLAC_FC2], L.g_sg);
+    if (nc > 5) pg.lin(c, B, E, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2], L.s_z);
+    TRY(pg.flush(c));
+    if (nc > 5) {
+      TRY(d2r_softmax_fwd(c.dt, c.dt, L.s_z, L.s_g, E, B, E, 1.0f, nullptr, 1, c.st));
+      TRY(d2r_lerp_fwd(c.dt, L.s_g, L.s_a, L.s_b, L.e5, (int64_t)B * E, c.st));
+    }
+    if (nc > 1) TRY(d2r_sqdiff_fwd(c.dt, refs[1], L.g_c, L.g_sq, (int64_t)T * E, c.st));  // GLAC's local branch: (t - c)^2 behind the core
   }
   // --- group B: the first linears behind the cores and behind IMRC's attention ---------------------------------------------------------
   if (nc > 2) grp.lin(c, T, d.hidi, E, L.y, E, lp[D2R_RL_IMRC_FC1], L.f1, D2R_ACT_RELU);
@@ -375,17 +388,6 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     g.batch(B, n, (int64_t)n * E, E);
     TRY(d2r_gemm(&g.d, c.st));
     TRY(d2r_l2norm_fwd(c.dt, L.g_wsum, L.e1, L.g_ne1, B, E, c.st));
-  }
-  // --- GESC (cell 5): per-sample vectors ------------------------------------------------------------------------------------------------------
-  if (nc > 5) {
-    const void* x = refs[5];
-    TRY(lin(c, B, E, E, x, TEe, lp[D2R_RL_GESC_TPOOL], L.s_a, D2R_ACT_TANH));
-    TRY(lin(c, B, E, E, other, SEe, lp[D2R_RL_GESC_IPOOL], L.s_b, D2R_ACT_TANH));
-    TRY(d2r_add(c.dt, L.s_a, L.s_b, L.s_ab, (int64_t)B * E, c.st));
-    TRY(lin(c, B, E, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0], L.s_z1, D2R_ACT_TANH));
-    TRY(lin(c, B, E, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2], L.s_z));
-    TRY(d2r_softmax_fwd(c.dt, c.dt, L.s_z, L.s_g, E, B, E, 1.0f, nullptr, 1, c.st));
-    TRY(d2r_lerp_fwd(c.dt, L.s_g, L.s_a, L.s_b, L.e5, (int64_t)B * E, c.st));
   }
   // --- K8: path normalisation, gates, aggregation ------------------------------------------------------------------
   const void* embs[6] = {refs[0], L.e1, L.e2, L.e3, L.e4, L.e5};
@@ -642,34 +644,62 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
                               d.ldkv, skv, pa, dsa, d.lkp, B, d.Lq, d.Lk, E, XSCALE, c.st));
   }
   // --- the per-sample vector chains: GLAC's global branch, GESC (both accumulate into the cls rows of dx[1] / dx[5] and d_other) ----------
-  if (nc > 1) {
-    const void* x = refs[1];
-    TRY(dxg(c, B, E, E, K.g_dS, ldsg, lp[D2R_RL_GLAC_FC2].w, K.g_dl2g, E));
-    defer(jobs, B, E, E, K.g_dS, ldsg, L.g_l2g, E, lp[D2R_RL_GLAC_FC2]);
-    TRY(d2r_l2norm_bwd(c.dt, K.g_dl2g, L.g_glo, L.g_nglo, K.g_dglo, B, E, c.st));
-    TRY(dxg(c, B, E, E, K.g_dglo, E, lp[D2R_RL_GLAC_GLO].w, K.g_ddg, E));
-    defer(jobs, B, E, E, K.g_dglo, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO]);
-    TRY(d2r_sqdiff_bwd(c.dt, L.g_pt, L.g_pi, K.g_ddg, K.g_dpt, K.g_dpi, BEn, c.st));
-    TRY(d2r_act_bwd2(c.dt, D2R_ACT_TANH, K.g_dpt, L.g_pt, K.g_dptp, K.g_dpi, L.g_pi, K.g_dpip, BEn, c.st));
-    TRY(dxg(c, B, E, E, K.g_dptp, E, lp[D2R_RL_GLAC_TPOOL].w, dx[1], TEe, 1.f));  // token 0 of every sample
-    defer(jobs, B, E, E, K.g_dptp, E, x, TEe, lp[D2R_RL_GLAC_TPOOL]);
-    TRY(dxg(c, B, E, E, K.g_dpip, E, lp[D2R_RL_GLAC_IPOOL].w, d_other, SEe, 1.f));
-    defer(jobs, B, E, E, K.g_dpip, E, other, SEe, lp[D2R_RL_GLAC_IPOOL]);
-  }
-  if (nc > 5) {
-    const void* x = refs[5];
-    TRY(d2r_lerp_bwd(c.dt, L.s_g, L.s_a, L.s_b, K.de[5], K.s_dg, K.s_da1, K.s_db1, BEn, c.st));
-    TRY(d2r_softmax_bwd(c.dt, c.dt, L.s_g, K.s_dg, K.s_dz, E, B, E, 1.0f, c.st));
-    TRY(dxg(c, B, E, E, K.s_dz, E, lp[D2R_RL_GESC_MLP2].w, K.s_dz1p, E, 0.f, nullptr, L.s_z1, D2R_ACT_TANH));
-    defer(jobs, B, E, E, K.s_dz, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2]);
-    TRY(dxg(c, B, E, E, K.s_dz1p, E, lp[D2R_RL_GESC_MLP0].w, K.s_dab, E));
-    defer(jobs, B, E, E, K.s_dz1p, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0]);
-    TRY(d2r_add2(c.dt, K.s_da1, K.s_dab, K.s_dat, K.s_db1, K.s_dab, K.s_dbt, BEn, c.st));
-    TRY(d2r_act_bwd2(c.dt, D2R_ACT_TANH, K.s_dat, L.s_a, K.s_dap, K.s_dbt, L.s_b, K.s_dbp, BEn, c.st));
-    TRY(dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f));
-    defer(jobs, B, E, E, K.s_dap, E, x, TEe, lp[D2R_RL_GESC_TPOOL]);
-    TRY(dxg(c, B, E, E, K.s_dbp, E, lp[D2R_RL_GESC_IPOOL].w, d_other, SEe, 1.f));
-    defer(jobs, B, E, E, K.s_dbp, E, other, SEe, lp[D2R_RL_GESC_IPOOL]);
+  //     in lock step: the dX products of the two chains (32 rows each) leave as one grouped launch per stage; the accumulating tails are
+  //     grouped where they write different buffers (layer 0: all dx[j] alias d_own; both image-pool tails add into d_other)
+  {
+    Group pg;
+    if (nc > 5) {
+      TRY(d2r_lerp_bwd(c.dt, L.s_g, L.s_a, L.s_b, K.de[5], K.s_dg, K.s_da1, K.s_db1, BEn, c.st));
+      TRY(d2r_softmax_bwd(c.dt, c.dt, L.s_g, K.s_dg, K.s_dz, E, B, E, 1.0f, c.st));
+    }
+    if (nc > 1) {
+      pg.dxg(c, B, E, E, K.g_dS, ldsg, lp[D2R_RL_GLAC_FC2].w, K.g_dl2g, E);
+      defer(jobs, B, E, E, K.g_dS, ldsg, L.g_l2g, E, lp[D2R_RL_GLAC_FC2]);
+    }
+    if (nc > 5) {
+      pg.dxg(c, B, E, E, K.s_dz, E, lp[D2R_RL_GESC_MLP2].w, K.s_dz1p, E, 0.f, nullptr, L.s_z1, D2R_ACT_TANH);
+      defer(jobs, B, E, E, K.s_dz, E, L.s_z1, E, lp[D2R_RL_GESC_MLP2]);
+    }
+    TRY(pg.flush(c));
+    if (nc > 1) {
+      TRY(d2r_l2norm_bwd(c.dt, K.g_dl2g, L.g_glo, L.g_nglo, K.g_dglo, B, E, c.st));
+      pg.dxg(c, B, E, E, K.g_dglo, E, lp[D2R_RL_GLAC_GLO].w, K.g_ddg, E);
+      defer(jobs, B, E, E, K.g_dglo, E, L.g_dg, E, lp[D2R_RL_GLAC_GLO]);
+    }
+    if (nc > 5) {
+      pg.dxg(c, B, E, E, K.s_dz1p, E, lp[D2R_RL_GESC_MLP0].w, K.s_dab, E);
+      defer(jobs, B, E, E, K.s_dz1p, E, L.s_ab, E, lp[D2R_RL_GESC_MLP0]);
+    }
+    TRY(pg.flush(c));
+    if (nc > 1) {
+      TRY(d2r_sqdiff_bwd(c.dt, L.g_pt, L.g_pi, K.g_ddg, K.g_dpt, K.g_dpi, BEn, c.st));
+      TRY(d2r_act_bwd2(c.dt, D2R_ACT_TANH, K.g_dpt, L.g_pt, K.g_dptp, K.g_dpi, L.g_pi, K.g_dpip, BEn, c.st));
+    }
+    if (nc > 5) {
+      TRY(d2r_add2(c.dt, K.s_da1, K.s_dab, K.s_dat, K.s_db1, K.s_dab, K.s_dbt, BEn, c.st));
+      TRY(d2r_act_bwd2(c.dt, D2R_ACT_TANH, K.s_dat, L.s_a, K.s_dap, K.s_dbt, L.s_b, K.s_dbp, BEn, c.st));
+    }
+    // tails (beta = 1).  Order of the additions into a buffer as in the sequential schedule: GLAC's before GESC's.
+    if (nc > 1) {
+      pg.dxg(c, B, E, E, K.g_dptp, E, lp[D2R_RL_GLAC_TPOOL].w, dx[1], TEe, 1.f);  // token 0 of every sample
+      defer(jobs, B, E, E, K.g_dptp, E, refs[1], TEe, lp[D2R_RL_GLAC_TPOOL]);
+      pg.dxg(c, B, E, E, K.g_dpip, E, lp[D2R_RL_GLAC_IPOOL].w, d_other, SEe, 1.f);
+      defer(jobs, B, E, E, K.g_dpip, E, other, SEe, lp[D2R_RL_GLAC_IPOOL]);
+    }
+    if (nc > 5 && !first) {  // dx[5] is a buffer of its own: GESC's text-pool tail joins the launch
+      pg.dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f);
+      defer(jobs, B, E, E, K.s_dap, E, refs[5], TEe, lp[D2R_RL_GESC_TPOOL]);
+    }
+    TRY(pg.flush(c));
+    if (nc > 5) {
+      if (first) {
+        pg.dxg(c, B, E, E, K.s_dap, E, lp[D2R_RL_GESC_TPOOL].w, dx[5], TEe, 1.f);
+        defer(jobs, B, E, E, K.s_dap, E, refs[5], TEe, lp[D2R_RL_GESC_TPOOL]);
+      }
+      pg.dxg(c, B, E, E, K.s_dbp, E, lp[D2R_RL_GESC_IPOOL].w, d_other, SEe, 1.f);
+      defer(jobs, B, E, E, K.s_dbp, E, other, SEe, lp[D2R_RL_GESC_IPOOL]);
+      TRY(pg.flush(c));
+    }
   }
   // --- the query-side projections (the key / value side of every cell and layer is one product at the end of the module): group B4 where
   //     the dx[j] are separate buffers, one after the other in layer 0 -------------------------------------------------------------------------

@@ -520,9 +520,10 @@ class _InteractionBase(D2RModule):
         if bundle is not None:  # K16: the whole module as one C call per direction
             out, paths = F.interaction(own, other, bundle, self.training)
             if self.training:  # BatchNorm1d bookkeeping of the GLAC cells (the running statistics are updated in the call)
-                for layer in [self.dynamic_itr_l0, *self.dynamic_itr_l1, self.dynamic_itr_l2]:
-                    if "glac" in layer.cell_names:
-                        layer.glac.SAF_module.bn.num_batches_tracked += 1
+                counters = [layer.glac.SAF_module.bn.num_batches_tracked for layer in [self.dynamic_itr_l0, *self.dynamic_itr_l1, self.dynamic_itr_l2]
+                            if "glac" in layer.cell_names]
+                if counters:
+                    torch._foreach_add_(counters, 1)  # one launch for the module's counters instead of one each
             paths = F.gather_batch(paths)  # (global-batch-exact data parallelism: the paths of every rank's samples)
             return [out], F.matmul_nt(paths, paths)
         B = text.shape[0]

@@ -187,7 +187,8 @@ def test_same_shape_groups_take_the_wide_kernel_and_match_the_128_wide_one(gpu):
 @pytest.mark.parametrize("layout", [0, 1], ids=["NT", "NN"])
 def test_grouped_launch_of_independent_products_is_bit_identical_to_separate_launches(layout, lowp, gpu):
     """d2r_gemm_group (gemm_glds.hip: independent forward / dX products of the routing cells in one launch of the 128 x 128 LDS-DMA
-    kernel) against one d2r_gemm per problem: every tile is computed exactly as in a launch of its own."""
+    kernel; gemm.hip: up to four per-sample products of at most 32 rows in one launch of the skinny kernel) against one d2r_gemm per
+    problem: every tile is computed exactly as in a launch of its own."""
     from d2r_amd import _lib
     from d2r_amd import functional as F
     from d2r_amd._lib import GemmDesc
@@ -197,7 +198,11 @@ def test_grouped_launch_of_independent_products_is_bit_identical_to_separate_lau
     # a small one that stays out of the group (M < 128), a deep reduction
     specs = [(4096, 2304, 768, True, 0, False, 0.0, 0), (4096, 768, 768, True, 2, False, 0.0, 0), (4096, 768, 768, True, 1, True, 0.0, 0),
              (6304, 768, 768, False, 0, False, 1.0, 0), (6304, 768, 768, True, 0, True, 1.0, 0), (300, 136, 128, True, 3, False, 0.0, 0),
-             (64, 768, 768, True, 0, False, 0.0, 0), (4096, 768, 3072, False, 0, False, 0.0, 1)]
+             (64, 768, 768, True, 0, False, 0.0, 0), (4096, 768, 3072, False, 0, False, 0.0, 1),
+             # per-sample products (at most 32 rows: the skinny kernel): five of them = one group of four + one launch of its own;
+             # tanh epilogue, an accumulating tail, the activation gradient of a reference, a 17-row one (two row tiles, ragged)
+             (32, 768, 768, True, 2, False, 0.0, 0), (32, 768, 768, True, 0, False, 1.0, 0), (32, 768, 768, False, 0, False, 0.0, 2),
+             (17, 768, 1536, True, 0, True, 0.0, 0), (32, 1536, 768, True, 2, False, 0.0, 0)]
     ops = []
     for M, N, K, hb, act, hr, beta, gact in specs:
         a = (torch.randn(M, K, device=gpu, generator=g) * 0.5).to(lowp)
