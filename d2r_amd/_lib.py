@@ -156,8 +156,8 @@ SIGNATURES = {
     "d2r_saf_dscores": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "d2r_saf_gate_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "d2r_saf_gate_stats": (i32, [vp, i32, i32, vp, vp]),
-    "d2r_saf_gate_fwd_ex": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double, vp]),
-    "d2r_saf_gate_bwd_ex": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, C.c_double, vp]),
+    "d2r_saf_gate_fwd_ex": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double, vp, i32, vp]),
+    "d2r_saf_gate_bwd_ex": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, C.c_double, vp, i32, i32, vp]),
     "d2r_jsdiv_fwd": (i32, [vp, vp, i32, vp, vp]),
     "d2r_jsdiv_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp]),
     "d2r_ce_fwd": (i32, [vp, vp, i32, i32, vp, vp]),

@@ -379,11 +379,12 @@ int layer_fwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     if (c.bn.fn && train) {  // statistics over the samples of every rank: local sums, the caller's all-reduce, then the gate
       TRY(d2r_saf_gate_stats(L.g_a, B, n, c.bn.buf, c.st));
       if (c.bn.fn(c.bn.user, c.bn.buf, c.st)) return d2r_fail(D2R_ERR_INVALID, "d2r_interaction_fwd: bn_sync failed");
-      TRY(d2r_saf_gate_fwd_ex(L.g_a, B, n, p.bn_weight, p.bn_bias, p.bn_running_mean, p.bn_running_var, train, L.g_w, L.g_saved, c.bn.buf, c.bn.ntotal, c.st));
-    } else {
-      TRY(d2r_saf_gate_fwd(L.g_a, B, n, p.bn_weight, p.bn_bias, p.bn_running_mean, p.bn_running_var, train, L.g_w, L.g_saved, c.st));
+      TRY(d2r_saf_gate_fwd_ex(L.g_a, B, n, p.bn_weight, p.bn_bias, p.bn_running_mean, p.bn_running_var, train, L.g_w, L.g_saved, c.bn.buf, c.bn.ntotal,
+                              L.g_w16, c.dt, c.st));
+    } else {  // (the gate also leaves the 16-bit copy of w that the weighted sum below reads as a GEMM operand)
+      TRY(d2r_saf_gate_fwd_ex(L.g_a, B, n, p.bn_weight, p.bn_bias, p.bn_running_mean, p.bn_running_var, train, L.g_w, L.g_saved, nullptr, 0.0, L.g_w16,
+                              c.dt, c.st));
     }
-    TRY(d2r_cast(D2R_F32, L.g_w, c.dt, L.g_w16, (int64_t)B * n, c.st));
     G g(c.dt, c.dt, D2R_GEMM_NN, 1, E, n, L.g_w16, n, L.g_S, E, L.g_wsum, E);  // wsum[b] = w[b] @ S[b]
     g.batch(B, n, (int64_t)n * E, E);
     TRY(d2r_gemm(&g.d, c.st));
@@ -532,15 +533,15 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     // d w[b] = d wsum[b] S[b]^T (fp32), the gate's backward, then d S[b] = w[b]^T d wsum[b] + d a w_saf in ONE pass (rank-one products)
     TRY(d2r_saf_dweights(c.dt, K.g_dwsum, L.g_S, B, n, E, K.g_dwf, c.st));
     if (c.bn.fn && train) {
-      TRY(d2r_saf_gate_bwd_ex(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, K.bn2, K.bn2 + 1, 1, c.bn.buf + 2, c.bn.ntotal, c.st));
+      TRY(d2r_saf_gate_bwd_ex(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, p.g_bn_weight, p.g_bn_bias, 1, c.bn.buf + 2,
+                              c.bn.ntotal, nullptr, 0, 1, c.st));
       if (c.bn.fn(c.bn.user, c.bn.buf + 2, c.st)) return d2r_fail(D2R_ERR_INVALID, "d2r_interaction_bwd: bn_sync failed");
-      TRY(d2r_saf_gate_bwd_ex(L.g_a, nullptr, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, nullptr, nullptr, 2, c.bn.buf + 2, c.bn.ntotal, c.st));
-    } else {
-      TRY(d2r_saf_gate_bwd(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, K.bn2, K.bn2 + 1, c.st));
+      TRY(d2r_saf_gate_bwd_ex(L.g_a, nullptr, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, nullptr, nullptr, 2, c.bn.buf + 2, c.bn.ntotal,
+                              K.g_da16, c.dt, 0, c.st));
+    } else {  // BatchNorm parameter gradients straight into their sinks; da also as the 16-bit operand of attn_sim_w's weight gradient
+      TRY(d2r_saf_gate_bwd_ex(L.g_a, K.g_dwf, B, n, p.bn_weight, p.bn_bias, L.g_saved, train, K.g_daf, p.g_bn_weight, p.g_bn_bias, 0, nullptr, 0.0,
+                              K.g_da16, c.dt, 1, c.st));
     }
-    TRY(acc32(c, K.bn2, p.g_bn_weight, 1));
-    TRY(acc32(c, K.bn2 + 1, p.g_bn_bias, 1));
-    TRY(d2r_cast(D2R_F32, K.g_daf, c.dt, K.g_da16, (int64_t)B * n, c.st));  // (the weight gradient of attn_sim_w below reads it as a GEMM operand)
     TRY(d2r_saf_dscores(c.dt, L.g_w16, K.g_dwsum, K.g_daf, lp[D2R_RL_GLAC_SAFW].w, B, n, E, K.g_dS, c.st));
     TRY(dwg(c, B * n, 1, E, K.g_da16, 1, L.g_S, E, lp[D2R_RL_GLAC_SAFW]));
     // split dS: row 0 of every sample = d sg (used in place, row stride n*E), rows 1.. = d sl (made contiguous)

@@ -31,12 +31,18 @@ __global__ __launch_bounds__(1024) void saf_gate_stats_kernel(const float* __res
   }
 }
 
+// 16-bit copy of an fp32 value (same rounding as d2r_cast): the consumers of the gate read it as a GEMM operand
+__device__ __forceinline__ void store16(void* p, int dtype, int64_t i, float v) {
+  if (dtype == D2R_BF16) reinterpret_cast<bf16_t*>(p)[i] = (bf16_t)v;
+  else reinterpret_cast<f16_t*>(p)[i] = (f16_t)v;
+}
+
 __global__ __launch_bounds__(1024) void saf_gate_fwd_kernel(const float* __restrict__ a, int B, int n,
                                                             const float* __restrict__ bn_w,
                                                             const float* __restrict__ bn_b, float* running_mean,
                                                             float* running_var, int train, float* __restrict__ w,
                                                             float* __restrict__ saved, const double* __restrict__ gstats,
-                                                            double ntotal) {
+                                                            double ntotal, void* __restrict__ w16, int w16_dtype) {
   __shared__ float sh[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int N = B * n;
@@ -82,7 +88,9 @@ __global__ __launch_bounds__(1024) void saf_gate_fwd_kernel(const float* __restr
     const float inv = 1.f / (s + 1e-8f);
     for (int k = lane; k < n; k += 64) {
       const float y = (a[b * n + k] - mean) * rstd * gw + gb;
-      w[b * n + k] = inv / (1.f + expf(-y));
+      const float wv = inv / (1.f + expf(-y));
+      w[b * n + k] = wv;
+      if (w16) store16(w16, w16_dtype, b * n + k, wv);
     }
   }
 }
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(1024) void saf_gate_bwd_kernel(const float* __restr
                                                             const float* __restrict__ saved, int train,
                                                             float* __restrict__ da, float* __restrict__ d_bn_w,
                                                             float* __restrict__ d_bn_b, int phase, double* __restrict__ gsums,
-                                                            double ntotal) {
+                                                            double ntotal, void* __restrict__ da16, int da16_dtype, int accumulate) {
   // phase 0: the whole backward with this rank's own sums (local batch statistics).  Global-batch-exact mode: phase 1 stops behind
   // stage 1 (d y in `da`, the LOCAL sums = this rank's share of the BatchNorm parameter gradients, and the fp64 sums for the
   // all-reduce in gsums); phase 2 finishes with the all-reduced sums over the ntotal scores of the global batch.
@@ -105,7 +113,9 @@ __global__ __launch_bounds__(1024) void saf_gate_bwd_kernel(const float* __restr
     const float m1 = (float)(gsums[0] / ntotal), m2 = (float)(gsums[1] / ntotal);
     for (int i = tid; i < N; i += blockDim.x) {
       const float xh = (a[i] - mean) * rstd;
-      da[i] = gw * rstd * (da[i] - m1 - xh * m2);
+      const float v = gw * rstd * (da[i] - m1 - xh * m2);
+      da[i] = v;
+      if (da16) store16(da16, da16_dtype, i, v);
     }
     return;
   }
@@ -136,9 +146,9 @@ __global__ __launch_bounds__(1024) void saf_gate_bwd_kernel(const float* __restr
   }
   const float tdy = block_sum(sdy, sh);
   const float tdyx = block_sum(sdyx, sh);
-  if (tid == 0) {
-    d_bn_w[0] = tdyx;
-    d_bn_b[0] = tdy;
+  if (tid == 0) {  // (accumulate: straight into the caller's fp32 gradient sinks)
+    d_bn_w[0] = accumulate ? d_bn_w[0] + tdyx : tdyx;
+    d_bn_b[0] = accumulate ? d_bn_b[0] + tdy : tdy;
     if (phase == 1) gsums[0] = (double)tdy, gsums[1] = (double)tdyx;
   }
   if (phase == 1) return;
@@ -146,19 +156,22 @@ __global__ __launch_bounds__(1024) void saf_gate_bwd_kernel(const float* __restr
   const float m1 = tdy / (float)N, m2 = tdyx / (float)N;
   for (int i = tid; i < N; i += blockDim.x) {
     const float dy = da[i];
+    float v;
     if (train) {
       const float xh = (a[i] - mean) * rstd;
-      da[i] = gw * rstd * (dy - m1 - xh * m2);
+      v = gw * rstd * (dy - m1 - xh * m2);
     } else {
-      da[i] = gw * rstd * dy;
+      v = gw * rstd * dy;
     }
+    da[i] = v;
+    if (da16) store16(da16, da16_dtype, i, v);
   }
 }
 
 extern "C" int d2r_saf_gate_fwd(const float* a, int B, int n, const float* bn_weight, const float* bn_bias,
                                 float* running_mean, float* running_var, int train, float* w, float* saved,
                                 void* stream) {
-  return d2r_saf_gate_fwd_ex(a, B, n, bn_weight, bn_bias, running_mean, running_var, train, w, saved, nullptr, 0.0, stream);
+  return d2r_saf_gate_fwd_ex(a, B, n, bn_weight, bn_bias, running_mean, running_var, train, w, saved, nullptr, 0.0, nullptr, 0, stream);
 }
 
 extern "C" int d2r_saf_gate_stats(const float* a, int B, int n, double* sums, void* stream) {
@@ -169,29 +182,31 @@ extern "C" int d2r_saf_gate_stats(const float* a, int B, int n, double* sums, vo
 
 extern "C" int d2r_saf_gate_fwd_ex(const float* a, int B, int n, const float* bn_weight, const float* bn_bias, float* running_mean,
                                    float* running_var, int train, float* w, float* saved, const double* gstats, double ntotal,
-                                   void* stream) {
+                                   void* w16, int w16_dtype, void* stream) {
+  D2R_REQUIRE(!w16 || d2r_is16(w16_dtype), "d2r_saf_gate_fwd_ex: the copy of w is bf16 or fp16");
   D2R_REQUIRE(a && bn_weight && bn_bias && running_mean && running_var && w && saved, "d2r_saf_gate_fwd: null pointer");
   D2R_REQUIRE(B >= 1 && n >= 1, "d2r_saf_gate_fwd: bad shape");
   D2R_REQUIRE(!gstats || ntotal >= (double)B * n, "d2r_saf_gate_fwd: the global element count is smaller than this rank's");
   hipLaunchKernelGGL(saf_gate_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, B, n, bn_weight, bn_bias,
-                     running_mean, running_var, train, w, saved, gstats, ntotal);
+                     running_mean, running_var, train, w, saved, gstats, ntotal, w16, w16_dtype);
   return d2r_check_launch("d2r_saf_gate_fwd");
 }
 
 extern "C" int d2r_saf_gate_bwd(const float* a, const float* dw, int B, int n, const float* bn_weight,
                                 const float* bn_bias, const float* saved, int train, float* da, float* d_bn_weight,
                                 float* d_bn_bias, void* stream) {
-  return d2r_saf_gate_bwd_ex(a, dw, B, n, bn_weight, bn_bias, saved, train, da, d_bn_weight, d_bn_bias, 0, nullptr, 0.0, stream);
+  return d2r_saf_gate_bwd_ex(a, dw, B, n, bn_weight, bn_bias, saved, train, da, d_bn_weight, d_bn_bias, 0, nullptr, 0.0, nullptr, 0, 0, stream);
 }
 
 extern "C" int d2r_saf_gate_bwd_ex(const float* a, const float* dw, int B, int n, const float* bn_weight, const float* bn_bias,
                                    const float* saved, int train, float* da, float* d_bn_weight, float* d_bn_bias, int phase,
-                                   double* gsums, double ntotal, void* stream) {
+                                   double* gsums, double ntotal, void* da16, int da16_dtype, int accumulate, void* stream) {
+  D2R_REQUIRE(!da16 || d2r_is16(da16_dtype), "d2r_saf_gate_bwd_ex: the copy of da is bf16 or fp16");
   D2R_REQUIRE(a && bn_weight && bn_bias && saved && da && (phase == 2 || (dw && d_bn_weight && d_bn_bias)), "d2r_saf_gate_bwd: null pointer");
   D2R_REQUIRE(B >= 1 && n >= 1, "d2r_saf_gate_bwd: bad shape");
   D2R_REQUIRE(phase == 0 || (phase >= 1 && phase <= 2 && gsums && train && ntotal >= (double)B * n), "d2r_saf_gate_bwd: bad phase / global sums");
   hipLaunchKernelGGL(saf_gate_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, dw, B, n, bn_weight, bn_bias,
-                     saved, train, da, d_bn_weight, d_bn_bias, phase, gsums, ntotal);
+                     saved, train, da, d_bn_weight, d_bn_bias, phase, gsums, ntotal, da16, da16_dtype, accumulate);
   return d2r_check_launch("d2r_saf_gate_bwd");
 }
 

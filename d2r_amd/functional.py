@@ -1632,7 +1632,7 @@ class _SafGate(torch.autograd.Function):
             _lib.call("d2r_saf_gate_stats", a.data_ptr(), B, n, sums.data_ptr(), _stream())
             _allreduce_pair(sums)
             _lib.call("d2r_saf_gate_fwd_ex", a.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(), running_mean.data_ptr(),
-                      running_var.data_ptr(), 1, w.data_ptr(), saved.data_ptr(), sums.data_ptr(), float(DP_EXACT[1] * B * n), _stream())
+                      running_var.data_ptr(), 1, w.data_ptr(), saved.data_ptr(), sums.data_ptr(), float(DP_EXACT[1] * B * n), None, 0, _stream())
         else:
             _lib.call("d2r_saf_gate_fwd", a.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(), running_mean.data_ptr(),
                       running_var.data_ptr(), 1 if train else 0, w.data_ptr(), saved.data_ptr(), _stream())
@@ -1651,10 +1651,10 @@ class _SafGate(torch.autograd.Function):
             gs = torch.empty(2, dtype=torch.float64, device=a.device)
             nt = float(DP_EXACT[1] * B * n)
             _lib.call("d2r_saf_gate_bwd_ex", a.data_ptr(), dw.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(), saved.data_ptr(), 1,
-                      da.data_ptr(), dbw.data_ptr(), dbb.data_ptr(), 1, gs.data_ptr(), nt, _stream())
+                      da.data_ptr(), dbw.data_ptr(), dbb.data_ptr(), 1, gs.data_ptr(), nt, None, 0, 0, _stream())
             _allreduce_pair(gs)
             _lib.call("d2r_saf_gate_bwd_ex", a.data_ptr(), None, B, n, bn_w.data_ptr(), bn_b.data_ptr(), saved.data_ptr(), 1,
-                      da.data_ptr(), None, None, 2, gs.data_ptr(), nt, _stream())
+                      da.data_ptr(), None, None, 2, gs.data_ptr(), nt, None, 0, 0, _stream())
             return da, dbw, dbb, None, None, None
         _lib.call("d2r_saf_gate_bwd", a.data_ptr(), dw.data_ptr(), B, n, bn_w.data_ptr(), bn_b.data_ptr(),
                   saved.data_ptr(), 1 if ctx.train else 0, da.data_ptr(), dbw.data_ptr(), dbb.data_ptr(), _stream())

@@ -258,11 +258,15 @@ int d2r_saf_gate_bwd(const float* a, const float* dw, int B, int n, const float*
  * parameter gradients in d_bn_weight / d_bn_bias, fp64 {sum dy, sum dy*xhat} in gsums); after the all-reduce phase 2 finishes `da`
  * with the global sums.  gstats = NULL / phase 0: local-batch statistics (= d2r_saf_gate_fwd / _bwd). */
 int d2r_saf_gate_stats(const float* a, int B, int n, double* sums, void* stream);
+/* w16 / da16 (optional): a bf16 / fp16 copy of w (forward) and of the finished da (backward: phase 0 or 2), rounded as d2r_cast would -
+ * their consumers read them as GEMM operands.  accumulate != 0: the BatchNorm parameter gradients are ADDED to d_bn_weight / d_bn_bias
+ * (the caller's fp32 gradient sinks) instead of overwriting them. */
 int d2r_saf_gate_fwd_ex(const float* a, int B, int n, const float* bn_weight, const float* bn_bias, float* running_mean,
-                        float* running_var, int train, float* w, float* saved, const double* gstats, double ntotal, void* stream);
+                        float* running_var, int train, float* w, float* saved, const double* gstats, double ntotal, void* w16,
+                        int w16_dtype, void* stream);
 int d2r_saf_gate_bwd_ex(const float* a, const float* dw, int B, int n, const float* bn_weight, const float* bn_bias,
                         const float* saved, int train, float* da, float* d_bn_weight, float* d_bn_bias, int phase, double* gsums,
-                        double ntotal, void* stream);
+                        double ntotal, void* da16, int da16_dtype, int accumulate, void* stream);
 
 /* The two rank-one products around the gate in the BACKWARD pass of the SAF-weighted sum wsum[b] = w[b] @ S[b]
  * (models/XModules.py:382-384; S [B,n,E], 16-bit): dw[b,i] = <dwsum[b,:], S[b,i,:]> (fp32 [B,n]) and
