@@ -144,6 +144,7 @@ SIGNATURES = {
     "d2r_cast": (i32, [i32, vp, i32, vp, i64, vp]),
     "d2r_colsum_workspace": (sz, [i64, i32]),
     "d2r_colsum": (i32, [i32, vp, i64, i64, i32, vp, vp, sz, vp]),
+    "d2r_colsum_add": (i32, [i32, vp, i64, i64, i32, vp, vp, sz, vp]),
     "d2r_meanpool_fwd": (i32, [i32, C.POINTER(vp), i32, i32, i32, i32, vp, vp]),
     "d2r_meanpool_bwd_multi": (i32, [i32, vp, i32, i32, i32, i32, C.POINTER(vp), C.c_uint, vp]),
     "d2r_meanpool_bwd": (i32, [i32, vp, i32, i32, i32, vp, i32, vp]),

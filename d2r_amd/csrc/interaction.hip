@@ -504,8 +504,12 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
     gw.batch(nc, P, hid, (int64_t)P * hid);
     gw.d.beta = 1.f;
     TRY(d2r_gemm(&gw.d, c.st));
-    TRY(d2r_colsum(D2R_F32, K.dG, (int64_t)nc * P, B, nc * P, K.cs2, K.cws, K.cws_bytes, c.st));
-    TRY(acc32(c, K.cs2, lp[D2R_RL_R2].gb, (int64_t)nc * P));
+    if (B <= 32) {  // (one row slice: the column sums go straight into the bias gradient)
+      TRY(d2r_colsum_add(D2R_F32, K.dG, (int64_t)nc * P, B, nc * P, lp[D2R_RL_R2].gb, K.cws, K.cws_bytes, c.st));
+    } else {
+      TRY(d2r_colsum(D2R_F32, K.dG, (int64_t)nc * P, B, nc * P, K.cs2, K.cws, K.cws_bytes, c.st));
+      TRY(acc32(c, K.cs2, lp[D2R_RL_R2].gb, (int64_t)nc * P));
+    }
     TRY(d2r_act_bwd(D2R_F32, D2R_ACT_RELU, K.dh, L.h, K.dhp, (int64_t)B * nc * hid, c.st));
     if (first) {
       TRY(dxg(c, B, E, nc * hid, K.dhp, (int64_t)nc * hid, lp[D2R_RL_R0].w, K.dpooled, E, 0.f, nullptr, nullptr, D2R_ACT_NONE, D2R_F32));
@@ -519,8 +523,12 @@ int layer_bwd(const Ctx& c, const Dims& d, const d2r_routing_layer_params& p, in
       gw0.batch(nc, hid, (int64_t)B * E, (int64_t)hid * E);
       gw0.d.beta = 1.f;
       TRY(d2r_gemm(&gw0.d, c.st));
-      TRY(d2r_colsum(D2R_F32, K.dhp, (int64_t)nc * hid, B, nc * hid, K.cs0, K.cws, K.cws_bytes, c.st));
-      TRY(acc32(c, K.cs0, lp[D2R_RL_R0].gb, (int64_t)nc * hid));
+      if (B <= 32) {
+        TRY(d2r_colsum_add(D2R_F32, K.dhp, (int64_t)nc * hid, B, nc * hid, lp[D2R_RL_R0].gb, K.cws, K.cws_bytes, c.st));
+      } else {
+        TRY(d2r_colsum(D2R_F32, K.dhp, (int64_t)nc * hid, B, nc * hid, K.cs0, K.cws, K.cws_bytes, c.st));
+        TRY(acc32(c, K.cs0, lp[D2R_RL_R0].gb, (int64_t)nc * hid));
+      }
       // dx[0] already holds the aggregation's gradient (and, in the final layer, every dx[j] the skip-path gradient)
       TRY(d2r_meanpool_bwd_multi(c.dt, K.dpooled, nc, B, d.Lq, E, dx, final ? 0xffu : 1u, c.st));  // (one launch for the nc inputs)
     }

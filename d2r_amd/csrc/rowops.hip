@@ -654,18 +654,19 @@ extern "C" int d2r_l2norm_bwd(int dtype, const void* dY, const void* X, const fl
 // =====================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ld, int64_t M, int N,
-                                                     float* __restrict__ ws) {
+                                                     float* __restrict__ ws, float* __restrict__ direct, int accumulate) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= N) return;
   float s = 0.f;
   for (int64_t m = blockIdx.y; m < M; m += gridDim.y) s += to_f<T>(X[m * ld + c]);
-  ws[(int64_t)blockIdx.y * N + c] = s;
+  if (direct) direct[c] = accumulate ? direct[c] + s : s;  // (one slice: the partial IS the sum)
+  else ws[(int64_t)blockIdx.y * N + c] = s;
 }
 
 // vectorised variant: 256 threads = 64 column packs (1 KiB contiguous per row and wave) x 4 row groups
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ X, int64_t ld, int64_t M, int N,
-                                                         float* __restrict__ ws) {
+                                                         float* __restrict__ ws, float* __restrict__ direct, int accumulate) {
   constexpr int VEC = PackOf<T>::N;
   __shared__ float sh[4][64 * VEC];
   const int pk = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -687,7 +688,10 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ X
   __syncthreads();
   for (int c = threadIdx.x; c < 64 * VEC; c += 256) {
     const int col = blockIdx.x * 64 * VEC + c;
-    if (col < N) ws[(int64_t)blockIdx.y * N + col] = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c];
+    if (col >= N) continue;
+    const float t = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c];
+    if (direct) direct[col] = accumulate ? direct[col] + t : t;
+    else ws[(int64_t)blockIdx.y * N + col] = t;
   }
 }
 
@@ -698,28 +702,42 @@ static int colsum_slices(int64_t M) {
 
 extern "C" size_t d2r_colsum_workspace(int64_t M, int N) { return (size_t)colsum_slices(M) * N * sizeof(float); }
 
-extern "C" int d2r_colsum(int dtype, const void* X, int64_t ld, int64_t M, int N, float* out, void* workspace,
-                          size_t workspace_bytes, void* stream) {
-  D2R_REQUIRE(X && out, "d2r_colsum: null pointer");
-  D2R_REQUIRE(ld >= N && M >= 0 && N >= 1, "d2r_colsum: bad shape");
+static int colsum_run(const char* fn, int dtype, const void* X, int64_t ld, int64_t M, int N, float* out, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  D2R_REQUIRE(X && out, "%s: null pointer", fn);
+  D2R_REQUIRE(ld >= N && M >= 0 && N >= 1, "%s: bad shape", fn);
   if (!workspace || workspace_bytes < d2r_colsum_workspace(M, N))
-    return d2r_fail(D2R_ERR_WORKSPACE, "d2r_colsum: workspace %zu < %zu", workspace_bytes, d2r_colsum_workspace(M, N));
+    return d2r_fail(D2R_ERR_WORKSPACE, "%s: workspace %zu < %zu", fn, workspace_bytes, d2r_colsum_workspace(M, N));
   hipStream_t st = (hipStream_t)stream;
   const int S = colsum_slices(M);
+  // one slice of rows (M <= 32: the bias gradients of the per-sample linears, routers and head): its partial sums ARE the result - they
+  // go straight to `out` (added to it on request) instead of through the workspace and a second launch
+  float* direct = S == 1 ? out : nullptr;
+  if (S > 1 && accumulate) return d2r_fail(D2R_ERR_INVALID, "%s: accumulation needs M <= 32 (one row slice)", fn);
   dim3 grid(d2r_cdiv(N, 256), S), block(256);
   float* ws = (float*)workspace;
-  if (dtype != D2R_BF16 && dtype != D2R_F16 && dtype != D2R_F32) return d2r_fail(D2R_ERR_INVALID, "d2r_colsum: bad dtype %d", dtype);
+  if (dtype != D2R_BF16 && dtype != D2R_F16 && dtype != D2R_F32) return d2r_fail(D2R_ERR_INVALID, "%s: bad dtype %d", fn, dtype);
   const int VEC = dtype != D2R_F32 ? 8 : 4;
   const bool vec = d2r_aligned16(X) && (ld * (int64_t)d2r_esize(dtype)) % 16 == 0 && N % VEC == 0;
   if (vec) {
     dim3 gv(d2r_cdiv(N, 64 * VEC), S);
-    if (dtype == D2R_BF16) hipLaunchKernelGGL((colsum_vec_kernel<bf16_t>), gv, block, 0, st, (const bf16_t*)X, ld, M, N, ws);
-    else if (dtype == D2R_F16) hipLaunchKernelGGL((colsum_vec_kernel<f16_t>), gv, block, 0, st, (const f16_t*)X, ld, M, N, ws);
-    else hipLaunchKernelGGL((colsum_vec_kernel<float>), gv, block, 0, st, (const float*)X, ld, M, N, ws);
-  } else if (dtype == D2R_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)X, ld, M, N, ws);
-  else if (dtype == D2R_F16) hipLaunchKernelGGL((colsum_kernel<f16_t>), grid, block, 0, st, (const f16_t*)X, ld, M, N, ws);
-  else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)X, ld, M, N, ws);
-  if (int rc = d2r_check_launch("d2r_colsum")) return rc;
+    if (dtype == D2R_BF16) hipLaunchKernelGGL((colsum_vec_kernel<bf16_t>), gv, block, 0, st, (const bf16_t*)X, ld, M, N, ws, direct, accumulate);
+    else if (dtype == D2R_F16) hipLaunchKernelGGL((colsum_vec_kernel<f16_t>), gv, block, 0, st, (const f16_t*)X, ld, M, N, ws, direct, accumulate);
+    else hipLaunchKernelGGL((colsum_vec_kernel<float>), gv, block, 0, st, (const float*)X, ld, M, N, ws, direct, accumulate);
+  } else if (dtype == D2R_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)X, ld, M, N, ws, direct, accumulate);
+  else if (dtype == D2R_F16) hipLaunchKernelGGL((colsum_kernel<f16_t>), grid, block, 0, st, (const f16_t*)X, ld, M, N, ws, direct, accumulate);
+  else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)X, ld, M, N, ws, direct, accumulate);
+  if (int rc = d2r_check_launch(fn)) return rc;
+  if (direct) return D2R_OK;
   hipLaunchKernelGGL(sum_partials_kernel, dim3(d2r_cdiv(N, 64)), dim3(256), 0, st, ws, S, N, N, out);
   return d2r_check_launch("d2r_colsum(sum)");
+}
+extern "C" int d2r_colsum(int dtype, const void* X, int64_t ld, int64_t M, int N, float* out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  return colsum_run("d2r_colsum", dtype, X, ld, M, N, out, 0, workspace, workspace_bytes, stream);
+}
+// out[n] += sum_m X[m, n] for M <= 32 rows: a bias gradient added straight into its fp32 sink (one launch instead of three)
+extern "C" int d2r_colsum_add(int dtype, const void* X, int64_t ld, int64_t M, int N, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  return colsum_run("d2r_colsum_add", dtype, X, ld, M, N, out, 1, workspace, workspace_bytes, stream);
 }

@@ -199,6 +199,9 @@ int d2r_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n
 size_t d2r_colsum_workspace(int64_t M, int N);
 int d2r_colsum(int dtype, const void* X, int64_t ld, int64_t M, int N, float* out, void* workspace,
                size_t workspace_bytes, void* stream);
+/* out[n] += sum_m X[m, n] for M <= 32 rows (one row slice): the bias gradient of a per-sample linear added straight into its fp32 sink */
+int d2r_colsum_add(int dtype, const void* X, int64_t ld, int64_t M, int N, float* out, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K1  router pooling  (models/Router.py:23: x.mean(-2));  pooled: fp32 [B, D]

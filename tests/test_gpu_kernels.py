@@ -1099,3 +1099,33 @@ def test_dual_elementwise_launches_equal_two_single_launches(gpu, dtype):
         _lib.call("d2r_add2", dt, t[0].data_ptr(), t[1].data_ptr(), p1.data_ptr(), t[2].data_ptr(), t[1].data_ptr(), p2.data_ptr(), n, st)
         torch.cuda.synchronize()
         assert torch.equal(o1, p1) and torch.equal(o2, p2), (n, off, "add2")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "fp16"])
+def test_column_sums_small_and_large_row_counts_and_accumulation(gpu, dtype):
+    """d2r_colsum over at most 32 rows writes its single slice of partial sums straight to the output (one launch); more rows go through the
+    workspace and the fixed-order second stage; d2r_colsum_add adds the sums of at most 32 rows into an fp32 sink (the bias gradients of
+    the routers) and refuses more rows.  Against fp64 column sums; vectorised and scalar paths (N a multiple of the pack width or not)."""
+    from d2r_amd import _lib
+    from d2r_amd import functional as F
+    dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype]
+    st = F._stream()
+    g = torch.Generator(device=gpu).manual_seed(12)
+    lib = _lib.load()
+    for M, N, ld in ((32, 768, 768), (17, 1003, 1010), (1, 64, 64), (200, 768, 768), (4096, 136, 144)):
+        x = torch.randn(M, ld, device=gpu, generator=g).to(dtype)
+        ws = torch.empty(lib.d2r_colsum_workspace(M, N), dtype=torch.uint8, device=gpu)
+        out = torch.full((N,), 7.0, device=gpu)
+        _lib.call("d2r_colsum", dt, x.data_ptr(), ld, M, N, out.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        ref = x[:, :N].double().sum(0)
+        tol = 1e-6 * (M ** 0.5) * float(x[:, :N].double().abs().max()) * M ** 0.5 + 1e-6
+        assert float((out.double() - ref).abs().max()) <= tol, (M, N, "colsum")
+        sink = torch.randn(N, device=gpu, generator=g)
+        s0 = sink.clone()
+        if M <= 32:
+            _lib.call("d2r_colsum_add", dt, x.data_ptr(), ld, M, N, sink.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            torch.cuda.synchronize()
+            assert torch.equal(sink, s0 + out), (M, N, "colsum_add is sink + colsum, one fp32 add per column")
+        else:
+            with pytest.raises(_lib.D2RError):
+                _lib.call("d2r_colsum_add", dt, x.data_ptr(), ld, M, N, sink.data_ptr(), ws.data_ptr(), ws.numel(), st)
